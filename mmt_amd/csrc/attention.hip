@@ -1,0 +1,453 @@
+// Fused masked-softmax attention of the video-BERT, forward and backward (gfx950, head dim 128).
+// Replaces bert.py:141-168 (QK^T/sqrt(dh) + additive -10000 key mask -> softmax -> dropout -> .V ->
+// merge heads) and its autograd backward; the (B,H,S,S) probability tensor is never materialised.
+//
+// Layout: qkv bf16 [rows, 3d] = [Q | K | V] from the fused QKV GEMM, head h at columns h*128 of each
+// section; sample b owns rows cu[b]..cu[b+1] (dense: b*S..).  ctx bf16 [rows, d].
+//
+// All three kernels use the "swapped" MFMA form so that the softmax row (one query) is lane-local:
+//   S^T[key][q] = K . Q^T            a = K fragment (ds_read_b128), b = Q fragment (registers)
+//   O^T[d][q]  += V^T . P^T          a = V^T fragment (ds_read_b64_tr_b16 from the row-major V tile)
+// A lane (q = lane&15, g = lane>>4) then holds scores for keys 16f + 4g + r, and after bf16 packing those
+// registers ARE the b-operand of the second MFMA (k-index permutation kappa(g,j) shared with the
+// transpose read), so P never leaves registers.
+// 64x128 bf16 tiles live in LDS as 256-B rows whose 16-B chunks are XOR-swizzled with
+// SWZ16(row) = ((row&7)<<1)|((row>>3)&1): conflict-free for both the b128 (row-per-lane) and the
+// transpose reads.  Tiles arrive by LDS-DMA with the swizzle applied on the source address.
+//
+// Dropout mask of element (b,h,q,k): hash of (key, (b*H+h)*S4+q) then of (k>>1); q,k are positions
+// inside the sample's (packed) sequence.  Backward regenerates it.
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define NEG_BIG (-1.0e30f)
+
+__device__ __forceinline__ int swz16(int r) { return ((r & 7) << 1) | ((r >> 3) & 1); }
+
+__device__ __forceinline__ void stage64x128(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_last,
+                                            bf16_t* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rbase = (wave * 4 + i) * 4;
+    const int rr = rbase + (lane >> 4);
+    const int c = (lane & 15) ^ swz16(rr);
+    const int gr = min(row0 + rr, row_last);
+    const bf16_t* src = G + (int64_t)gr * ld + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * 128), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8_t frag_b128(const bf16_t* tile, int r, int chunk) {
+  return *(const bf16x8_t*)(tile + r * 128 + ((chunk ^ swz16(r)) << 3));
+}
+
+// 8 contraction values (rows kappa(g,.) of k-chunk ks) for column colbase + (lane&15)
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tile, int ks, int colbase, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  const int col = colbase + 4 * (t & 3);
+  const int r0 = ks * 32 + 4 * g + (t >> 2), r1 = r0 + 16;
+  const int ch = col >> 3, w = col & 7;
+  const bf16_t* p0 = tile + r0 * 128 + ((ch ^ swz16(r0)) << 3) + w;
+  const bf16_t* p1 = tile + r1 * 128 + ((ch ^ swz16(r1)) << 3) + w;
+  bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p0));
+  bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x4& a, const f32x4& b) {
+  u32x4 u = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+__device__ __forceinline__ unsigned attn_rowkey(unsigned key, unsigned bh, unsigned S4, unsigned q) {
+  return mix32(key ^ ((bh * S4 + q) * 0x9e3779b9U));
+}
+__device__ __forceinline__ bool attn_keep(unsigned rowkey, unsigned k, unsigned thr16) {
+  const unsigned r = mix32(rowkey ^ (k >> 1));
+  return ((k & 1) ? (r >> 16) : (r & 0xffffU)) >= thr16;
+}
+
+struct AttnArgs {
+  const bf16_t* qkv; int64_t ld;       // [rows, 3d]
+  const int32_t* cu; int S_dense;      // cu nullable => dense b*S_dense
+  const float* mask_bias;              // [rows] 0 / -10000 (additive, bert.py:395)
+  bf16_t* ctx; int64_t ldc;            // [rows, d]   (fwd: out; bwd: in)
+  float* lse;                          // [rows, H] natural-log logsumexp of the scaled+masked scores
+  const bf16_t* dctx;                  // [rows, d] bwd
+  bf16_t* dqkv;                        // [rows, 3d] bwd out
+  float* delta;                        // [rows, H] bwd scratch: rowsum(dO * O)
+  int H, d; float scale;
+  uint32_t drop_key, thr16; float drop_scale; int S4;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (q tiles of 64, H, B), 4 waves x 16 queries
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 64 * 2];
+  float* bias_s = (float*)(smem + 2 * 2 * 64 * 128);  // [2][64]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int off = a.cu ? a.cu[b] : b * a.S_dense;
+  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= Sb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int row_last = off + Sb - 1;
+  const int nkt = (Sb + 63) >> 6;
+  const bf16_t* Kg = a.qkv + a.d + h * 128;
+  const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
+
+  const int q_local = q0 + wave * 16 + li;
+  const int qrow = off + min(q_local, Sb - 1);
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
+  const unsigned rowkey = attn_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
+  const float c1 = a.scale * LOG2E;
+
+  f32x4 o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  auto stage = [&](int kt, int st) {
+    bf16_t* base = smem + st * (2 * 64 * 128);
+    stage64x128(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
+    stage64x128(Vg, a.ld, off + kt * 64, row_last, base + 64 * 128, wave, lane);
+    if (tid < 64) {
+      const int k = kt * 64 + tid;
+      bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const bf16_t* Ks = smem + cur * (2 * 64 * 128);
+    const bf16_t* Vs = Ks + 64 * 128;
+    f32x4 s[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
+    }
+    float mt = NEG_BIG;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const f32x4 bv = *(const f32x4*)(bias_s + cur * 64 + f * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[f][r] = s[f][r] * c1 + bv[r]; mt = fmaxf(mt, s[f][r]); }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[f][r] = exp2f(s[f][r] - m_new); psum += s[f][r]; }
+      if (a.thr16) {
+        const unsigned k0 = (unsigned)(kt * 64 + f * 16 + 4 * lg);
+        const unsigned r01 = mix32(rowkey ^ (k0 >> 1)), r23 = mix32(rowkey ^ ((k0 >> 1) + 1));
+        s[f][0] = (r01 & 0xffffU) >= a.thr16 ? s[f][0] * a.drop_scale : 0.f;
+        s[f][1] = (r01 >> 16) >= a.thr16 ? s[f][1] * a.drop_scale : 0.f;
+        s[f][2] = (r23 & 0xffffU) >= a.thr16 ? s[f][2] * a.drop_scale : 0.f;
+        s[f][3] = (r23 >> 16) >= a.thr16 ? s[f][3] * a.drop_scale : 0.f;
+      }
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] *= alpha;
+    const bf16x8_t pb0 = pack8(s[0], s[1]), pb1 = pack8(s[2], s[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 0, fd * 16, lane), pb0, o[fd], 0, 0, 0);
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 1, fd * 16, lane), pb1, o[fd], 0, 0, 0);
+    }
+  }
+  if (q_local < Sb) {
+    const float inv = 1.0f / l_run;
+    bf16_t* dst = a.ctx + (int64_t)qrow * a.ldc + h * 128 + 4 * lg;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2 v = {pack_bf2(o[fd][0] * inv, o[fd][1] * inv), pack_bf2(o[fd][2] * inv, o[fd][3] * inv)};
+      *(u32x2*)(dst + fd * 16) = v;
+    }
+    if (lg == 0) a.lse[(int64_t)qrow * a.H + h] = (m_run + log2f(l_run)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: dQ (+ delta).  Same tiling as forward: grid (q tiles, H, B).
+//   dA^T[key][q] = V . dO^T ; dS = P o (keep*dA*sc - delta) ; dQ^T[d][q] += K^T . dS^T
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 64 * 2];
+  float* bias_s = (float*)(smem + 2 * 2 * 64 * 128);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int off = a.cu ? a.cu[b] : b * a.S_dense;
+  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= Sb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int row_last = off + Sb - 1;
+  const int nkt = (Sb + 63) >> 6;
+  const bf16_t* Kg = a.qkv + a.d + h * 128;
+  const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
+  const int q_local = q0 + wave * 16 + li;
+  const bool q_ok = q_local < Sb;
+  const int qrow = off + min(q_local, Sb - 1);
+  bf16x8_t qf[4], dof[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
+    const u16x8 dv = *(const u16x8*)(a.dctx + (int64_t)qrow * a.ldc + h * 128 + kk * 32 + lg * 8);
+    const u16x8 ov = *(const u16x8*)(a.ctx + (int64_t)qrow * a.ldc + h * 128 + kk * 32 + lg * 8);
+    dof[kk] = __builtin_bit_cast(bf16x8_t, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f(dv[e]) * bf2f(ov[e]);
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  if (q_ok && lg == 0) a.delta[(int64_t)qrow * a.H + h] = dl;
+  const float lse2 = a.lse[(int64_t)qrow * a.H + h] * LOG2E;
+  const unsigned rowkey = attn_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
+  const float c1 = a.scale * LOG2E;
+
+  f32x4 o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int st) {
+    bf16_t* base = smem + st * (2 * 64 * 128);
+    stage64x128(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
+    stage64x128(Vg, a.ld, off + kt * 64, row_last, base + 64 * 128, wave, lane);
+    if (tid < 64) {
+      const int k = kt * 64 + tid;
+      bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const bf16_t* Ks = smem + cur * (2 * 64 * 128);
+    const bf16_t* Vs = Ks + 64 * 128;
+    f32x4 s[4], da[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
+        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Vs, f * 16 + li, kk * 4 + lg), dof[kk], da[f], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const f32x4 bv = *(const f32x4*)(bias_s + cur * 64 + f * 16 + 4 * lg);
+      const unsigned k0 = (unsigned)(kt * 64 + f * 16 + 4 * lg);
+      unsigned r01 = 0xffffffffU, r23 = 0xffffffffU;
+      if (a.thr16) { r01 = mix32(rowkey ^ (k0 >> 1)); r23 = mix32(rowkey ^ ((k0 >> 1) + 1)); }
+      const unsigned u[4] = {r01 & 0xffffU, r01 >> 16, r23 & 0xffffU, r23 >> 16};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s[f][r] * c1 + bv[r] - lse2);
+        const float dp = (u[r] >= a.thr16) ? da[f][r] * a.drop_scale : 0.f;
+        s[f][r] = p * (dp - dl);  // dS
+      }
+    }
+    const bf16x8_t sb0 = pack8(s[0], s[1]), sb1 = pack8(s[2], s[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 0, fd * 16, lane), sb0, o[fd], 0, 0, 0);
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 1, fd * 16, lane), sb1, o[fd], 0, 0, 0);
+    }
+  }
+  if (q_ok) {
+    bf16_t* dst = a.dqkv + (int64_t)qrow * a.ld + h * 128 + 4 * lg;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2 v = {pack_bf2(o[fd][0] * a.scale, o[fd][1] * a.scale), pack_bf2(o[fd][2] * a.scale, o[fd][3] * a.scale)};
+      *(u32x2*)(dst + fd * 16) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV.  grid (key tiles of 64, H, B); each wave owns 16 keys, loops over q tiles.
+//   S[q][key] = Q . K^T (a = Q frag from LDS, b = K frag in registers) ; dA = dO . V^T
+//   dV^T[d][key] += dO^T . A ; dK^T[d][key] += Q^T . dS     (a = transpose reads of the dO / Q tiles)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 3 * 64 * 2];
+  float* aux_s = (float*)(smem + 2 * 2 * 64 * 128);  // [2][3][64]: lse2, delta, rowkey(bits)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int off = a.cu ? a.cu[b] : b * a.S_dense;
+  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
+  const int k0 = blockIdx.x * 64;
+  if (k0 >= Sb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int row_last = off + Sb - 1;
+  const int nqt = (Sb + 63) >> 6;
+  const bf16_t* Qg = a.qkv + h * 128;
+  const bf16_t* dOg = a.dctx + h * 128;
+  const int key_local = k0 + wave * 16 + li;
+  const bool key_ok = key_local < Sb;
+  const int krow = off + min(key_local, Sb - 1);
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    kf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + a.d + h * 128 + kk * 32 + lg * 8);
+    vf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + 2 * a.d + h * 128 + kk * 32 + lg * 8);
+  }
+  const float bias2 = key_ok ? a.mask_bias[krow] * LOG2E : -INFINITY;
+  const float c1 = a.scale * LOG2E;
+  const unsigned bh = (unsigned)(b * a.H + h);
+
+  f32x4 dk[8], dv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  auto stage = [&](int qt, int st) {
+    bf16_t* base = smem + st * (2 * 64 * 128);
+    stage64x128(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
+    stage64x128(dOg, a.ldc, off + qt * 64, row_last, base + 64 * 128, wave, lane);
+    if (tid < 64) {
+      const int q = qt * 64 + tid;
+      const int row = off + min(q, Sb - 1);
+      float* ax = aux_s + st * 192;
+      ax[tid] = q < Sb ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
+      ax[64 + tid] = a.delta[(int64_t)row * a.H + h];
+      ax[128 + tid] = __uint_as_float(attn_rowkey(a.drop_key, bh, (unsigned)a.S4, (unsigned)q));
+    }
+  };
+  stage(0, 0);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int cur = qt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (qt + 1 < nqt) stage(qt + 1, cur ^ 1);
+    const bf16_t* Qs = smem + cur * (2 * 64 * 128);
+    const bf16_t* dOs = Qs + 64 * 128;
+    const float* ax = aux_s + cur * 192;
+    f32x4 s[4], da[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Qs, f * 16 + li, kk * 4 + lg), kf[kk], s[f], 0, 0, 0);
+        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(dOs, f * 16 + li, kk * 4 + lg), vf[kk], da[f], 0, 0, 0);
+      }
+    }
+    // lane (key = li, g) holds S[q = 16f + 4g + r][key]
+    f32x4 pa[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const f32x4 l2 = *(const f32x4*)(ax + f * 16 + 4 * lg);
+      const f32x4 dlt = *(const f32x4*)(ax + 64 + f * 16 + 4 * lg);
+      const f32x4 rkf = *(const f32x4*)(ax + 128 + f * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s[f][r] * c1 + bias2 - l2[r]);
+        bool keep = true;
+        if (a.thr16) keep = attn_keep(__float_as_uint(rkf[r]), (unsigned)key_local, a.thr16);
+        pa[f][r] = keep ? p * a.drop_scale : 0.f;                 // A = dropout(P)
+        const float dp = keep ? da[f][r] * a.drop_scale : 0.f;
+        s[f][r] = p * (dp - dlt[r]);                              // dS
+      }
+    }
+    const bf16x8_t ab0 = pack8(pa[0], pa[1]), ab1 = pack8(pa[2], pa[3]);
+    const bf16x8_t sb0 = pack8(s[0], s[1]), sb1 = pack8(s[2], s[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(dOs, 0, fd * 16, lane), ab0, dv[fd], 0, 0, 0);
+      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(dOs, 1, fd * 16, lane), ab1, dv[fd], 0, 0, 0);
+      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 0, fd * 16, lane), sb0, dk[fd], 0, 0, 0);
+      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 1, fd * 16, lane), sb1, dk[fd], 0, 0, 0);
+    }
+  }
+  if (key_ok) {
+    bf16_t* dstk = a.dqkv + (int64_t)krow * a.ld + a.d + h * 128 + 4 * lg;
+    bf16_t* dstv = a.dqkv + (int64_t)krow * a.ld + 2 * a.d + h * 128 + 4 * lg;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2 vk = {pack_bf2(dk[fd][0] * a.scale, dk[fd][1] * a.scale), pack_bf2(dk[fd][2] * a.scale, dk[fd][3] * a.scale)};
+      u32x2 vv = {pack_bf2(dv[fd][0], dv[fd][1]), pack_bf2(dv[fd][2], dv[fd][3])};
+      *(u32x2*)(dstk + fd * 16) = vk;
+      *(u32x2*)(dstv + fd * 16) = vv;
+    }
+  }
+}
+
+// test helper: materialise the attention dropout keep-mask, uint8 [B,H,S,S] (dense layout only)
+__global__ void attn_mask_export_kernel(uint8_t* out, int B, int H, int S, int S4, uint32_t key, uint32_t thr16) {
+  const int64_t n = (int64_t)B * H * S * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % S), q = (int)((i / S) % S);
+    const unsigned bh = (unsigned)(i / ((int64_t)S * S));
+    out[i] = thr16 ? (uint8_t)attn_keep(attn_rowkey(key, bh, (unsigned)S4, (unsigned)q), (unsigned)k, thr16) : 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_args(const void* qkv, int B, int S, int H, int d) {
+  if (!qkv || B <= 0 || S <= 0 || H <= 0) return MMT_ERR_ARG;
+  if (d != H * 128) return MMT_ERR_ARG;  // head dim 128 only (every published MMT config)
+  return 0;
+}
+
+extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx,
+                            float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key,
+                            uint32_t thr16, float drop_scale, void* stream) {
+  if (int e = check_args(qkv, B, S, H, d)) return e;
+  if (!mask_bias || !ctx || !lse) return MMT_ERR_ARG;
+  AttnArgs a = {};
+  a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
+                            const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
+                            int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                            void* stream) {
+  if (int e = check_args(qkv, B, S, H, d)) return e;
+  if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta) return MMT_ERR_ARG;
+  AttnArgs a = {};
+  a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
+  a.delta = delta; a.H = H; a.d = d; a.scale = scale;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3;
+  const dim3 grid((S + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,
+                                     void* stream) {
+  if (!out) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(attn_mask_export_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, B, H, S,
+                     (S + 3) & ~3, drop_key, thr16);
+  return (int)hipGetLastError();
+}

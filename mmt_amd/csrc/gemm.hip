@@ -1,0 +1,370 @@
+// bf16 MFMA GEMMs for the MMT hot path (gfx950).
+//
+//   gemm_nt : C[M,N] = A[M,K] . B[N,K]^T      forward Linear + input-gradient GEMMs, fused epilogues
+//   gemm_tn : C[N,K2] = A[rows,N]^T . B[rows,K2]   weight gradients (contraction over tokens)
+//
+// Structure (both): 256 threads = 4 waves (2x2), 128x{128,64} block tile, BK = 64, double-buffered
+// LDS filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip).
+// The LDS image is lane-linear, so the bank-conflict XOR swizzle is applied to the per-lane SOURCE
+// address and again on the fragment read (cdna guide 5.4 rule 21).
+//   NT: rows are 128 B (8 x 16 B chunks); chunk c of row r lives at chunk c ^ (r & 7); fragments are
+//       ds_read_b128.
+//   TN: rows are 256 B (16 chunks); chunk c of row r lives at c ^ ((r & 7) << 1); fragments are two
+//       ds_read_b64_tr_b16 (hardware 4x16 transpose) because the contraction index is the ROW.
+// MFMA operands are swapped (a = B-side fragment) so each lane ends up with 4 consecutive output
+// columns of one row: 8/16-byte stores instead of 2-byte scatters.
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define BK 64
+
+template <int R>
+__device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ G, int64_t ld, int row0, int k0,
+                                         bf16_t* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < R / 32; ++i) {
+    const int rbase = (wave * (R / 32) + i) * 8;  // 8 rows of 128 B per wave-instruction
+    const int r = rbase + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const bf16_t* src = G + (int64_t)(row0 + r) * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * BK), 16, 0, 0);
+  }
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+    void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
+    const int32_t* __restrict__ n_rows_dev) {
+  constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 fragments per wave in m / n
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+  const int tiles_n = N / BN;
+  const int nblk = gridDim.x;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nrows = n_rows_dev ? *n_rows_dev : M;
+  if (m0 >= nrows) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int STAGE = (BM + BN) * BK;  // elements per pipeline stage: [A tile | B tile]
+
+  const int KT = K / BK;
+  stage_nt<BM>(A, lda, m0, 0, smem, wave, lane);
+  stage_nt<BN>(B, ldb, n0, 0, smem + BM * BK, wave, lane);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) {
+      stage_nt<BM>(A, lda, m0, (kt + 1) * BK, smem + (cur ^ 1) * STAGE, wave, lane);
+      stage_nt<BN>(B, ldb, n0, (kt + 1) * BK, smem + (cur ^ 1) * STAGE + BM * BK, wave, lane);
+    }
+    const bf16_t* as = smem + cur * STAGE;
+    const bf16_t* bs = as + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[MI], bfr[NI];
+      const int c = ks * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * (BM / 2) + i * 16 + li;
+        af[i] = *(const bf16x8_t*)(as + r * BK + ((c ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int r = wn * (BN / 2) + j * 16 + li;
+        bfr[j] = *(const bf16x8_t*)(bs + r * BK + ((c ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane (li, lg), reg r holds C[row(i, li)][col(j, lg) + r] ----
+  float csum[NI][4];
+  if constexpr (EPI == MMT_EPI_DGELU) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = m0 + wm * (BM / 2) + i * 16 + li;
+    const bool row_ok = row < M;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+      f32x4 v = acc[i][j];
+      if constexpr (EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU ||
+                    EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_BIAS_F32) {
+        const f32x4 b = *(const f32x4*)(epi.bias + col);
+        v += b;
+      }
+      if (!row_ok) continue;
+      if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+      } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+        // GELU is evaluated on the bf16-rounded pre-activation so that backward (which only has
+        // the stored bf16 value) differentiates exactly the function that was applied.
+        float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
+        float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
+        u32x2 g = {pack_bf2(gelu_erf_f(p0), gelu_erf_f(p1)), pack_bf2(gelu_erf_f(p2), gelu_erf_f(p3))};
+        *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
+      } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+        if (epi.drop_thr16) {
+          const int orow = epi.row_index ? epi.row_index[row] : row;
+          bool k[4];
+          keep4(epi.drop_key, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = k[r] ? v[r] * epi.drop_scale : 0.f;
+        }
+        v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+        *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+      } else if constexpr (EPI == MMT_EPI_DGELU) {
+        const u32x2 a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+        v[0] *= gelu_erf_grad_f(bf2f((bf16_t)(a[0] & 0xffff)));
+        v[1] *= gelu_erf_grad_f(bf2f((bf16_t)(a[0] >> 16)));
+        v[2] *= gelu_erf_grad_f(bf2f((bf16_t)(a[1] & 0xffff)));
+        v[3] *= gelu_erf_grad_f(bf2f((bf16_t)(a[1] >> 16)));
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+        if (row < nrows) {
+          csum[j][0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[j][1] += bf2f((bf16_t)(o[0] >> 16));
+          csum[j][2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[j][3] += bf2f((bf16_t)(o[1] >> 16));
+        }
+      } else if constexpr (EPI == MMT_EPI_ADD_F32) {
+        v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+        *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+      } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
+        *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+      }
+    }
+  }
+  if constexpr (EPI == MMT_EPI_DGELU) {
+    if (epi.colsum) {  // per-row-tile column sums of the bf16 output (-> bias gradient, deterministic)
+      __syncthreads();
+      float* red = (float*)smem;  // [2][BN]
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = csum[j][r];
+          s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+          s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+          if (li == 0) red[wm * BN + wn * (BN / 2) + j * 16 + lg * 4 + r] = s;
+        }
+      __syncthreads();
+      if (tid < BN) epi.colsum[(int64_t)tm * N + n0 + tid] = red[tid] + red[BN + tid];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: weight gradient.  Tiles: At[64 rows][128 n], Bt[64 rows][128 k2], both row-major 256-B rows.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ G, int64_t ld, int row0, int c0,
+                                         bf16_t* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rbase = (wave * 4 + i) * 4;  // 4 rows of 256 B per wave-instruction
+    const int r = rbase + (lane >> 4);
+    const int c = (lane & 15) ^ ((r & 7) << 1);
+    const bf16_t* src = G + (int64_t)(row0 + r) * ld + c0 + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * 128), 16, 0, 0);
+  }
+}
+
+// 8 contraction values for column `col` of a [64][128] tile, k-sub-step ks: lane group g gets rows
+// ks*32 + 4g + {0..3} and ks*32 + 16 + 4g + {0..3} (same permutation for both operands).
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int ks, int colbase, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  const int col = colbase + 4 * (t & 3);
+  const int r0 = ks * 32 + 4 * g + (t >> 2);
+  const int r1 = r0 + 16;
+  const int ch = col >> 3, w = col & 7;
+  const bf16_t* p0 = tile + r0 * 128 + ((ch ^ ((r0 & 7) << 1)) << 3) + w;
+  const bf16_t* p1 = tile + r1 * 128 + ((ch ^ ((r1 & 7) << 1)) << 3) + w;
+  bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p0));
+  bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+    float* __restrict__ ws, int rows, int N, int K2, int splits,
+    const int32_t* __restrict__ n_rows_dev) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128];
+  const int tiles_k = K2 / 128, tiles = (N / 128) * tiles_k;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / tiles, tile = id % tiles;
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int ktiles = (nrows + 63) / 64;
+  const int per = (ktiles + splits - 1) / splits;
+  const int kt_begin = split * per, kt_end = min(ktiles, kt_begin + per);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int TSTAGE = 2 * 64 * 128;  // [A tile | B tile] per stage
+
+  if (kt_begin < kt_end) {
+    stage_tn(A, lda, kt_begin * 64, n0, smem, wave, lane);
+    stage_tn(B, ldb, kt_begin * 64, k0, smem + 64 * 128, wave, lane);
+  }
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      stage_tn(A, lda, (kt + 1) * 64, n0, smem + (cur ^ 1) * TSTAGE, wave, lane);
+      stage_tn(B, ldb, (kt + 1) * 64, k0, smem + (cur ^ 1) * TSTAGE + 64 * 128, wave, lane);
+    }
+    bf16_t* at = smem + cur * TSTAGE;
+    bf16_t* bt = at + 64 * 128;
+    const int live = nrows - kt * 64;  // rows of this tile that exist
+    if (live < 64) {                   // ragged tail: zero dead rows of both operands
+      for (int e = tid; e < (64 - live) * 32; e += 256) {
+        const int r = live + e / 32, q = e % 32;  // 32 x 16-B per pair of row images
+        u32x4 z = {0, 0, 0, 0};
+        if (q < 16) *(u32x4*)(at + r * 128 + q * 8) = z;
+        else *(u32x4*)(bt + r * 128 + (q - 16) * 8) = z;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_frag(at, ks, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(bt, ks, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = ws + (int64_t)split * N * K2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wm * 64 + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k2 = k0 + wn * 64 + j * 16 + lg * 4;
+      *(f32x4*)(out + (int64_t)n * K2 + k2) = acc[i][j];
+    }
+  }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ ws, int splits, int64_t count4,
+                                    float* __restrict__ out, int accumulate) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 s = ((const f32x4*)ws)[i];
+    for (int k = 1; k < splits; ++k) s += ((const f32x4*)ws)[k * count4 + i];
+    if (accumulate) s += ((const f32x4*)out)[i];
+    ((f32x4*)out)[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int EPI>
+static int launch_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  const int grid = ((M + BM - 1) / BM) * (N / BN);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(grid), dim3(256), 0, s, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
+  return (int)hipGetLastError();
+}
+
+template <int EPI>
+static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                         int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  // 128x128 when it still yields >= 2 tiles per CU or N is wide; otherwise 128x64 for more blocks.
+  const long t128 = (long)((M + 127) / 128) * (N / 128);
+  const bool want128 = e.reserved == 1 || (e.reserved == 0 && t128 >= 512);  // reserved: 1/2 force a tile (tests)
+  if (N % 128 == 0 && want128) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  return launch_nt<128, 64, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+}
+
+extern "C" int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                                int64_t ldc, int M, int N, int K, int epilogue, const MmtEpilogue* epi,
+                                const int32_t* n_rows_dev, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MMT_ERR_ARG;
+  if (K % BK || N % 64) return MMT_ERR_ARG;
+  if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
+    return MMT_ERR_ALIGN;
+  MmtEpilogue e = {};
+  if (epi) e = *epi;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case MMT_EPI_BF16: return dispatch_tile<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_BIAS_BF16:
+      if (!e.bias) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_BIAS_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_BIAS_GELU:
+      if (!e.bias || !e.out2) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_BIAS_GELU>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_BIAS_DROP_RES:
+      if (!e.bias || !e.res) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_BIAS_DROP_RES>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_DGELU:
+      if (!e.aux) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_DGELU>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_ADD_F32:
+      if (!e.res) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_ADD_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_F32: return dispatch_tile<MMT_EPI_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_BIAS_F32:
+      if (!e.bias) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_BIAS_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+  }
+  return MMT_ERR_ARG;
+}
+
+extern "C" int mmt_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* ws,
+                                int rows, int N, int K2, int splits, const int32_t* n_rows_dev,
+                                void* stream) {
+  if (!A || !B || !ws || rows <= 0 || N <= 0 || K2 <= 0 || splits <= 0) return MMT_ERR_ARG;
+  if (N % 128 || K2 % 128) return MMT_ERR_ARG;
+  if ((lda % 8) || (ldb % 8) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)ws & 15))
+    return MMT_ERR_ALIGN;
+  const int grid = (N / 128) * (K2 / 128) * splits;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, ws, rows, N, K2, splits, n_rows_dev);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_reduce_slabs(const float* ws, int splits, int64_t count, float* out, int accumulate,
+                                void* stream) {
+  if (!ws || !out || splits <= 0 || count <= 0 || (count & 3)) return MMT_ERR_ARG;
+  const int64_t c4 = count / 4;
+  const int grid = (int)((c4 + 255) / 256 < 2048 ? (c4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, splits, c4,
+                     out, accumulate);
+  return (int)hipGetLastError();
+}

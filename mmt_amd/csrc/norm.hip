@@ -1,0 +1,276 @@
+// LayerNorm / embedding kernels of the video-BERT (gfx950).  All are HBM/Infinity-Cache bound:
+// one wave per row, 16-byte vector accesses, fp32 statistics (eps = 1e-12 is below bf16 resolution).
+//
+//   ln_fwd       : h = LN(z)                         bert.py:188,236 (z = pre-LN sum from the GEMM epilogue)
+//   embed_ln_fwd : h = dropout(LN(feat + type_emb[t] + pos_emb[p]))          bert.py:87-105
+//   ln_bwd       : dz (+ dy = dropout'(dz) in bf16 for the GEMMs) and per-block partial column sums
+//                  of dgamma, dbeta, dbias
+//   col_reduce   : sums the per-block partials
+//   table_grad   : embedding-table gradients (deterministic segmented sums, no atomics)
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define MAXC 4  // d <= 1024: up to 4 float4 chunks per lane
+
+template <bool EMBED>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const float* __restrict__ z_in, const int32_t* __restrict__ type_ids, const int32_t* __restrict__ pos_ids,
+    const float* __restrict__ type_emb, const float* __restrict__ pos_emb, float* __restrict__ z_save,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ h32,
+    bf16_t* __restrict__ h16, float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
+    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key,
+    uint32_t thr16, float drop_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int nch = d >> 8;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    f32x4 x[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        x[c] = *(const f32x4*)(z_in + (int64_t)row * d + col);
+        if constexpr (EMBED) {
+          x[c] += *(const f32x4*)(type_emb + (int64_t)type_ids[row] * d + col);
+          if (pos_ids) x[c] += *(const f32x4*)(pos_emb + (int64_t)pos_ids[row] * d + col);
+          if (z_save) *(f32x4*)(z_save + (int64_t)row * d + col) = x[c];
+        }
+        s += x[c][0] + x[c][1] + x[c][2] + x[c][3];
+      }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < nch) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = x[c][k] - mean; v += t * t; }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const int orow = row_index ? row_index[row] : row;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        const f32x4 g = *(const f32x4*)(gamma + col), b = *(const f32x4*)(beta + col);
+        f32x4 y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = (x[c][k] - mean) * rstd * g[k] + b[k];
+        if constexpr (EMBED) {
+          if (thr16) {
+            bool kp[4];
+            keep4(drop_key, (unsigned long long)orow * (unsigned)d + (unsigned)col, thr16, kp);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = kp[k] ? y[k] * drop_scale : 0.f;
+          }
+        }
+        if (h32) *(f32x4*)(h32 + (int64_t)row * d + col) = y;
+        u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+        *(u32x2*)(h16 + (int64_t)row * d + col) = o;
+      }
+  }
+}
+
+// DROP: 0 none, 1 dropout applied BEFORE the LN input (dy = mask*dz*scale), 2 dropout applied AFTER the
+// LN output (incoming dout is masked first; embeddings).
+template <int DROP>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ z, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma, float* __restrict__ dz_out,
+    bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows, int d, int rows_per_block,
+    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key,
+    uint32_t thr16, float drop_scale) {
+  __shared__ float red[4][3][MAXC * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int nch = d >> 8;
+  f32x4 dg[MAXC], db[MAXC], dbias[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = dbias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(nrows, r_begin + rows_per_block);
+  for (int row = r_begin + wave; row < r_end; row += 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int orow = row_index ? row_index[row] : row;
+    f32x4 xh[MAXC], g[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        f32x4 go = *(const f32x4*)(dout + (int64_t)row * d + col);
+        if constexpr (DROP == 2) {
+          if (thr16) {
+            bool kp[4];
+            keep4(drop_key, (unsigned long long)orow * (unsigned)d + (unsigned)col, thr16, kp);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) go[k] = kp[k] ? go[k] * drop_scale : 0.f;
+          }
+        }
+        const f32x4 zz = *(const f32x4*)(z + (int64_t)row * d + col);
+        const f32x4 gm = *(const f32x4*)(gamma + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xh[c][k] = (zz[k] - mean) * rstd;
+          g[c][k] = go[k] * gm[k];
+          s1 += g[c][k];
+          s2 += g[c][k] * xh[c][k];
+          dg[c][k] += go[k] * xh[c][k];
+          db[c][k] += go[k];
+        }
+      }
+    const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        f32x4 dzv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dzv[k] = rstd * (g[c][k] - m1 - xh[c][k] * m2);
+        if (dz_out) *(f32x4*)(dz_out + (int64_t)row * d + col) = dzv;
+        if (dy_out) {
+          f32x4 dyv = dzv;
+          if constexpr (DROP == 1) {
+            if (thr16) {
+              bool kp[4];
+              keep4(drop_key, (unsigned long long)orow * (unsigned)d + (unsigned)col, thr16, kp);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) dyv[k] = kp[k] ? dyv[k] * drop_scale : 0.f;
+            }
+          }
+          u32x2 o = {pack_bf2(dyv[0], dyv[1]), pack_bf2(dyv[2], dyv[3])};
+          *(u32x2*)(dy_out + (int64_t)row * d + col) = o;
+          // the bias gradient sums exactly what the weight-gradient GEMM will read (bf16-rounded)
+          dbias[c][0] += bf2f((bf16_t)(o[0] & 0xffff)); dbias[c][1] += bf2f((bf16_t)(o[0] >> 16));
+          dbias[c][2] += bf2f((bf16_t)(o[1] & 0xffff)); dbias[c][3] += bf2f((bf16_t)(o[1] >> 16));
+        }
+      }
+  }
+  // cross-wave reduction of the column partials, one [3][d] record per block
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nch) {
+      const int col = c * 256 + lane * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[wave][0][col + k] = dg[c][k];
+        red[wave][1][col + k] = db[c][k];
+        red[wave][2][col + k] = dbias[c][k];
+      }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * d; e += 256) {
+    const int which = e / d, col = e % d;
+    partials[((int64_t)blockIdx.x * 3 + which) * d + col] =
+        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+// out[j][c] (+)= sum_b partials[b][j][c]   (j < nvec; fixed summation order => deterministic)
+struct ColOuts { float* p[4]; };
+__global__ void col_reduce_kernel(const float* __restrict__ partials, int nblocks, int nvec, int d,
+                                  ColOuts outs, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nvec * d) return;
+  const int j = e / d, c = e % d;
+  float* out = outs.p[j];
+  if (!out) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[((int64_t)b * nvec + j) * d + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// dtable[v][c] (+)= sum over rows with ids[row] == v of g[row][c].   grid = (vocab, d/256).
+__global__ __launch_bounds__(256) void table_grad_kernel(
+    const float* __restrict__ g, const int32_t* __restrict__ ids, int rows, int d,
+    const int32_t* __restrict__ n_rows_dev, float* __restrict__ dtable, int accumulate) {
+  const int v = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  __shared__ int32_t sid[256];
+  float s = 0.f;
+  for (int r0 = 0; r0 < nrows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    sid[threadIdx.x] = r < nrows ? ids[r] : -1;
+    __syncthreads();
+    const int lim = min(256, nrows - r0);
+    for (int k = 0; k < lim; ++k)
+      if (sid[k] == v) s += g[(int64_t)(r0 + k) * d + col];
+    __syncthreads();
+  }
+  float* o = dtable + (int64_t)v * d + col;
+  *o = accumulate ? *o + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int ln_grid(int rows) {
+  int g = (rows + 3) / 4;
+  return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+}
+
+extern "C" int mmt_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h32,
+                          void* h16, float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev,
+                          void* stream) {
+  if (!z || !gamma || !beta || !h16 || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
+                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
+                                const float* type_emb, const float* pos_emb, float* z_save,
+                                const float* gamma, const float* beta, float eps, float* h32, void* h16,
+                                float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev,
+                                const int32_t* row_index, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                                void* stream) {
+  if (!features || !type_ids || !type_emb || !gamma || !beta || !h16 || !mean || !rstd || rows <= 0)
+    return MMT_ERR_ARG;
+  if (pos_ids && !pos_emb) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, features,
+                     type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, (bf16_t*)h16, mean,
+                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_ln_bwd_rows_per_block(void) { return 32; }
+
+extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
+                          const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
+                          int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
+                          uint32_t drop_key, uint32_t thr16, float drop_scale, void* stream) {
+  if (!dout || !z || !mean || !rstd || !gamma || !partials || rows <= 0) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  const int rpb = 32, grid = (rows + rpb - 1) / rpb;
+  hipStream_t s = (hipStream_t)stream;
+#define LN_BWD_LAUNCH(MODE)                                                                            \
+  hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), 0, s, dout, z, mean, rstd, gamma, dz, \
+                     (bf16_t*)dy, partials, rows, d, rpb, n_rows_dev, row_index, drop_key, thr16, drop_scale)
+  if (drop_mode == 0) LN_BWD_LAUNCH(0);
+  else if (drop_mode == 1) LN_BWD_LAUNCH(1);
+  else if (drop_mode == 2) LN_BWD_LAUNCH(2);
+  else return MMT_ERR_ARG;
+#undef LN_BWD_LAUNCH
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,
+                              float* out2, float* out3, int accumulate, void* stream) {
+  if (!partials || nblocks <= 0 || nvec <= 0 || nvec > 4 || d <= 0) return MMT_ERR_ARG;
+  const int n = nvec * d;
+  ColOuts outs = {{out0, out1, out2, out3}};
+  hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
+                     nblocks, nvec, d, outs, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int vocab,
+                              const int32_t* n_rows_dev, float* dtable, int accumulate, void* stream) {
+  if (!g || !ids || !dtable || rows <= 0 || vocab <= 0 || d % 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(table_grad_kernel, dim3(vocab, d / 256), dim3(256), 0, (hipStream_t)stream, g, ids, rows,
+                     d, n_rows_dev, dtable, accumulate);
+  return (int)hipGetLastError();
+}

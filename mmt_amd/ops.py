@@ -1,0 +1,171 @@
+"""Thin per-kernel Python wrappers over the C ABI (used by the unit tests and by the modules).
+
+Every function takes CUDA(HIP) torch tensors, passes raw device pointers + the current stream to
+libmmt_hip.so and returns torch tensors.  No computation happens in Python and nothing here falls
+back to torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import EPI, MmtEpilogue, check
+
+ROW_ALIGN = 256
+
+
+def pad_rows(n):
+  return (n + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+
+def _p(t):
+  return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+  for t in ts:
+    if t is not None and not t.is_cuda:
+      raise RuntimeError('mmt_amd kernels need GPU tensors (no CPU fallback)')
+
+
+def dropout_params(p):
+  """(thr16, scale) with keep-probability quantised to 1/65536 (see mmt_common.h)."""
+  thr = int(round(float(p) * 65536.0))
+  if thr <= 0:
+    return 0, 1.0
+  return thr, 1.0 / (1.0 - thr / 65536.0)
+
+
+def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, aux=None, colsum=None,
+            row_index=None, drop_key=0, drop_p=0.0, n_rows_dev=None, tile=0):
+  """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue.  a/b bf16 row-major, rows padded to 128."""
+  _need_cuda(a, b, out)
+  M = a.shape[0] if m is None else m
+  N, K = b.shape
+  e = MmtEpilogue()
+  e.bias, e.res, e.out2, e.aux = (x.data_ptr() if x is not None else None for x in (bias, res, out2, aux))
+  e.ldres = res.stride(0) if res is not None else 0
+  e.ldout2 = out2.stride(0) if out2 is not None else 0
+  e.ldaux = aux.stride(0) if aux is not None else 0
+  e.colsum = colsum.data_ptr() if colsum is not None else None
+  e.row_index = row_index.data_ptr() if row_index is not None else None
+  thr, scale = dropout_params(drop_p)
+  e.drop_key, e.drop_thr16, e.drop_scale = drop_key, thr, scale
+  e.reserved = tile
+  rc = _lib.lib().mmt_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
+                                   EPI[epilogue], ctypes.byref(e), _p(n_rows_dev), _stream())
+  check(rc, 'mmt_gemm_nt_bf16')
+  return out
+
+
+def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=None):
+  """out[N,K2] (+)= a[rows,N]^T @ b[rows,K2]  (fp32 result; split over rows, deterministic reduce)."""
+  _need_cuda(a, b)
+  rows = a.shape[0] if rows is None else rows
+  N, K2 = a.shape[1], b.shape[1]
+  ws = torch.empty(splits, N, K2, device=a.device, dtype=torch.float32)
+  L = _lib.lib()
+  check(L.mmt_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), rows, N, K2, splits,
+                           _p(n_rows_dev), _stream()), 'mmt_gemm_tn_bf16')
+  if out is None:
+    out = torch.empty(N, K2, device=a.device, dtype=torch.float32)
+    accumulate = False
+  check(L.mmt_reduce_slabs(_p(ws), splits, N * K2, _p(out), int(accumulate), _stream()), 'mmt_reduce_slabs')
+  return out
+
+
+def ln_fwd(z, gamma, beta, eps, rows=None, n_rows_dev=None, want_h32=True):
+  _need_cuda(z)
+  R, d = z.shape
+  rows = R if rows is None else rows
+  h32 = torch.zeros_like(z) if want_h32 else None
+  h16 = torch.zeros(R, d, device=z.device, dtype=torch.bfloat16)
+  mean = torch.zeros(R, device=z.device, dtype=torch.float32)
+  rstd = torch.zeros(R, device=z.device, dtype=torch.float32)
+  check(_lib.lib().mmt_ln_fwd(_p(z), _p(gamma), _p(beta), eps, _p(h32), _p(h16), _p(mean), _p(rstd), rows, d,
+                              _p(n_rows_dev), _stream()), 'mmt_ln_fwd')
+  return h32, h16, mean, rstd
+
+
+def embed_ln_fwd(features, type_ids, pos_ids, type_emb, pos_emb, gamma, beta, eps, rows=None, drop_key=0,
+                 drop_p=0.0, row_index=None, n_rows_dev=None):
+  _need_cuda(features)
+  R, d = features.shape
+  rows = R if rows is None else rows
+  z = torch.zeros_like(features)
+  h32 = torch.zeros_like(features)
+  h16 = torch.zeros(R, d, device=features.device, dtype=torch.bfloat16)
+  mean = torch.zeros(R, device=features.device, dtype=torch.float32)
+  rstd = torch.zeros(R, device=features.device, dtype=torch.float32)
+  thr, scale = dropout_params(drop_p)
+  check(_lib.lib().mmt_embed_ln_fwd(_p(features), _p(type_ids), _p(pos_ids), _p(type_emb), _p(pos_emb), _p(z),
+                                    _p(gamma), _p(beta), eps, _p(h32), _p(h16), _p(mean), _p(rstd), rows, d,
+                                    _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _stream()),
+        'mmt_embed_ln_fwd')
+  return z, h32, h16, mean, rstd
+
+
+def ln_bwd(dout, z, mean, rstd, gamma, rows=None, drop_mode=0, drop_key=0, drop_p=0.0, want_dy=True,
+           row_index=None, n_rows_dev=None):
+  """Returns dz (fp32), dy (bf16 or None), dgamma, dbeta, dbias (fp32 [d])."""
+  _need_cuda(dout)
+  R, d = z.shape
+  rows = R if rows is None else rows
+  L = _lib.lib()
+  rpb = L.mmt_ln_bwd_rows_per_block()
+  nblk = (rows + rpb - 1) // rpb
+  dz = torch.zeros_like(z)
+  dy = torch.zeros(R, d, device=z.device, dtype=torch.bfloat16) if want_dy else None
+  partials = torch.empty(nblk, 3, d, device=z.device, dtype=torch.float32)
+  thr, scale = dropout_params(drop_p)
+  check(L.mmt_ln_bwd(_p(dout), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dy), _p(partials), rows, d,
+                     drop_mode, _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _stream()), 'mmt_ln_bwd')
+  outs = [torch.empty(d, device=z.device, dtype=torch.float32) for _ in range(3)]
+  check(L.mmt_col_reduce(_p(partials), nblk, 3, d, _p(outs[0]), _p(outs[1]), _p(outs[2]), None, 0, _stream()),
+        'mmt_col_reduce')
+  return dz, dy, outs[0], outs[1], outs[2]
+
+
+def table_grad(g, ids, vocab, rows=None, n_rows_dev=None):
+  _need_cuda(g)
+  R, d = g.shape
+  rows = R if rows is None else rows
+  out = torch.empty(vocab, d, device=g.device, dtype=torch.float32)
+  check(_lib.lib().mmt_table_grad(_p(g), _p(ids), rows, d, vocab, _p(n_rows_dev), _p(out), 0, _stream()),
+        'mmt_table_grad')
+  return out
+
+
+def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0):
+  _need_cuda(qkv)
+  R, d3 = qkv.shape
+  d = d3 // 3
+  ctx = torch.zeros(R, d, device=qkv.device, dtype=torch.bfloat16)
+  lse = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
+  thr, sc = dropout_params(drop_p)
+  check(_lib.lib().mmt_attn_fwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), B, S, H, d, scale,
+                                drop_key, thr, sc, _stream()), 'mmt_attn_fwd')
+  return ctx, lse
+
+
+def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0):
+  _need_cuda(qkv)
+  R, d3 = qkv.shape
+  d = d3 // 3
+  dqkv = torch.zeros_like(qkv)
+  delta = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
+  thr, sc = dropout_params(drop_p)
+  check(_lib.lib().mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
+                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _stream()), 'mmt_attn_bwd')
+  return dqkv
+
+
+def attn_dropout_mask(B, H, S, drop_key, drop_p, device='cuda'):
+  out = torch.empty(B, H, S, S, device=device, dtype=torch.uint8)
+  thr, _ = dropout_params(drop_p)
+  check(_lib.lib().mmt_attn_dropout_mask(_p(out), B, H, S, drop_key, thr, _stream()), 'mmt_attn_dropout_mask')
+  return out

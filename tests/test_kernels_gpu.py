@@ -1,0 +1,272 @@
+"""GPU unit tests: every HIP kernel against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+  return torch.device('cuda:0')
+
+
+def _rand(shape, scale=1.0, seed=0, dtype=torch.float32):
+  g = torch.Generator(device='cpu').manual_seed(seed)
+  return (torch.randn(*shape, generator=g) * scale).to(dtype).to(_dev())
+
+
+def _close(name, got, want, atol, rtol):
+  got, want = got.float(), want.float()
+  err = (got - want).abs()
+  tol = atol + rtol * want.abs()
+  bad = err > tol
+  if bad.any():
+    idx = bad.nonzero()[:8].tolist()
+    raise AssertionError('%s: %d/%d mismatches, max err %.4g (ref max %.4g); first bad idx %s; got %s want %s'
+                         % (name, int(bad.sum()), bad.numel(), err.max().item(), want.abs().max().item(), idx,
+                            got[bad][:4].tolist(), want[bad][:4].tolist()))
+
+
+def _gelu(x):
+  return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+@pytest.mark.parametrize('M,N,K,tile', [(256, 64, 64, 2), (384, 192, 128, 2), (256, 128, 64, 1),
+                                        (512, 384, 256, 1), (7168, 1536, 512, 0), (7168, 512, 3072, 0)])
+def test_gemm_nt_plain_and_bias(M, N, K, tile):
+  from mmt_amd import ops
+  a = _rand((M, K), seed=1, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.1, seed=2, dtype=torch.bfloat16)
+  bias = _rand((N,), seed=3)
+  ref = a.float() @ b.float().t()
+  out = torch.zeros(M, N, device=_dev(), dtype=torch.bfloat16)
+  ops.gemm_nt(a, b, out, 'BF16', tile=tile)
+  _close('BF16', out, ref, 2e-2, 1e-2)
+  o32 = torch.zeros(M, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, o32, 'F32', tile=tile)
+  _close('F32', o32, ref, 1e-3, 1e-4)
+  ops.gemm_nt(a, b, o32, 'BIAS_F32', bias=bias, tile=tile)
+  _close('BIAS_F32', o32, ref + bias, 1e-3, 1e-4)
+  ops.gemm_nt(a, b, out, 'BIAS_BF16', bias=bias, tile=tile)
+  _close('BIAS_BF16', out, ref + bias, 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_nt_fused_epilogues(tile):
+  from mmt_amd import ops
+  M, N, K = 384, 256, 192
+  a = _rand((M, K), seed=4, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.1, seed=5, dtype=torch.bfloat16)
+  bias = _rand((N,), seed=6)
+  res = _rand((M, N), seed=7)
+  ref = a.float() @ b.float().t()
+  # bias + GELU (two outputs)
+  pre = torch.zeros(M, N, device=_dev(), dtype=torch.bfloat16)
+  act = torch.zeros_like(pre)
+  ops.gemm_nt(a, b, pre, 'BIAS_GELU', bias=bias, out2=act, tile=tile)
+  _close('gelu.pre', pre, ref + bias, 2e-2, 1e-2)
+  _close('gelu.act', act, _gelu(pre.float()), 1e-2, 1e-2)
+  # bias + residual (dropout off)
+  z = torch.zeros(M, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, z, 'BIAS_DROP_RES', bias=bias, res=res, tile=tile)
+  _close('drop_res(p=0)', z, ref + bias + res, 1e-3, 1e-4)
+  # dropout on: every element is either res or res + (acc+bias)/(1-p); keep rate ~ 0.9; deterministic
+  ops.gemm_nt(a, b, z, 'BIAS_DROP_RES', bias=bias, res=res, drop_key=1234, drop_p=0.1, tile=tile)
+  thr, sc = ops.dropout_params(0.1)
+  kept = (z - res - (ref + bias) * sc).abs() < 1e-3 + 1e-4 * (ref + bias).abs() * sc
+  dropped = (z - res).abs() < 1e-6
+  assert bool((kept | dropped).all())
+  rate = kept.float().mean().item()
+  assert 0.88 < rate < 0.92, rate
+  z2 = torch.zeros_like(z)
+  ops.gemm_nt(a, b, z2, 'BIAS_DROP_RES', bias=bias, res=res, drop_key=1234, drop_p=0.1, tile=3 - tile)
+  assert torch.equal(z == res, z2 == res)  # mask depends only on (key, element), not on the tiling
+  # add fp32
+  ops.gemm_nt(a, b, z, 'ADD_F32', res=res, tile=tile)
+  _close('add_f32', z, ref + res, 1e-3, 1e-4)
+  # dGELU + column sums
+  aux = _rand((M, N), seed=8, dtype=torch.bfloat16)
+  out = torch.zeros(M, N, device=_dev(), dtype=torch.bfloat16)
+  colsum = torch.zeros((M + 127) // 128, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, out, 'DGELU', aux=aux, colsum=colsum, tile=tile)
+  x = aux.float().requires_grad_(True)
+  _gelu(x).backward(ref)
+  _close('dgelu', out, x.grad, 3e-2, 1.5e-2)
+  _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
+
+
+def test_gemm_nt_live_rows_and_colsum_mask():
+  from mmt_amd import ops
+  M, N, K = 512, 128, 64
+  a = _rand((M, K), seed=9, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.1, seed=10, dtype=torch.bfloat16)
+  aux = _rand((M, N), seed=11, dtype=torch.bfloat16)
+  live = torch.tensor([200], device=_dev(), dtype=torch.int32)
+  out = torch.full((M, N), 7.0, device=_dev(), dtype=torch.bfloat16)
+  colsum = torch.zeros(4, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, out, 'DGELU', aux=aux, colsum=colsum, n_rows_dev=live, tile=2)
+  assert bool((out[256:] == 7.0).all())  # tiles beyond the live row count exit early
+  _close('colsum live', colsum.sum(0), out[:200].float().sum(0), 1e-2, 1e-4)
+
+
+@pytest.mark.parametrize('rows,N,K2,splits,live', [(256, 128, 128, 1, None), (448, 256, 128, 3, None),
+                                                   (512, 128, 384, 4, 333), (7168, 512, 1536, 8, 6976)])
+def test_gemm_tn_weight_gradient(rows, N, K2, splits, live):
+  from mmt_amd import ops
+  a = _rand((rows, N), seed=12, dtype=torch.bfloat16)
+  b = _rand((rows, K2), 0.1, seed=13, dtype=torch.bfloat16)
+  n = rows if live is None else live
+  nr = None if live is None else torch.tensor([live], device=_dev(), dtype=torch.int32)
+  if live is not None:  # garbage (incl. NaN) beyond the live rows must not leak in
+    a[live:] = float('nan')
+    b[live:] = float('nan')
+  ref = a[:n].float().t() @ b[:n].float()
+  got = ops.gemm_tn(a, b, splits=splits, n_rows_dev=nr)
+  _close('tn', got, ref, 2e-3 * math.sqrt(n / 256.0), 2e-4)
+  acc = torch.ones_like(got)
+  ops.gemm_tn(a, b, splits=splits, n_rows_dev=nr, out=acc, accumulate=True)
+  _close('tn accumulate', acc, ref + 1.0, 2e-3 * math.sqrt(n / 256.0), 2e-4)
+
+
+@pytest.mark.parametrize('d', [256, 512, 1024])
+def test_layernorm_fwd_bwd(d):
+  from mmt_amd import ops
+  R, rows = 256, 203
+  z = _rand((R, d), 2.0, seed=14) + 0.5
+  gamma = 1.0 + 0.1 * _rand((d,), seed=15)
+  beta = 0.1 * _rand((d,), seed=16)
+  h32, h16, mean, rstd = ops.ln_fwd(z, gamma, beta, 1e-12, rows=rows)
+  zr = z[:rows].clone().requires_grad_(True)
+  gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+  ref = torch.nn.functional.layer_norm(zr, (d,), gr, br, 1e-12)
+  _close('ln.h32', h32[:rows], ref, 1e-5, 1e-5)
+  _close('ln.h16', h16[:rows], ref, 2e-2, 1e-2)
+  assert bool((h32[rows:] == 0).all())
+  dout = _rand((R, d), seed=17)
+  ref.backward(dout[:rows])
+  dz, dy, dg, db, dbias = ops.ln_bwd(dout, z, mean, rstd, gamma, rows=rows)
+  _close('ln.dz', dz[:rows], zr.grad, 2e-5, 1e-4)
+  _close('ln.dy', dy[:rows], zr.grad, 2e-2, 1e-2)
+  _close('ln.dgamma', dg, gr.grad, 1e-3, 1e-4)
+  _close('ln.dbeta', db, br.grad, 1e-3, 1e-4)
+  _close('ln.dbias', dbias, dy[:rows].float().sum(0), 1e-3, 1e-4)
+  # dropout-before-LN mode: dy = mask * dz / (1-p), same mask as the GEMM epilogue would have drawn
+  dz2, dy2, _, _, _ = ops.ln_bwd(dout, z, mean, rstd, gamma, rows=rows, drop_mode=1, drop_key=77, drop_p=0.1)
+  assert torch.equal(dz2, dz)
+  thr, sc = ops.dropout_params(0.1)
+  kept = dy2[:rows].float() != 0
+  _close('ln.dy drop', dy2[:rows].float(), dz[:rows] * sc * kept, 2e-2, 1e-2)
+  assert 0.87 < kept.float().mean().item() < 0.93
+
+
+def test_embedding_layernorm_fwd_bwd():
+  from mmt_amd import ops
+  R, rows, d = 256, 218, 512
+  feats = _rand((R, d), seed=18)
+  g = torch.Generator().manual_seed(19)
+  tids = torch.randint(0, 19, (R,), generator=g).int().to(_dev())
+  pids = torch.randint(0, 32, (R,), generator=g).int().to(_dev())
+  temb, pemb = _rand((19, d), 0.05, seed=20), _rand((32, d), 0.05, seed=21)
+  gamma = 1.0 + 0.1 * _rand((d,), seed=22)
+  beta = 0.1 * _rand((d,), seed=23)
+  z, h32, h16, mean, rstd = ops.embed_ln_fwd(feats, tids, pids, temb, pemb, gamma, beta, 1e-12, rows=rows)
+  zr = (feats + temb[tids.long()] + pemb[pids.long()])[:rows]
+  _close('emb.z', z[:rows], zr, 1e-6, 1e-6)
+  _close('emb.h32', h32[:rows], torch.nn.functional.layer_norm(zr, (d,), gamma, beta, 1e-12), 1e-5, 1e-5)
+  z2, h2, _, _, _ = ops.embed_ln_fwd(feats, tids, None, temb, None, gamma, beta, 1e-12, rows=rows)
+  _close('emb.nopos', z2[:rows], (feats + temb[tids.long()])[:rows], 1e-6, 1e-6)
+  # table gradient: segmented sum
+  gsum = ops.table_grad(feats, tids, 19, rows=rows)
+  ref = torch.zeros(19, d, device=_dev()).index_add_(0, tids[:rows].long(), feats[:rows])
+  _close('table_grad', gsum, ref, 1e-4, 1e-5)
+  # dropout-after-LN (mode 2): forward mask and backward mask agree
+  _, hd, _, _, _ = ops.embed_ln_fwd(feats, tids, pids, temb, pemb, gamma, beta, 1e-12, rows=rows, drop_key=5,
+                                    drop_p=0.1)
+  keep = hd[:rows] != 0
+  thr, sc = ops.dropout_params(0.1)
+  _close('emb.drop', hd[:rows], h32[:rows] * sc * keep, 1e-5, 1e-5)
+  dout = _rand((R, d), seed=24)
+  dz_d, _, _, _, _ = ops.ln_bwd(dout, z, mean, rstd, gamma, rows=rows, drop_mode=2, drop_key=5, drop_p=0.1,
+                                want_dy=False)
+  dz_ref, _, _, _, _ = ops.ln_bwd(dout * keep_pad(keep, R) * sc, z, mean, rstd, gamma, rows=rows, want_dy=False)
+  _close('emb.bwd mask', dz_d[:rows], dz_ref[:rows], 1e-5, 1e-5)
+
+
+def keep_pad(keep, R):
+  out = torch.zeros(R, keep.shape[1], device=keep.device)
+  out[:keep.shape[0]] = keep.float()
+  return out
+
+
+def _attn_ref(qkv, bias, B, S, H, scale, cu=None, mask=None, sc=1.0):
+  """fp32 reference of bert.py:141-168 on the bf16-rounded inputs; returns ctx [rows, d]."""
+  d = qkv.shape[1] // 3
+  dh = d // H
+  out = torch.zeros(qkv.shape[0], d, device=qkv.device)
+  for b in range(B):
+    o, n = (b * S, S) if cu is None else (int(cu[b]), int(cu[b + 1] - cu[b]))
+    x = qkv[o:o + n]
+    q, k, v = (x[:, i * d:(i + 1) * d].reshape(n, H, dh).transpose(0, 1) for i in range(3))
+    s = q @ k.transpose(1, 2) * scale + bias[o:o + n][None, None, :]
+    p = torch.softmax(s, -1)
+    if mask is not None:
+      p = p * mask[b, :, :n, :n] * sc
+    out[o:o + n] = (p @ v).transpose(0, 1).reshape(n, d)
+  return out
+
+
+@pytest.mark.parametrize('B,S,H', [(2, 16, 2), (3, 37, 2), (2, 70, 4), (2, 218, 4), (1, 300, 2)])
+def test_attention_fwd_bwd_dense(B, S, H):
+  from mmt_amd import ops
+  d = H * 128
+  rows = B * S
+  R = ops.pad_rows(rows)
+  qkv = _rand((R, 3 * d), 1.0, seed=25, dtype=torch.bfloat16)
+  g = torch.Generator().manual_seed(26)
+  valid = (torch.rand(R, generator=g) > 0.3)
+  valid[::S] = True
+  bias = ((~valid).float() * -10000.0).to(_dev())
+  scale = 1.0 / math.sqrt(128.0)
+  ctx, lse = ops.attn_fwd(qkv, bias, B, S, H, scale)
+  x = qkv[:rows].float().requires_grad_(True)
+  ref = _attn_ref(x, bias, B, S, H, scale)
+  _close('attn.ctx', ctx[:rows], ref, 2e-2, 2e-2)
+  dctx = _rand((R, d), seed=27, dtype=torch.bfloat16)
+  ref.backward(dctx[:rows].float())
+  dqkv = ops.attn_bwd(qkv, bias, ctx, lse, dctx, B, S, H, scale)
+  for i, nm in enumerate('QKV'):
+    _close('attn.d' + nm, dqkv[:rows, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d], 4e-2, 4e-2)
+
+
+def test_attention_dropout_replay_and_varlen():
+  from mmt_amd import ops
+  B, S, H = 3, 50, 2
+  d = H * 128
+  scale = 1.0 / math.sqrt(128.0)
+  rows = B * S
+  R = ops.pad_rows(rows)
+  qkv = _rand((R, 3 * d), 1.0, seed=28, dtype=torch.bfloat16)
+  bias = torch.zeros(R, device=_dev())
+  bias[5:9] = -10000.0
+  # dropout: export the mask the kernel draws and replay it through the reference
+  mask = ops.attn_dropout_mask(B, H, S, 99, 0.1).float()
+  assert 0.88 < mask.mean().item() < 0.92
+  thr, sc = ops.dropout_params(0.1)
+  ctx, lse = ops.attn_fwd(qkv, bias, B, S, H, scale, drop_key=99, drop_p=0.1)
+  x = qkv[:rows].float().requires_grad_(True)
+  ref = _attn_ref(x, bias, B, S, H, scale, mask=mask, sc=sc)
+  _close('attn.drop ctx', ctx[:rows], ref, 2e-2, 2e-2)
+  dctx = _rand((R, d), seed=29, dtype=torch.bfloat16)
+  ref.backward(dctx[:rows].float())
+  dqkv = ops.attn_bwd(qkv, bias, ctx, lse, dctx, B, S, H, scale, drop_key=99, drop_p=0.1)
+  _close('attn.drop dqkv', dqkv[:rows], x.grad, 4e-2, 4e-2)
+  # variable-length packing: three samples of 11, 50, 30 rows
+  cu = torch.tensor([0, 11, 61, 91], dtype=torch.int32, device=_dev())
+  ctx2, lse2 = ops.attn_fwd(qkv, bias, 3, 50, H, scale, cu_seqlens=cu)
+  x2 = qkv[:91].float().requires_grad_(True)
+  ref2 = _attn_ref(x2, bias, 3, 50, H, scale, cu=cu.cpu())
+  _close('attn.varlen ctx', ctx2[:91], ref2, 2e-2, 2e-2)
+  ref2.backward(dctx[:91].float())
+  dqkv2 = ops.attn_bwd(qkv, bias, ctx2, lse2, dctx, 3, 50, H, scale, cu_seqlens=cu)
+  _close('attn.varlen dqkv', dqkv2[:91], x2.grad, 4e-2, 4e-2)
