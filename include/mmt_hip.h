@@ -57,6 +57,7 @@ typedef struct MmtEpilogue {
   int64_t ldaux;
   float* colsum;            /* nullable: [ceil(M/128), N] per-row-tile column sums of `out`     */
   const int32_t* row_index; /* nullable: row -> original token index (b*S+s) for the RNG        */
+  const uint32_t* seed_dev; /* nullable: per-step seed in device memory, hashed into drop_key   */
   uint32_t drop_key;        /* dropout stream key (seed, site, layer mixed by the host)         */
   uint32_t drop_thr16;      /* keep iff u16 >= thr16; 0 disables dropout                        */
   float drop_scale;         /* 1 / (1 - thr16/65536)                                            */
@@ -79,6 +80,162 @@ int mmt_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
                      int rows, int N, int K2, int splits, const int32_t* n_rows_dev, void* stream);
 int mmt_reduce_slabs(const float* ws, int splits, int64_t count, float* out, int accumulate,
                      void* stream);
+
+/* out[i] (+)= sum_s ws[s][i] over a [rows, cols_ws] slab keeping only the first cols_out columns
+ * (un-pads the K-padded ReduceDim weight gradients). */
+int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int cols_ws, int cols_out, float* out,
+                        int accumulate, void* stream);
+
+/* ---- LayerNorm / embeddings (norm.hip) ---------------------------------------------------------
+ * h = LN(z) over the last dim, fp32 statistics.  bert.py:188,236 (BertSelfOutput / BertOutput
+ * layer_norm; z is the pre-LN sum written by MMT_EPI_BIAS_DROP_RES).  d % 256 == 0, d <= 1024. */
+int mmt_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h32, void* h16,
+               float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev, void* stream);
+/* h = dropout(LN(features + type_emb[type_ids] + pos_emb[pos_ids]))   bert.py:87-105.
+ * z_save receives the pre-LN sum (needed by backward). pos_ids may be NULL (pos_enc='none'). */
+int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
+                     const float* type_emb, const float* pos_emb, float* z_save, const float* gamma,
+                     const float* beta, float eps, float* h32, void* h16, float* mean, float* rstd,
+                     int rows, int d, const int32_t* n_rows_dev, const int32_t* row_index,
+                     uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
+                     void* stream);
+/* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
+ * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
+ * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */
+int mmt_ln_bwd_rows_per_block(void);
+int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd, const float* gamma,
+               float* dz, void* dy, float* partials, int rows, int d, int drop_mode,
+               const int32_t* n_rows_dev, const int32_t* row_index, uint32_t drop_key, uint32_t thr16,
+               float drop_scale, const uint32_t* seed_dev, void* stream);
+/* out_j[c] (+)= sum_b partials[b][j][c], j < nvec <= 4 (NULL outputs are skipped); fixed order. */
+int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,
+                   float* out2, float* out3, int accumulate, void* stream);
+/* dtable[v] (+)= sum of g[row] over rows with ids[row] == v: gradient of nn.Embedding (bert.py:78-81)
+ * as a deterministic segmented sum (no atomics). */
+int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int vocab,
+                   const int32_t* n_rows_dev, float* dtable, int accumulate, void* stream);
+/* partials[blk][c] = column sums of a bf16 matrix over 32-row blocks (bias gradients). */
+int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t* n_rows_dev,
+                    float* partials, void* stream);
+
+/* ---- fused attention (attention.hip), head dim 128 ----------------------------------------------
+ * Replaces bert.py:141-168: softmax(QK^T/sqrt(dh) + mask_bias[key]) -> dropout -> .V, merged heads.
+ * qkv bf16 [rows, 3d]; sample b owns rows cu_seqlens[b]..cu_seqlens[b+1] (NULL => b*S..(b+1)*S);
+ * mask_bias fp32 [rows] is the additive key mask (0 / -10000, bert.py:395); lse fp32 [rows, H]. */
+int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx, float* lse,
+                 int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
+                 float drop_scale, const uint32_t* seed_dev, void* stream);
+/* Backward of the above (autograd of bert.py:141-168): dqkv bf16 [rows, 3d]; delta fp32 [rows,H] scratch. */
+int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
+                 const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H, int d,
+                 float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                 const uint32_t* seed_dev, void* stream);
+/* Test helper: the keep-mask mmt_attn_fwd draws, uint8 [B,H,S,S] (dense layout). */
+int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,
+                          const uint32_t* seed_dev, void* stream);
+
+/* ---- parameter packing / optimizer (elementwise.hip) --------------------------------------------- */
+#define MMT_PACK_MAX 24
+typedef struct MmtPackItem {
+  const float* src;  /* fp32 master [rows, cols]                                                   */
+  void* dst;         /* bf16 [rows, dst_ld], columns cols..dst_ld zero-filled                      */
+  void* dst_t;       /* nullable bf16 transposed copy [dst_t_rows >= cols, dst_t_ld >= rows]       */
+  int32_t rows, cols, dst_ld, dst_t_ld, dst_t_rows, reserved;
+} MmtPackItem;
+/* bf16 shadows of the fp32 master weights (and W^T copies for the input-gradient GEMMs). */
+int mmt_pack_weights(const MmtPackItem* items, int n, void* stream);
+/* torch.optim.Adam step (train.py:100) over one flat fp32 buffer; step_dev = 1-based step on device. */
+int mmt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  const int32_t* step_dev, void* stream);
+
+/* ---- video tokens (assemble.hip) -------------------------------------------------------------------
+ * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip. */
+#define MMT_MAX_EXPERTS 16
+typedef struct MmtExpertIO {
+  const float* feat;     /* [B, T, D] fp32  features[mod]                                        */
+  const float* maxpool;  /* [B, D] fp32     features_maxpool[mod]                                */
+  const float* ind;      /* [B, T] fp32     features_ind[mod]                                    */
+  const float* t;        /* [B, T] fp32     features_t[mod]                                      */
+  void* x;               /* bf16 [rows_pad, Dpad] GEMM input (rows: B*T feature rows then B maxpool rows) */
+  float* y;              /* fp32 [rows_pad, d] ReduceDim.fc output (pre-normalisation)           */
+  void* dy;              /* bf16 [rows_pad, d] gradient wrt y (backward)                         */
+  int32_t D, Dpad, type_idx, rows_pad;
+} MmtExpertIO;
+/* Token plan: slot[b*S+s] -> row (or -1), cu_seqlens[B+1], *n_rows_dev, and per-row row_index (b*S+s),
+ * type_ids, pos_ids (clamp(features_t,0,max_pos) model.py:516-520), mask_bias, agg_row[b*M+m].
+ * pack=0 keeps all S=1+M*(T+1) slots; pack=1 drops padded FEA tokens (exact, see assemble.hip). */
+int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos, int32_t* counts,
+                   int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot, int32_t* row_index,
+                   int32_t* type_ids, int32_t* pos_ids, float* mask_bias, int32_t* agg_row, void* stream);
+int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, void* stream);
+int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
+                      float* features, void* stream);
+int mmt_video_scatter_bwd(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
+                          const float* dfeatures, void* stream);
+
+/* ---- read-out, similarity, losses (simloss.hip) --------------------------------------------------- */
+/* vid_embds[i] = F.normalize(last_hidden[agg_row[i]]), i < B*M      model.py:583-587,621-625 */
+int mmt_readout_fwd(const float* last_hidden, const int32_t* agg_row, int BM, int d, float* vid_embds,
+                    float* inv_norm, void* stream);
+/* writes the B*M AGG rows of dlast_hidden (all other rows must be zero beforehand) */
+int mmt_readout_bwd(const float* vid_embds, const float* inv_norm, const float* dvid_embds,
+                    const int32_t* agg_row, int BM, int d, float* dlast_hidden, void* stream);
+/* sharded_cross_view_inner_product, model.py:789-837: txt [NT,M,d], vid [NV,M,d], tw [NT,M], vw [NV,M]
+ * -> sims [NT,NV] (rows = text); dots [NT,NV,M] is saved for backward. */
+int mmt_sims_fwd(const float* txt, const float* vid, const float* tw, const float* vw, int NT, int NV, int M,
+                 int d, float* sims, float* dots, void* stream);
+int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, const float* dots,
+                 const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
+                 float* dvw, void* stream);
+/* MaxMarginRankingLoss.forward (loss.py:38-65): loss scalar + d loss/d sims; partial = n floats scratch. */
+int mmt_maxmargin(const float* sims, int n, float margin, int fix_norm, float* partial, float* loss,
+                  float* grad, void* stream);
+/* InfoNceLoss.forward (loss.py:68-81); scratch = 3n floats. */
+int mmt_infonce(const float* sims, int n, float* scratch, float* loss, float* grad, void* stream);
+
+/* ---- whole-encoder engine (bert_engine.hip) --------------------------------------------------------
+ * One call runs every kernel of model/bert.py BertModel.forward (bert.py:371-414, without the unused
+ * pooler) resp. its autograd backward on `stream`.  Pointers in MmtBertLayer/MmtBertModel address the
+ * caller's flat parameter / shadow / gradient buffers (mmt_amd/flat.py); `ws` is a caller-allocated
+ * workspace of mmt_bert_workspace_bytes() that carries the saved activations from forward to backward. */
+typedef struct MmtBertLayer {
+  const void *wqkv, *wqkv_t, *wo, *wo_t, *w1, *w1_t, *w2, *w2_t;              /* bf16 shadows            */
+  const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b;           /* fp32 master             */
+  float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_ln1_g, *g_ln1_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2_g, *g_ln2_b;
+} MmtBertLayer;
+
+typedef struct MmtBertModel {
+  int32_t hidden, layers, heads, inter, max_pos, type_vocab;
+  float ln_eps, p_hidden, p_attn;
+  int32_t reserved;
+  const float *pos_emb, *type_emb, *emb_ln_g, *emb_ln_b;
+  float *g_pos_emb, *g_type_emb, *g_emb_ln_g, *g_emb_ln_b;
+  const MmtBertLayer* layer; /* host array [layers] */
+} MmtBertModel;
+
+typedef struct MmtBertBatch {
+  const float* features;      /* [rows_alloc, hidden] fp32 token features (bert.py:98 `features`)        */
+  const int32_t* type_ids;    /* [rows] token_type_ids                                                  */
+  const int32_t* pos_ids;     /* [rows] position_ids, NULL for pos_enc='none'                           */
+  const float* mask_bias;     /* [rows] (1 - attention_mask) * -10000   (bert.py:386-395)               */
+  const int32_t* cu_seqlens;  /* [batch+1] or NULL (dense: sample b owns rows b*seq..)                  */
+  const int32_t* row_index;   /* [rows] row -> b*seq+s (RNG coordinates) or NULL (identity)             */
+  const int32_t* n_rows_dev;  /* live row count on device or NULL (= rows)                              */
+  const uint32_t* seed_dev;   /* per-step dropout seed on device or NULL                                */
+  int32_t rows, rows_alloc, batch, seq;
+} MmtBertBatch;
+
+int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc);
+/* out_last: fp32 [rows_alloc, hidden] last-layer hidden states (sequence_output).  training != 0 enables
+ * dropout with p_hidden / p_attn. */
+int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last, int training,
+                     void* stream);
+/* dlast: fp32 [rows_alloc, hidden] gradient of sequence_output (overwritten as scratch);
+ * dfeatures: fp32 [rows_alloc, hidden] gradient wrt `features`; parameter gradients are WRITTEN (not
+ * accumulated) through the g_* pointers. */
+int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast, float* dfeatures,
+                      int training, void* stream);
 
 #ifdef __cplusplus
 }

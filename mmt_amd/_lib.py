@@ -14,8 +14,44 @@ c_int, c_i64, c_u32, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
 
 class MmtEpilogue(ctypes.Structure):
   _fields_ = [('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('out2', c_vp), ('ldout2', c_i64),
-              ('aux', c_vp), ('ldaux', c_i64), ('colsum', c_vp), ('row_index', c_vp),
+              ('aux', c_vp), ('ldaux', c_i64), ('colsum', c_vp), ('row_index', c_vp), ('seed_dev', c_vp),
               ('drop_key', c_u32), ('drop_thr16', c_u32), ('drop_scale', c_f32), ('reserved', ctypes.c_int32)]
+
+
+class MmtPackItem(ctypes.Structure):
+  _fields_ = [('src', c_vp), ('dst', c_vp), ('dst_t', c_vp), ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+              ('dst_ld', ctypes.c_int32), ('dst_t_ld', ctypes.c_int32), ('dst_t_rows', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
+
+
+class MmtExpertIO(ctypes.Structure):
+  _fields_ = [('feat', c_vp), ('maxpool', c_vp), ('ind', c_vp), ('t', c_vp), ('x', c_vp), ('y', c_vp), ('dy', c_vp),
+              ('D', ctypes.c_int32), ('Dpad', ctypes.c_int32), ('type_idx', ctypes.c_int32),
+              ('rows_pad', ctypes.c_int32)]
+
+
+_LAYER_PTRS = ['wqkv', 'wqkv_t', 'wo', 'wo_t', 'w1', 'w1_t', 'w2', 'w2_t',
+               'bqkv', 'bo', 'ln1_g', 'ln1_b', 'b1', 'b2', 'ln2_g', 'ln2_b',
+               'g_wqkv', 'g_bqkv', 'g_wo', 'g_bo', 'g_ln1_g', 'g_ln1_b', 'g_w1', 'g_b1', 'g_w2', 'g_b2',
+               'g_ln2_g', 'g_ln2_b']
+
+
+class MmtBertLayer(ctypes.Structure):
+  _fields_ = [(n, c_vp) for n in _LAYER_PTRS]
+
+
+class MmtBertModel(ctypes.Structure):
+  _fields_ = ([(n, ctypes.c_int32) for n in ('hidden', 'layers', 'heads', 'inter', 'max_pos', 'type_vocab')] +
+              [(n, c_f32) for n in ('ln_eps', 'p_hidden', 'p_attn')] + [('reserved', ctypes.c_int32)] +
+              [(n, c_vp) for n in ('pos_emb', 'type_emb', 'emb_ln_g', 'emb_ln_b', 'g_pos_emb', 'g_type_emb',
+                                   'g_emb_ln_g', 'g_emb_ln_b')] +
+              [('layer', ctypes.POINTER(MmtBertLayer))])
+
+
+class MmtBertBatch(ctypes.Structure):
+  _fields_ = ([(n, c_vp) for n in ('features', 'type_ids', 'pos_ids', 'mask_bias', 'cu_seqlens', 'row_index',
+                                   'n_rows_dev', 'seed_dev')] +
+              [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')])
 
 
 EPI = dict(BF16=0, BIAS_BF16=1, BIAS_GELU=2, BIAS_DROP_RES=3, DGELU=4, ADD_F32=5, F32=6, BIAS_F32=7)
@@ -30,17 +66,37 @@ SIGNATURES = {
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
-                                 c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp]),
+                                 c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_ln_bwd_rows_per_block': (c_int, []),
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
-                           c_u32, c_u32, c_f32, c_vp]),
+                           c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     'mmt_attn_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
-                             c_f32, c_vp]),
+                             c_f32, c_vp, c_vp]),
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
-                             c_u32, c_u32, c_f32, c_vp]),
-    'mmt_attn_dropout_mask': (c_int, [c_vp, c_int, c_int, c_int, c_u32, c_u32, c_vp]),
+                             c_u32, c_u32, c_f32, c_vp, c_vp]),
+    'mmt_attn_dropout_mask': (c_int, [c_vp, c_int, c_int, c_int, c_u32, c_u32, c_vp, c_vp]),
+    'mmt_reduce_slabs_2d': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    'mmt_colsum_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_pack_weights': (c_int, [ctypes.POINTER(MmtPackItem), c_int, c_vp]),
+    'mmt_adam_step': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
+    'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_vp]),
+    'mmt_video_scatter': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_video_scatter_bwd': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_readout_fwd': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_readout_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'mmt_sims_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_sims_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                             c_vp]),
+    'mmt_maxmargin': (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_infonce': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_bert_workspace_bytes': (c_i64, [ctypes.POINTER(MmtBertModel), c_int]),
+    'mmt_bert_forward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_int, c_vp]),
+    'mmt_bert_backward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp, c_int,
+                                  c_vp]),
 }
 
 _lib = None

@@ -80,6 +80,7 @@ struct AttnArgs {
   float* delta;                        // [rows, H] bwd scratch: rowsum(dO * O)
   int H, d; float scale;
   uint32_t drop_key, thr16; float drop_scale; int S4;
+  const uint32_t* seed_dev;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
     qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
-  const unsigned rowkey = attn_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
+  const unsigned rowkey = attn_rowkey(eff_key(a.drop_key, a.seed_dev), (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
   const float c1 = a.scale * LOG2E;
 
   f32x4 o[8];
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   dl += __shfl_xor(dl, 32, 64);
   if (q_ok && lg == 0) a.delta[(int64_t)qrow * a.H + h] = dl;
   const float lse2 = a.lse[(int64_t)qrow * a.H + h] * LOG2E;
-  const unsigned rowkey = attn_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
+  const unsigned rowkey = attn_rowkey(eff_key(a.drop_key, a.seed_dev), (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
   const float c1 = a.scale * LOG2E;
 
   f32x4 o[8];
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float bias2 = key_ok ? a.mask_bias[krow] * LOG2E : -INFINITY;
   const float c1 = a.scale * LOG2E;
   const unsigned bh = (unsigned)(b * a.H + h);
+  const unsigned dkey = eff_key(a.drop_key, a.seed_dev);
 
   f32x4 dk[8], dv[8];
 #pragma unroll
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       float* ax = aux_s + st * 192;
       ax[tid] = q < Sb ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
       ax[64 + tid] = a.delta[(int64_t)row * a.H + h];
-      ax[128 + tid] = __uint_as_float(attn_rowkey(a.drop_key, bh, (unsigned)a.S4, (unsigned)q));
+      ax[128 + tid] = __uint_as_float(attn_rowkey(dkey, bh, (unsigned)a.S4, (unsigned)q));
     }
   };
   stage(0, 0);
@@ -398,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // test helper: materialise the attention dropout keep-mask, uint8 [B,H,S,S] (dense layout only)
-__global__ void attn_mask_export_kernel(uint8_t* out, int B, int H, int S, int S4, uint32_t key, uint32_t thr16) {
+__global__ void attn_mask_export_kernel(uint8_t* out, int B, int H, int S, int S4, uint32_t key_in, uint32_t thr16,
+                                        const uint32_t* seed_dev) {
+  const unsigned key = eff_key(key_in, seed_dev);
   const int64_t n = (int64_t)B * H * S * S;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % S), q = (int)((i / S) % S);
@@ -416,13 +420,13 @@ static int check_args(const void* qkv, int B, int S, int H, int d) {
 
 extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx,
                             float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key,
-                            uint32_t thr16, float drop_scale, void* stream) {
+                            uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
-  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -430,14 +434,14 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
 extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                             const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
                             int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                            void* stream) {
+                            const uint32_t* seed_dev, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
-  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   const dim3 grid((S + 63) / 64, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -445,9 +449,9 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
 }
 
 extern "C" int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,
-                                     void* stream) {
+                                     const uint32_t* seed_dev, void* stream) {
   if (!out) return MMT_ERR_ARG;
   hipLaunchKernelGGL(attn_mask_export_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, B, H, S,
-                     (S + 3) & ~3, drop_key, thr16);
+                     (S + 3) & ~3, drop_key, thr16, seed_dev);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,204 @@
+// Host-side engine: chains the gfx950 kernels into model/bert.py BertModel forward / backward.
+// No device code here; everything is asynchronous launches on the caller's stream (graph-capturable).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmt_hip.h"
+
+namespace {
+
+enum { SITE_EMB = 0, SITE_PROBS = 1, SITE_ATTN_OUT = 2, SITE_FFN_OUT = 3 };
+inline uint32_t site_key(int layer, int site) { return 0x5eed0000u + (uint32_t)layer * 16u + (uint32_t)site; }
+inline uint32_t thr16_of(float p) { int t = (int)(p * 65536.0f + 0.5f); return t < 0 ? 0u : (uint32_t)t; }
+inline float scale_of(uint32_t thr) { return thr ? 1.0f / (1.0f - (float)thr / 65536.0f) : 1.0f; }
+
+struct LayerWs {
+  char *qkv, *ctx, *a16, *hpre, *g, *h16;
+  float *lse, *z1, *mean1, *rstd1, *a32, *z2, *mean2, *rstd2, *h32;
+};
+struct Ws {
+  float *z0, *mean0, *rstd0, *h32_in;
+  char* h16_in;
+  LayerWs layer[64];
+  float *dz, *dA, *delta, *ln_partials, *col_partials, *slabs;
+  char *dy, *dhpre, *dctx, *dqkv;
+  size_t bytes;
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int tn_splits(int N, int K2, int rows) {
+  const int tiles = (N / 128) * (K2 / 128);
+  int s = (384 + tiles - 1) / tiles;
+  const int ktiles = (rows + 63) / 64;
+  if (s > ktiles) s = ktiles;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
+  const size_t d = m->hidden, I = m->inter, H = m->heads;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+  w->z0 = (float*)take(R * d * 4); w->mean0 = (float*)take(R * 4); w->rstd0 = (float*)take(R * 4);
+  w->h32_in = (float*)take(R * d * 4); w->h16_in = take(R * d * 2);
+  for (int l = 0; l < m->layers; ++l) {
+    LayerWs& L = w->layer[l];
+    L.qkv = take(R * 3 * d * 2); L.ctx = take(R * d * 2); L.lse = (float*)take(R * H * 4);
+    L.z1 = (float*)take(R * d * 4); L.mean1 = (float*)take(R * 4); L.rstd1 = (float*)take(R * 4);
+    L.a32 = (float*)take(R * d * 4); L.a16 = take(R * d * 2);
+    L.hpre = take(R * I * 2); L.g = take(R * I * 2);
+    L.z2 = (float*)take(R * d * 4); L.mean2 = (float*)take(R * 4); L.rstd2 = (float*)take(R * 4);
+    L.h32 = (float*)take(R * d * 4); L.h16 = take(R * d * 2);
+  }
+  w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
+  w->dy = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
+  w->delta = (float*)take(R * H * 4);
+  const size_t rpb = (size_t)mmt_ln_bwd_rows_per_block();
+  w->ln_partials = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
+  size_t cp = (size_t)((R + 31) / 32) * 3 * d;            // colsum of dqkv
+  const size_t cp2 = (size_t)((R + 127) / 128) * I;       // DGELU epilogue column sums
+  if (cp2 > cp) cp = cp2;
+  w->col_partials = (float*)take(cp * 4);
+  size_t slab = 0;
+  const int shapes[4][2] = {{(int)(3 * d), (int)d}, {(int)d, (int)d}, {(int)I, (int)d}, {(int)d, (int)I}};
+  for (auto& s : shapes) {
+    const size_t need = (size_t)tn_splits(s[0], s[1], R) * s[0] * s[1];
+    if (need > slab) slab = need;
+  }
+  w->slabs = (float*)take(slab * 4);
+  w->bytes = off;
+}
+
+int check_model(const MmtBertModel* m, const MmtBertBatch* b) {
+  if (!m || !b || !m->layer) return MMT_ERR_ARG;
+  if (m->layers <= 0 || m->layers > 64) return MMT_ERR_ARG;
+  if (m->hidden != m->heads * 128) return MMT_ERR_ARG;      // head dim 128
+  if (m->hidden % 256 || m->hidden > 1024 || m->inter % 128) return MMT_ERR_ARG;
+  if (b->rows <= 0 || b->rows > b->rows_alloc || b->rows_alloc % MMT_ROW_ALIGN) return MMT_ERR_ARG;
+  if (!b->features || !b->type_ids || !b->mask_bias) return MMT_ERR_ARG;
+  return 0;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int wgrad(const void* A, int N, const void* B, int K2, int rows, float* slabs, float* out, const int32_t* nr,
+          void* stream) {
+  const int splits = tn_splits(N, K2, rows);
+  TRY(mmt_gemm_tn_bf16(A, N, B, K2, slabs, rows, N, K2, splits, nr, stream));
+  return mmt_reduce_slabs(slabs, splits, (int64_t)N * K2, out, 0, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc) {
+  if (!m || rows_alloc <= 0 || m->layers > 64) return MMT_ERR_ARG;
+  Ws w;
+  layout(m, rows_alloc, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+
+extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last,
+                                int training, void* stream) {
+  TRY(check_model(m, b));
+  if (!ws || !out_last) return MMT_ERR_ARG;
+  Ws w;
+  layout(m, b->rows_alloc, (char*)ws, &w);
+  const int d = m->hidden, I = m->inter, rows = b->rows;
+  const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
+  const float sh = scale_of(th), sa = scale_of(ta);
+  const float qk_scale = 0.08838834764831845f;  // 1/sqrt(128)
+
+  TRY(mmt_embed_ln_fwd(b->features, b->type_ids, b->pos_ids, m->type_emb, m->pos_emb, w.z0, m->emb_ln_g,
+                       m->emb_ln_b, m->ln_eps, w.h32_in, w.h16_in, w.mean0, w.rstd0, rows, d, b->n_rows_dev,
+                       b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
+  const float* hin32 = w.h32_in;
+  const char* hin16 = w.h16_in;
+  for (int l = 0; l < m->layers; ++l) {
+    const MmtBertLayer& P = m->layer[l];
+    LayerWs& L = w.layer[l];
+    MmtEpilogue e = {};
+    e.bias = P.bqkv;
+    TRY(mmt_gemm_nt_bf16(hin16, d, P.wqkv, d, L.qkv, 3 * d, rows, 3 * d, d, MMT_EPI_BIAS_BF16, &e, b->n_rows_dev, stream));
+    TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
+                     site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+    e = {};
+    e.bias = P.bo; e.res = hin32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
+    e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
+    TRY(mmt_gemm_nt_bf16(L.ctx, d, P.wo, d, L.z1, d, rows, d, d, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
+    TRY(mmt_ln_fwd(L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, b->n_rows_dev, stream));
+    e = {};
+    e.bias = P.b1; e.out2 = L.g; e.ldout2 = I;
+    TRY(mmt_gemm_nt_bf16(L.a16, d, P.w1, d, L.hpre, I, rows, I, d, MMT_EPI_BIAS_GELU, &e, b->n_rows_dev, stream));
+    e = {};
+    e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
+    e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
+    TRY(mmt_gemm_nt_bf16(L.g, I, P.w2, I, L.z2, d, rows, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
+    float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
+    TRY(mmt_ln_fwd(L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16, L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
+    hin32 = hout32;
+    hin16 = L.h16;
+  }
+  return 0;
+}
+
+extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
+                                 float* dfeatures, int training, void* stream) {
+  TRY(check_model(m, b));
+  if (!ws || !dlast || !dfeatures) return MMT_ERR_ARG;
+  Ws w;
+  layout(m, b->rows_alloc, (char*)ws, &w);
+  const int d = m->hidden, I = m->inter, rows = b->rows;
+  const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
+  const float sh = scale_of(th), sa = scale_of(ta);
+  const float qk_scale = 0.08838834764831845f;
+  const int rpb = mmt_ln_bwd_rows_per_block();
+  const int ln_blocks = (rows + rpb - 1) / rpb;
+  const int32_t* nr = b->n_rows_dev;
+
+  float* dcur = dlast;  // gradient wrt the current layer's output
+  for (int l = m->layers - 1; l >= 0; --l) {
+    const MmtBertLayer& P = m->layer[l];
+    LayerWs& L = w.layer[l];
+    const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
+    // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
+    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy, w.ln_partials, rows, d, 1, nr, b->row_index,
+                   site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
+    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln2_g, P.g_ln2_b, P.g_b2, nullptr, 0, stream));
+    TRY(wgrad(w.dy, d, L.g, I, rows, w.slabs, P.g_w2, nr, stream));
+    MmtEpilogue e = {};
+    e.aux = L.hpre; e.ldaux = I; e.colsum = w.col_partials;
+    TRY(mmt_gemm_nt_bf16(w.dy, d, P.w2_t, d, w.dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
+    TRY(mmt_col_reduce(w.col_partials, (rows + 127) / 128, 1, I, P.g_b1, nullptr, nullptr, nullptr, 0, stream));
+    // --- BertIntermediate: dense(d->I) ---
+    TRY(wgrad(w.dhpre, I, L.a16, d, rows, w.slabs, P.g_w1, nr, stream));
+    e = {};
+    e.res = w.dz; e.ldres = d;
+    TRY(mmt_gemm_nt_bf16(w.dhpre, I, P.w1_t, I, w.dA, d, rows, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
+    // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
+    TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials, rows, d, 1, nr, b->row_index,
+                   site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln1_g, P.g_ln1_b, P.g_bo, nullptr, 0, stream));
+    TRY(wgrad(w.dy, d, L.ctx, d, rows, w.slabs, P.g_wo, nr, stream));
+    e = {};
+    TRY(mmt_gemm_nt_bf16(w.dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
+    // --- BertSelfAttention ---
+    TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, w.dqkv, w.delta, b->batch, b->seq,
+                     m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+    TRY(mmt_colsum_bf16(w.dqkv, 3 * d, rows, 3 * d, nr, w.col_partials, stream));
+    TRY(mmt_col_reduce(w.col_partials, (rows + 31) / 32, 1, 3 * d, P.g_bqkv, nullptr, nullptr, nullptr, 0, stream));
+    TRY(wgrad(w.dqkv, 3 * d, hin16, d, rows, w.slabs, P.g_wqkv, nr, stream));
+    e = {};
+    e.res = w.dz; e.ldres = d;
+    float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
+    // dA was consumed by the LN1 backward above, so it is free again here.
+    TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+    dcur = dnext;
+  }
+  // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---
+  TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials, rows, d, 2, nr,
+                 b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
+  TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, m->g_emb_ln_g, m->g_emb_ln_b, nullptr, nullptr, 0, stream));
+  TRY(mmt_table_grad(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, m->g_type_emb, 0, stream));
+  if (b->pos_ids) TRY(mmt_table_grad(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, m->g_pos_emb, 0, stream));
+  return 0;
+}

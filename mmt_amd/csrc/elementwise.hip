@@ -1,0 +1,132 @@
+// Memory-bound utility kernels (gfx950): weight packing fp32 -> bf16 (+ transposed copy for the
+// input-gradient GEMMs), bf16 column sums (bias gradients), padded slab reduction, fused Adam.
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+// ---- weight packing ----------------------------------------------------------------------------
+// One launch packs up to MMT_PACK_MAX matrices: dst[r][c] = bf16(src[r][c]) for c < cols, 0 for
+// cols <= c < dst_ld; optional dst_t[c][r] (ld = dst_t_ld, rows padded with zeros up to dst_t_rows).
+struct PackTable { MmtPackItem item[MMT_PACK_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackTable tab) {
+  __shared__ float tile[64][65];
+  const MmtPackItem it = tab.item[blockIdx.y];
+  const int tiles_c = (it.dst_ld + 63) / 64, tiles_r = (it.rows + 63) / 64;
+  if ((int)blockIdx.x >= tiles_c * tiles_r) return;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < it.rows && c < it.cols) v = it.src[(int64_t)r * it.cols + c];
+    tile[i][tx] = v;
+    if (r < it.rows && c < it.dst_ld) ((bf16_t*)it.dst)[(int64_t)r * it.dst_ld + c] = f2bf(v);
+  }
+  if (!it.dst_t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {  // transposed: row = source column, col = source row
+    const int c = c0 + i, r = r0 + tx;
+    if (c < it.dst_t_rows && r < it.dst_t_ld) ((bf16_t*)it.dst_t)[(int64_t)c * it.dst_t_ld + r] = f2bf(tile[tx][i]);
+  }
+}
+
+extern "C" int mmt_pack_weights(const MmtPackItem* items, int n, void* stream) {
+  if (!items || n <= 0) return MMT_ERR_ARG;
+  for (int base = 0; base < n; base += MMT_PACK_MAX) {
+    PackTable tab;
+    tab.n = n - base < MMT_PACK_MAX ? n - base : MMT_PACK_MAX;
+    int max_tiles = 0;
+    for (int i = 0; i < tab.n; ++i) {
+      const MmtPackItem& it = items[base + i];
+      if (!it.src || !it.dst || it.rows <= 0 || it.cols <= 0 || it.dst_ld < it.cols) return MMT_ERR_ARG;
+      if (it.dst_t && (it.dst_t_ld < it.rows || it.dst_t_rows < it.cols)) return MMT_ERR_ARG;
+      tab.item[i] = it;
+      const int t = ((it.dst_ld + 63) / 64) * ((it.rows + 63) / 64);
+      max_tiles = t > max_tiles ? t : max_tiles;
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(max_tiles, tab.n), dim3(256), 0, (hipStream_t)stream, tab);
+  }
+  return (int)hipGetLastError();
+}
+
+// ---- bf16 column sums: partials[blk][c] = sum over the block's 32 rows -------------------------
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int rows, int cols,
+                                                          const int32_t* __restrict__ n_rows_dev,
+                                                          float* __restrict__ partials) {
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= cols) return;
+  const int r0 = blockIdx.x * 32, r1 = min(nrows, r0 + 32);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    const u32x2 v = *(const u32x2*)(x + (int64_t)r * ld + c);
+    s[0] += bf2f((bf16_t)(v[0] & 0xffff)); s[1] += bf2f((bf16_t)(v[0] >> 16));
+    s[2] += bf2f((bf16_t)(v[1] & 0xffff)); s[3] += bf2f((bf16_t)(v[1] >> 16));
+  }
+  *(f32x4*)(partials + (int64_t)blockIdx.x * cols + c) = s;
+}
+
+extern "C" int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t* n_rows_dev,
+                               float* partials, void* stream) {
+  if (!x || !partials || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3)) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((rows + 31) / 32, (cols + 1023) / 1024), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, n_rows_dev, partials);
+  return (int)hipGetLastError();
+}
+
+// ---- slab reduction with column un-padding: out[r][c] (+)= sum_s ws[s][r][c], c < cols_out ------
+__global__ void reduce_slabs_2d_kernel(const float* __restrict__ ws, int splits, int rows, int cols_ws, int cols_out,
+                                       float* __restrict__ out, int accumulate) {
+  const int64_t n = (int64_t)rows * cols_out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_out), c = (int)(i % cols_out);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[((int64_t)k * rows + r) * cols_ws + c];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+extern "C" int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int cols_ws, int cols_out, float* out,
+                                   int accumulate, void* stream) {
+  if (!ws || !out || splits <= 0 || rows <= 0 || cols_out <= 0 || cols_out > cols_ws) return MMT_ERR_ARG;
+  const int64_t n = (int64_t)rows * cols_out;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(reduce_slabs_2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, splits, rows,
+                     cols_ws, cols_out, out, accumulate);
+  return (int)hipGetLastError();
+}
+
+// ---- fused Adam over a flat fp32 buffer (torch.optim.Adam semantics, train.py:100) --------------
+// p, m, v updated in place from g; `step_dev` holds the 1-based step count on the device (graph safe).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                                                   const int32_t* __restrict__ step_dev) {
+  const float t = (float)*step_dev;
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = gv[k] + weight_decay * pv[k];
+      mv[k] = beta1 * mv[k] + (1.0f - beta1) * gg;
+      vv[k] = beta2 * vv[k] + (1.0f - beta2) * gg * gg;
+      const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+      pv[k] -= step_size * (mv[k] / denom);
+    }
+    ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+  }
+}
+
+extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                             float lr, float beta1, float beta2, float eps, float weight_decay,
+                             const int32_t* step_dev, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || count <= 0 || (count & 3)) return MMT_ERR_ARG;
+  const int64_t n4 = count / 4;
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step_dev);
+  return (int)hipGetLastError();
+}

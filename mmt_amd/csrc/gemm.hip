@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   const int tm = id / tiles_n, tn = id % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nrows = n_rows_dev ? *n_rows_dev : M;
-  if (m0 >= nrows) return;
+  if (m0 >= nrows) {  // dead tile (variable-length packing): contributes zeros to the column sums
+    if constexpr (EPI == MMT_EPI_DGELU) {
+      if (epi.colsum && threadIdx.x < BN) epi.colsum[(int64_t)tm * N + n0 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         if (epi.drop_thr16) {
           const int orow = epi.row_index ? epi.row_index[row] : row;
           bool k[4];
-          keep4(epi.drop_key, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+          keep4(eff_key(epi.drop_key, epi.seed_dev), (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = k[r] ? v[r] * epi.drop_scale : 0.f;
         }

@@ -52,6 +52,12 @@ __device__ __forceinline__ void keep4(unsigned key, unsigned long long idx, unsi
   k[2] = (r1 & 0xffffU) >= thr16; k[3] = (r1 >> 16) >= thr16;
 }
 
+// Per-step seed lives in device memory (kernel arguments are frozen under hipGraph replay): the
+// effective stream key is a hash of the by-value site key and *seed_dev.
+__device__ __forceinline__ unsigned eff_key(unsigned key, const unsigned* __restrict__ seed_dev) {
+  return seed_dev ? mix32(key ^ mix32(*seed_dev + 0x632be5abU)) : key;
+}
+
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)

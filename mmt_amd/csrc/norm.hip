@@ -18,11 +18,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const float* __restrict__ type_emb, const float* __restrict__ pos_emb, float* __restrict__ z_save,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ h32,
     bf16_t* __restrict__ h16, float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
-    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key,
-    uint32_t thr16, float drop_scale) {
+    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
+    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int nch = d >> 8;
+  const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
     f32x4 x[MAXC];
     float s = 0.f;
@@ -80,9 +81,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ z, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, float* __restrict__ dz_out,
     bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows, int d, int rows_per_block,
-    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key,
-    uint32_t thr16, float drop_scale) {
+    const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
+    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
   __shared__ float red[4][3][MAXC * 256];
+  const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int nch = d >> 8;
@@ -216,7 +218,7 @@ extern "C" int mmt_ln_fwd(const float* z, const float* gamma, const float* beta,
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
                      nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f);
+                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f, nullptr);
   return (int)hipGetLastError();
 }
 
@@ -225,14 +227,14 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
                                 const float* gamma, const float* beta, float eps, float* h32, void* h16,
                                 float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev,
                                 const int32_t* row_index, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                                void* stream) {
+                                const uint32_t* seed_dev, void* stream) {
   if (!features || !type_ids || !type_emb || !gamma || !beta || !h16 || !mean || !rstd || rows <= 0)
     return MMT_ERR_ARG;
   if (pos_ids && !pos_emb) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, features,
                      type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale);
+                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev);
   return (int)hipGetLastError();
 }
 
@@ -241,14 +243,15 @@ extern "C" int mmt_ln_bwd_rows_per_block(void) { return 32; }
 extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
                           const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
                           int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
-                          uint32_t drop_key, uint32_t thr16, float drop_scale, void* stream) {
+                          uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
+                          void* stream) {
   if (!dout || !z || !mean || !rstd || !gamma || !partials || rows <= 0) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   const int rpb = 32, grid = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(MODE)                                                                            \
   hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), 0, s, dout, z, mean, rstd, gamma, dz, \
-                     (bf16_t*)dy, partials, rows, d, rpb, n_rows_dev, row_index, drop_key, thr16, drop_scale)
+                     (bf16_t*)dy, partials, rows, d, rpb, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev)
   if (drop_mode == 0) LN_BWD_LAUNCH(0);
   else if (drop_mode == 1) LN_BWD_LAUNCH(1);
   else if (drop_mode == 2) LN_BWD_LAUNCH(2);

@@ -1,0 +1,274 @@
+// Expert read-out, gated text-video similarity and the max-margin ranking loss (gfx950).
+//
+//   readout  : vid_embds[b][m] = F.normalize(last_hidden[agg_row[b][m]])     model.py:583-587,621-625
+//   sims     : sims[t][v] = sum_m w[t][v][m] <T[t][m], V[v][m]>,  w = tw*vw / sum_m(tw*vw) (0 -> 1e-5)
+//              model.py:789-837 (sharded_cross_view_inner_product), fp32
+//   loss     : MaxMarginRankingLoss (loss.py:38-65) in closed form + its gradient matrix; InfoNCE (:68-81)
+//
+// These are tiny (n = batch of pairs), latency-bound fp32 kernels: one block per text row / video column,
+// wave-level dot products, fixed summation orders (deterministic).
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define MAXM MMT_MAX_EXPERTS
+
+// ---- read-out --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void readout_fwd_kernel(const float* __restrict__ last, const int32_t* __restrict__ agg_row,
+                                                          int BM, int d, float* __restrict__ out, float* __restrict__ inv_norm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < BM; i += gridDim.x * 4) {
+    const float* src = last + (int64_t)agg_row[i] * d;
+    float ss = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 v = *(const f32x4*)(src + c);
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int c = lane * 4; c < d; c += 256) *(f32x4*)(out + (int64_t)i * d + c) = *(const f32x4*)(src + c) * inv;
+    if (lane == 0) inv_norm[i] = inv;
+  }
+}
+
+// dlast[agg_row] = (g - yhat (yhat.g)) * inv ; every other row of dlast must already be zero
+__global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ inv_norm,
+                                                          const float* __restrict__ demb, const int32_t* __restrict__ agg_row,
+                                                          int BM, int d, float* __restrict__ dlast) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < BM; i += gridDim.x * 4) {
+    float dot = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 y = *(const f32x4*)(emb + (int64_t)i * d + c), g = *(const f32x4*)(demb + (int64_t)i * d + c);
+      dot += y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
+    }
+    dot = wave_sum(dot);
+    const float inv = inv_norm[i];
+    float* dst = dlast + (int64_t)agg_row[i] * d;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 y = *(const f32x4*)(emb + (int64_t)i * d + c), g = *(const f32x4*)(demb + (int64_t)i * d + c);
+      *(f32x4*)(dst + c) = (g - y * dot) * inv;
+    }
+  }
+}
+
+// ---- similarity ------------------------------------------------------------------------------------
+// txt [NT][M][d], vid [NV][M][d], tw [NT][M], vw [NV][M]; sims [NT][NV]; dots [NT][NV][M] saved for backward.
+__global__ __launch_bounds__(256) void sims_fwd_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
+                                                       const float* __restrict__ tw, const float* __restrict__ vw, int NT,
+                                                       int NV, int M, int d, float* __restrict__ sims,
+                                                       float* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) float ts[];  // [M][d] text row
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x * 4; i < M * d; i += 1024) *(f32x4*)(ts + i) = *(const f32x4*)(txt + (int64_t)t * M * d + i);
+  __syncthreads();
+  for (int v = blockIdx.y * 4 + wave; v < NV; v += gridDim.y * 4) {
+    float nrm = 0.f;
+    for (int m = 0; m < M; ++m) nrm += tw[t * M + m] * vw[v * M + m];
+    if (nrm == 0.f) nrm = 1e-5f;  // model.py:816
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+      float acc = 0.f;
+      for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 x = *(const f32x4*)(ts + m * d + c), y = *(const f32x4*)(vid + ((int64_t)v * M + m) * d + c);
+        acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      }
+      const float dm = wave_sum(acc);
+      s += tw[t * M + m] * vw[v * M + m] / nrm * dm;
+      if (lane == 0) dots[((int64_t)t * NV + v) * M + m] = dm;
+    }
+    if (lane == 0) sims[(int64_t)t * NV + v] = s;
+  }
+}
+
+// side 0: block per text row t -> dtxt[t], dtw[t];  side 1: block per video v -> dvid[v], dvw[v].
+__global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
+                                                       const float* __restrict__ tw, const float* __restrict__ vw,
+                                                       const float* __restrict__ dots, const float* __restrict__ dsims,
+                                                       int NT, int NV, int M, int d, int side, float* __restrict__ dx,
+                                                       float* __restrict__ dwt) {
+  __shared__ __attribute__((aligned(16))) float racc[4][1024];
+  __shared__ float rw[4];
+  const int self = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NO = side == 0 ? NV : NT;  // the other side's count
+  const float* other = side == 0 ? vid : txt;
+  const float* wother = side == 0 ? vw : tw;
+  for (int m = 0; m < M; ++m) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dws = 0.f;
+    for (int o = wave; o < NO; o += 4) {
+      const int t = side == 0 ? self : o, v = side == 0 ? o : self;
+      const float g = dsims[(int64_t)t * NV + v];
+      const float* dm = dots + ((int64_t)t * NV + v) * M;
+      float nrm = 0.f, gw = 0.f;
+      for (int j = 0; j < M; ++j) nrm += tw[t * M + j] * vw[v * M + j];
+      const bool zero = nrm == 0.f;
+      if (zero) nrm = 1e-5f;
+      for (int j = 0; j < M; ++j) gw += g * dm[j] * tw[t * M + j] * vw[v * M + j] / nrm;  // sum_j dw_j w_j
+      const float w = tw[t * M + m] * vw[v * M + m] / nrm;
+      // d sims / d a_m = (dots_m - sum_j w_j dots_j) / nrm   (no normaliser gradient in the 1e-5 branch)
+      const float da = zero ? g * dm[m] / nrm : (g * dm[m] - gw) / nrm;
+      dws += da * wother[o * M + m];
+      const float coef = g * w;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < d) acc[c] += *(const f32x4*)(other + ((int64_t)o * M + m) * d + col) * coef;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < d) *(f32x4*)(&racc[wave][col]) = acc[c];
+    }
+    if (lane == 0) rw[wave] = dws;
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256)
+      dx[((int64_t)self * M + m) * d + i] = racc[0][i] + racc[1][i] + racc[2][i] + racc[3][i];
+    if (threadIdx.x == 0) dwt[self * M + m] = rw[0] + rw[1] + rw[2] + rw[3];
+    __syncthreads();
+  }
+}
+
+// ---- losses ------------------------------------------------------------------------------------------
+// Block k handles diagonal index k: row k (first hinge direction) and column k (second direction).
+// partial[k] = sum_{c!=k} relu(m - s_kk + s_kc) + sum_{r!=k} relu(m - s_kk + s_rk)   (fix_norm: off-diagonal only)
+// G[r][c] = d loss / d s_rc  (already divided by the normaliser).
+__global__ __launch_bounds__(256) void maxmargin_kernel(const float* __restrict__ s, int n, float margin, int fix_norm,
+                                                        float* __restrict__ partial, float* __restrict__ G) {
+  __shared__ float redf[4];
+  __shared__ int redi[4];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float skk = s[(int64_t)k * n + k];
+  const float norm = fix_norm ? 2.0f * n * (n - 1) : 2.0f * n * n;
+  float acc = 0.f;
+  int cnt = 0;  // active hinges that pull s_kk down
+  for (int c = threadIdx.x; c < n; c += 256) {
+    const bool diag = c == k;
+    if (diag && fix_norm) continue;
+    const float h1 = margin - skk + s[(int64_t)k * n + c];                       // row k, column c
+    const float h2 = margin - skk + s[(int64_t)c * n + k];                       // row c, column k
+    const float h2g = margin - s[(int64_t)c * n + c] + s[(int64_t)k * n + c];    // second hinge of element (k, c)
+    acc += fmaxf(h1, 0.f) + fmaxf(h2, 0.f);
+    cnt += (h1 > 0.f) + (h2 > 0.f);
+    if (!diag) G[(int64_t)k * n + c] = ((h1 > 0.f ? 1.f : 0.f) + (h2g > 0.f ? 1.f : 0.f)) / norm;
+  }
+  acc = wave_sum(acc);
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) { redf[wave] = acc; redi[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[k] = (redf[0] + redf[1] + redf[2] + redf[3]) / norm;
+    const int total = redi[0] + redi[1] + redi[2] + redi[3];
+    // diagonal: with fix_norm the (k,k) terms are excluded; without it they contribute relu(margin) with zero
+    // gradient (s_kk cancels), but still count in `total` twice -> remove them.
+    const int self_terms = fix_norm ? 0 : (margin > 0.f ? 2 : 0);
+    G[(int64_t)k * n + k] = -(float)(total - self_terms) / norm;
+  }
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+// InfoNCE: loss = CE(rows) + CE(cols), mean over n.  Block k: logsumexp of row k and of column k.
+// G = (softmax_row + softmax_col - 2 I) / n is produced by a second pass once both lse vectors exist.
+__global__ __launch_bounds__(256) void infonce_lse_kernel(const float* __restrict__ s, int n, float* __restrict__ lse_row,
+                                                          float* __restrict__ lse_col, float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mr = -INFINITY, mc = -INFINITY;
+  for (int c = threadIdx.x; c < n; c += 256) { mr = fmaxf(mr, s[(int64_t)k * n + c]); mc = fmaxf(mc, s[(int64_t)c * n + k]); }
+  mr = wave_max(mr); mc = wave_max(mc);
+  if (lane == 0) { red[0][wave] = mr; red[1][wave] = mc; }
+  __syncthreads();
+  mr = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  mc = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  __syncthreads();
+  float sr = 0.f, sc = 0.f;
+  for (int c = threadIdx.x; c < n; c += 256) { sr += expf(s[(int64_t)k * n + c] - mr); sc += expf(s[(int64_t)c * n + k] - mc); }
+  sr = wave_sum(sr); sc = wave_sum(sc);
+  if (lane == 0) { red[0][wave] = sr; red[1][wave] = sc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float lr = mr + logf(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    const float lc = mc + logf(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    lse_row[k] = lr; lse_col[k] = lc;
+    partial[k] = (lr + lc - 2.0f * s[(int64_t)k * n + k]) / n;
+  }
+}
+__global__ void infonce_grad_kernel(const float* __restrict__ s, int n, const float* __restrict__ lse_row,
+                                    const float* __restrict__ lse_col, float* __restrict__ G) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * n) return;
+  const int r = (int)(i / n), c = (int)(i % n);
+  G[i] = (expf(s[i] - lse_row[r]) + expf(s[i] - lse_col[c]) - (r == c ? 2.f : 0.f)) / n;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int mmt_readout_fwd(const float* last_hidden, const int32_t* agg_row, int BM, int d, float* vid_embds,
+                               float* inv_norm, void* stream) {
+  if (!last_hidden || !agg_row || !vid_embds || !inv_norm || BM <= 0 || d % 4) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(readout_fwd_kernel, dim3((BM + 3) / 4), dim3(256), 0, (hipStream_t)stream, last_hidden, agg_row,
+                     BM, d, vid_embds, inv_norm);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_readout_bwd(const float* vid_embds, const float* inv_norm, const float* dvid_embds,
+                               const int32_t* agg_row, int BM, int d, float* dlast_hidden, void* stream) {
+  if (!vid_embds || !inv_norm || !dvid_embds || !agg_row || !dlast_hidden || BM <= 0 || d % 4) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(readout_bwd_kernel, dim3((BM + 3) / 4), dim3(256), 0, (hipStream_t)stream, vid_embds, inv_norm,
+                     dvid_embds, agg_row, BM, d, dlast_hidden);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_sims_fwd(const float* txt, const float* vid, const float* tw, const float* vw, int NT, int NV, int M,
+                            int d, float* sims, float* dots, void* stream) {
+  if (!txt || !vid || !tw || !vw || !sims || !dots || NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024)
+    return MMT_ERR_ARG;
+  const size_t lds = (size_t)M * d * sizeof(float);
+  if (lds > 64 * 1024) return MMT_ERR_ARG;
+  int gy = (NV + 3) / 4;
+  if (gy > 16) gy = 16;
+  hipLaunchKernelGGL(sims_fwd_kernel, dim3(NT, gy), dim3(256), lds, (hipStream_t)stream, txt, vid, tw, vw, NT, NV, M, d,
+                     sims, dots);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, const float* dots,
+                            const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
+                            float* dvw, void* stream) {
+  if (!txt || !vid || !tw || !vw || !dots || !dsims || !dtxt || !dvid || !dtw || !dvw) return MMT_ERR_ARG;
+  if (NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
+                     NV, M, d, 0, dtxt, dtw);
+  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NV), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
+                     NV, M, d, 1, dvid, dvw);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_maxmargin(const float* sims, int n, float margin, int fix_norm, float* partial, float* loss,
+                             float* grad, void* stream) {
+  if (!sims || !partial || !loss || !grad || n <= 1) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(maxmargin_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, sims, n, margin, fix_norm, partial,
+                     grad);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, loss);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_infonce(const float* sims, int n, float* scratch, float* loss, float* grad, void* stream) {
+  if (!sims || !scratch || !loss || !grad || n <= 0) return MMT_ERR_ARG;  // scratch: 3n floats
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, sims, n, scratch, scratch + n,
+                     scratch + 2 * n);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch + 2 * n, n, loss);
+  const int64_t nn = (int64_t)n * n;
+  hipLaunchKernelGGL(infonce_grad_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sims, n,
+                     scratch, scratch + n, grad);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,461 @@
+"""Drop-in for the reference's `model/model.py` (CENet + sharded_cross_view_inner_product) on MI355X.
+
+`CENet(**arch_args, expert_dims=..., tokenizer=...)` keeps the reference constructor
+(model/model.py:48-73), `forward(token_ids, features, features_t, features_ind, features_avgpool,
+features_maxpool, query_masks, out, device, debug)` (model/model.py:312-322), the returned dicts
+(model/model.py:633-661) and every parameter name, so `train.py` / `trainer/trainer.py` drive it
+unchanged and released checkpoints load.
+
+What runs where:
+  * video side -- ReduceDim per expert, token assembly, video BERT, expert read-out + L2 norm
+    (model/model.py:426-437, 485-587, 621-625): libmmt_hip.so, forward and backward;
+  * similarity (model/model.py:789-837) and the losses: libmmt_hip.so;
+  * text tower (HF BertModel, third party) and the small text heads (GatedEmbeddingUnit, MoE weights,
+    model/model.py:229-283, 683-750): stock PyTorch-ROCm ops on the GPU (SURVEY.md section 8f.2 = next row).
+Only the configuration every published config uses is implemented natively (vid_cont='bert',
+vid_inp='both', out_tok='mxp', pos_enc='tint'|'none', vid_wgh='none', keep_missing_modalities=True);
+anything else raises NotImplementedError instead of silently taking a slow path.
+"""
+import collections
+import ctypes
+import re
+import types
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib, ops
+from ._lib import MmtExpertIO, check
+from .bert import BertModel, EngineBatch
+from .flat import FlatParams
+
+
+def _round_up(x, m):
+  return (x + m - 1) // m * m
+
+
+class ReduceDim(nn.Module):
+  """model/model.py:717-726 (parameter container; also usable as a plain torch module for text)."""
+
+  def __init__(self, input_dimension, output_dimension):
+    super().__init__()
+    self.fc = nn.Linear(input_dimension, output_dimension)
+
+  def forward(self, x):
+    return F.normalize(self.fc(x), dim=-1)
+
+
+class ContextGating(nn.Module):
+  """model/model.py:736-750."""
+
+  def __init__(self, dimension, add_batch_norm=True):
+    super().__init__()
+    self.fc = nn.Linear(dimension, dimension)
+    self.add_batch_norm = add_batch_norm
+    self.batch_norm = nn.BatchNorm1d(dimension)
+
+  def forward(self, x):
+    x1 = self.fc(x)
+    if self.add_batch_norm:
+      x1 = self.batch_norm(x1)
+    return F.glu(torch.cat((x, x1), 1), 1)
+
+
+class GatedEmbeddingUnit(nn.Module):
+  """model/model.py:683-702."""
+
+  def __init__(self, input_dimension, output_dimension, use_bn, normalize):
+    super().__init__()
+    self.fc = nn.Linear(input_dimension, output_dimension)
+    self.cg = ContextGating(output_dimension, add_batch_norm=use_bn)
+    self.normalize = normalize
+
+  def forward(self, x):
+    x = self.cg(self.fc(x))
+    if self.normalize:
+      x = F.normalize(x, dim=-1)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# native autograd functions
+# ------------------------------------------------------------------------------------------------
+class _VideoTokensFn(torch.autograd.Function):
+  """features[row] = F.normalize(ReduceDim.fc(expert feature)) scattered into (packed) token rows."""
+
+  @staticmethod
+  def forward(ctx, net, plan, *params):
+    ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
+    return net._video_tokens_forward(plan)
+
+  @staticmethod
+  def backward(ctx, dfeat):
+    if ctx.plan.generation != ctx.generation:
+      raise RuntimeError('mmt_amd.CENet: video-token buffers were overwritten by a later forward')
+    return (None, None) + tuple(ctx.net._video_tokens_backward(ctx.plan, dfeat.contiguous()))
+
+
+class _ReadoutFn(torch.autograd.Function):
+  """vid_embds[b, m] = F.normalize(sequence_output[agg_row[b, m]])  (model.py:583-587, 621-625)."""
+
+  @staticmethod
+  def forward(ctx, last, agg_row, bm):
+    d = last.shape[1]
+    out = torch.empty(bm, d, device=last.device, dtype=torch.float32)
+    inv = torch.empty(bm, device=last.device, dtype=torch.float32)
+    check(_lib.lib().mmt_readout_fwd(ops._p(last), ops._p(agg_row), bm, d, ops._p(out), ops._p(inv), ops._stream()),
+          'mmt_readout_fwd')
+    ctx.save_for_backward(out, inv, agg_row)
+    ctx.shape = last.shape
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    out, inv, agg_row = ctx.saved_tensors
+    dlast = torch.zeros(ctx.shape, device=out.device, dtype=torch.float32)
+    check(_lib.lib().mmt_readout_bwd(ops._p(out), ops._p(inv), ops._p(dout.contiguous()), ops._p(agg_row),
+                                     out.shape[0], out.shape[1], ops._p(dlast), ops._stream()), 'mmt_readout_bwd')
+    return dlast, None, None
+
+
+class _SimsFn(torch.autograd.Function):
+  """sims[t, v] of model/model.py:789-837 for txt [NT,M,d], vid [NV,M,d], tw [NT,M], vw [NV,M]."""
+
+  @staticmethod
+  def forward(ctx, txt, vid, tw, vw):
+    nt, m, d = txt.shape
+    nv = vid.shape[0]
+    txt, vid, tw, vw = (x.detach().contiguous().float() for x in (txt, vid, tw, vw))
+    sims = torch.empty(nt, nv, device=txt.device, dtype=torch.float32)
+    dots = torch.empty(nt, nv, m, device=txt.device, dtype=torch.float32)
+    check(_lib.lib().mmt_sims_fwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), nt, nv, m, d, ops._p(sims),
+                                  ops._p(dots), ops._stream()), 'mmt_sims_fwd')
+    ctx.save_for_backward(txt, vid, tw, vw, dots)
+    return sims
+
+  @staticmethod
+  def backward(ctx, dsims):
+    txt, vid, tw, vw, dots = ctx.saved_tensors
+    nt, m, d = txt.shape
+    nv = vid.shape[0]
+    dtxt, dvid, dtw, dvw = (torch.empty_like(x) for x in (txt, vid, tw, vw))
+    check(_lib.lib().mmt_sims_bwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), ops._p(dots),
+                                  ops._p(dsims.contiguous().float()), nt, nv, m, d, ops._p(dtxt), ops._p(dvid),
+                                  ops._p(dtw), ops._p(dvw), ops._stream()), 'mmt_sims_bwd')
+    return dtxt, dvid, dtw, dvw
+
+
+def cross_view_similarity(vid_embds, text_embds, vid_weights, text_weights, merge='avg'):
+  """Tensor form of sharded_cross_view_inner_product: vid (B,M,d), text (B,M,C,d), vw (B,M), tw (B,C,M)."""
+  b, m, d = vid_embds.shape
+  c = text_embds.shape[2]
+  dev = vid_embds.device
+  on_cpu = not vid_embds.is_cuda
+  if on_cpu:  # eval path of the trainer hands CPU tensors (trainer.py:368,396): round-trip through the GPU
+    if not torch.cuda.is_available():
+      raise RuntimeError('mmt_amd similarity needs a GPU (no CPU fallback)')
+    vid_embds, text_embds, vid_weights, text_weights = (x.cuda() for x in (vid_embds, text_embds, vid_weights,
+                                                                           text_weights))
+  txt = text_embds.permute(0, 2, 1, 3).reshape(b * c, m, d)  # row = b*C + cap (model.py:805,822)
+  sims = _SimsFn.apply(txt, vid_embds, text_weights.reshape(b * c, m), vid_weights.reshape(b, m))
+  if c > 1:
+    if merge == 'avg':
+      sims = sims.view(b, c, b).mean(1)
+    elif merge != 'indep':
+      raise ValueError('unrecognised merge mode: {}'.format(merge))
+  return sims.to(dev) if on_cpu else sims
+
+
+def sharded_cross_view_inner_product(vid_embds, text_embds, vid_weights, text_weights, subspaces,
+                                     merge_caption_similiarities='avg'):
+  """model/model.py:789-837, same signature (dicts keyed by modality)."""
+  vid = torch.stack([vid_embds[mod] for mod in subspaces], 1)
+  b = vid.shape[0]
+  txt = torch.stack([text_embds[mod].reshape(b, -1, vid.shape[-1]) for mod in subspaces], 1)  # (B,M,C,d)
+  c = txt.shape[2]
+  return cross_view_similarity(vid, txt, vid_weights.reshape(b, -1), text_weights.reshape(b, c, -1),
+                               merge_caption_similiarities)
+
+
+class _VideoPlan:
+  """Per-(B,T) device buffers of the token pipeline."""
+
+  def __init__(self, net, bsz, t, device):
+    mods, dims = net.modalities, net.expert_dims
+    m = len(mods)
+    self.batch, self.tokens, self.seq = bsz, t, 1 + m * (t + 1)
+    self.rows = bsz * self.seq
+    self.rows_alloc = ops.pad_rows(self.rows)
+    self.generation = 0
+    i32 = dict(device=device, dtype=torch.int32)
+    self.counts = torch.zeros(bsz, **i32)
+    self.cu = torch.zeros(bsz + 1, **i32)
+    self.n_rows = torch.zeros(1, **i32)
+    self.slot = torch.zeros(self.rows, **i32)
+    self.row_index = torch.zeros(self.rows_alloc, **i32)
+    self.type_ids = torch.zeros(self.rows_alloc, **i32)
+    self.pos_ids = torch.zeros(self.rows_alloc, **i32)
+    self.mask_bias = torch.zeros(self.rows_alloc, device=device, dtype=torch.float32)
+    self.agg_row = torch.zeros(bsz * m, **i32)
+    self.features = None
+    self.src_rows = bsz * (t + 1)
+    self.src_rows_pad = _round_up(self.src_rows, 128)
+    d = net.same_dim
+    self.x, self.y, self.dy = {}, {}, {}
+    for mod in mods:
+      dpad = _round_up(dims[mod]['dim'], 128)
+      self.x[mod] = torch.zeros(self.src_rows_pad, dpad, device=device, dtype=torch.bfloat16)
+      self.y[mod] = torch.zeros(self.src_rows_pad, d, device=device, dtype=torch.float32)
+      self.dy[mod] = torch.zeros(self.src_rows_pad, d, device=device, dtype=torch.bfloat16)
+    self.io = (MmtExpertIO * m)()
+    self.inputs = None  # keeps the input tensors of the current batch alive
+
+
+class CENet(nn.Module):
+  """Whole cross-modal architecture (reference: model/model.py:45-661)."""
+
+  def __init__(self, l2renorm, expert_dims, tokenizer, keep_missing_modalities, test_caption_mode,
+               freeze_weights=False, mimic_ce_dims=False, concat_experts=False, concat_mix_experts=False,
+               use_experts='origfeat', txt_inp=None, txt_agg=None, txt_pro=None, txt_wgh=None, vid_inp=None,
+               vid_cont=None, vid_wgh=None, pos_enc=None, out_tok=None, use_mask='nomask', same_dim=512,
+               vid_bert_params=None, txt_bert_params=None, agg_dims=None, normalize_experts=True,
+               txt_bert=None, pack_tokens=True):
+    super().__init__()
+    self.expert_dims = expert_dims
+    self.modalities = list(expert_dims.keys())
+    self.test_caption_mode = test_caption_mode
+    self.keep_missing_modalities = keep_missing_modalities
+    self.l2renorm, self.same_dim = l2renorm, same_dim
+    self.txt_inp, self.txt_agg, self.txt_pro, self.txt_wgh = txt_inp, txt_agg, txt_pro, txt_wgh
+    self.vid_inp, self.vid_cont, self.vid_wgh = vid_inp, vid_cont, vid_wgh
+    self.pos_enc, self.out_tok = pos_enc, out_tok
+    self.vid_bert_params = vid_bert_params
+    self.normalize_experts = normalize_experts
+    self.pack_tokens = pack_tokens
+    unsupported = []
+    if vid_cont != 'bert': unsupported.append('vid_cont=%r' % vid_cont)
+    if vid_inp != 'both': unsupported.append('vid_inp=%r' % vid_inp)
+    if out_tok != 'mxp': unsupported.append('out_tok=%r' % out_tok)
+    if pos_enc not in ('tint', 'none'): unsupported.append('pos_enc=%r' % pos_enc)
+    if vid_wgh != 'none': unsupported.append('vid_wgh=%r' % vid_wgh)
+    if not keep_missing_modalities: unsupported.append('keep_missing_modalities=False')
+    if not normalize_experts: unsupported.append('normalize_experts=False')
+    if txt_pro not in ('gbn', 'gem', 'lin'): unsupported.append('txt_pro=%r' % txt_pro)
+    if txt_wgh not in ('emb', 'none'): unsupported.append('txt_wgh=%r' % txt_wgh)
+    if unsupported:
+      raise NotImplementedError('mmt_amd.CENet implements the published MMT configuration natively; '
+                                'unsupported: ' + ', '.join(unsupported))
+    if len(self.modalities) > 16:
+      raise NotImplementedError('at most 16 experts')
+
+    self.video_dim_reduce = nn.ModuleDict(
+        {mod: ReduceDim(expert_dims[mod]['dim'], same_dim) for mod in self.modalities})
+    self.vid_bert = BertModel(types.SimpleNamespace(**vid_bert_params))
+    self.vid_bert.compute_pooler = False
+    if self.vid_bert.config.hidden_size != same_dim:
+      raise ValueError('vid_bert hidden_size must equal same_dim')
+
+    # --- text tower (third party; model/model.py:136-190) ---
+    if not (txt_agg or '').startswith('bert'):
+      raise NotImplementedError('txt_agg=%r: only the BERT text tower of the published configs' % txt_agg)
+    z = re.match(r'bert([a-z]{3})(\d*)(\D*)', txt_agg)
+    assert z
+    state, freeze_until = z.groups()[0], z.groups()[1]
+    self.post_agg = z.groups()[2] if z.groups()[2] and z.groups()[2] != 'cls' else 'cls'
+    if txt_bert_params is None:
+      dout = vid_bert_params['hidden_dropout_prob']
+      txt_bert_params = {'hidden_dropout_prob': dout, 'attention_probs_dropout_prob': dout}
+    if txt_bert is None:
+      from transformers import BertModel as TxtBertModel  # model/model.py:39,161
+      txt_bert = TxtBertModel.from_pretrained('bert-base-cased', **txt_bert_params)
+    self.txt_bert = txt_bert
+    if state == 'frz':
+      for name, param in self.txt_bert.named_parameters():
+        parts = name.split('.')
+        if parts[0] != 'encoder':
+          continue
+        if freeze_until:
+          if len(parts) > 2 and parts[2].isdigit() and int(parts[2]) < int(freeze_until):
+            param.requires_grad = False
+        else:
+          param.requires_grad = False
+    if txt_inp == 'bertfrz':
+      for param in self.txt_bert.embeddings.parameters():
+        param.requires_grad = False
+    text_dim = self.txt_bert.config.hidden_size
+
+    self.text_GU = nn.ModuleDict()
+    for mod in self.modalities:
+      if txt_pro == 'gbn':
+        self.text_GU[mod] = GatedEmbeddingUnit(text_dim, same_dim, use_bn=True, normalize=normalize_experts)
+      elif txt_pro == 'gem':
+        self.text_GU[mod] = GatedEmbeddingUnit(text_dim, same_dim, use_bn=False, normalize=normalize_experts)
+      else:
+        self.text_GU[mod] = ReduceDim(text_dim, same_dim)
+    if txt_wgh == 'emb':
+      self.moe_fc_txt = nn.ModuleDict({mod: nn.Linear(text_dim, 1) for mod in self.modalities})
+      self.moe_txt_dropout = nn.Dropout(txt_bert_params['hidden_dropout_prob'])
+
+    # --- flat storage of everything the engine touches ---
+    named = self.vid_bert.engine_named_params('vid_bert.')
+    for mod in self.modalities:
+      named += [('video_dim_reduce.%s.fc.weight' % mod, self.video_dim_reduce[mod].fc.weight),
+                ('video_dim_reduce.%s.fc.bias' % mod, self.video_dim_reduce[mod].fc.bias)]
+    self._flat = FlatParams(named)
+    self.vid_bert.register_shadows(self._flat)
+    for mod in self.modalities:
+      dim = expert_dims[mod]['dim']
+      self._flat.add_shadow(('reduce', mod), [self.video_dim_reduce[mod].fc.weight], same_dim, dim,
+                            k_pad=_round_up(dim, 128))
+    self.vid_bert.attach_flat(self._flat)
+    self._plans = {}
+
+  def __str__(self):
+    n = sum(p.numel() for p in self.parameters() if p.requires_grad)
+    return super().__str__() + '\nTrainable parameters: {}'.format(n)
+
+  def engine_params(self):
+    """Parameters living in the flat buffer (video side), in layout order."""
+    return self._flat.params
+
+  # ---- video side --------------------------------------------------------------------------------
+  def _reduce_params(self):
+    out = []
+    for mod in self.modalities:
+      out += [self.video_dim_reduce[mod].fc.weight, self.video_dim_reduce[mod].fc.bias]
+    return out
+
+  def _prepare(self, device):
+    if self._flat.ensure(device):
+      self.vid_bert._structs = {}
+    self._flat.pack(force=self.training and torch.is_grad_enabled())
+    self.vid_bert._ensure_ready(device)
+
+  def _video_tokens_forward(self, plan):
+    L, m, d = _lib.lib(), len(self.modalities), self.same_dim
+    io, stream = plan.io, ops._stream()
+    max_pos = self.vid_bert_params['max_position_embeddings'] - 1
+    check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
+                           ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
+                           ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
+                           stream), 'mmt_video_plan')
+    check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, stream), 'mmt_video_cast')
+    for mod in self.modalities:
+      w, _ = self._flat.shadow(('reduce', mod))
+      ops.gemm_nt(plan.x[mod], w, plan.y[mod], 'BIAS_F32', m=plan.src_rows, bias=self.video_dim_reduce[mod].fc.bias)
+    feats = torch.empty(plan.rows_alloc, d, device=plan.slot.device, dtype=torch.float32)
+    check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(feats), stream),
+          'mmt_video_scatter')
+    return feats
+
+  def _video_tokens_backward(self, plan, dfeat):
+    L, m, d = _lib.lib(), len(self.modalities), self.same_dim
+    stream = ops._stream()
+    check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(dfeat), stream),
+          'mmt_video_scatter_bwd')
+    grad_buf = self._flat.grads[self._flat._which]  # the BERT backward (run just before) already picked it
+    grads = []
+    nblk = (plan.src_rows + 31) // 32
+    partials = torch.empty(nblk, d, device=dfeat.device, dtype=torch.float32)
+    for mod in self.modalities:
+      fc = self.video_dim_reduce[mod].fc
+      dim, dpad = self.expert_dims[mod]['dim'], plan.x[mod].shape[1]
+      splits = max(1, min(8, plan.src_rows // 64))
+      slabs = torch.empty(splits, d, dpad, device=dfeat.device, dtype=torch.float32)
+      check(L.mmt_gemm_tn_bf16(ops._p(plan.dy[mod]), d, ops._p(plan.x[mod]), dpad, ops._p(slabs), plan.src_rows, d,
+                               dpad, splits, None, stream), 'mmt_gemm_tn_bf16')
+      gw = self._flat.view(fc.weight, grad_buf)
+      check(L.mmt_reduce_slabs_2d(ops._p(slabs), splits, d, dpad, dim, ops._p(gw), 0, stream), 'mmt_reduce_slabs_2d')
+      check(L.mmt_colsum_bf16(ops._p(plan.dy[mod]), d, plan.src_rows, d, None, ops._p(partials), stream),
+            'mmt_colsum_bf16')
+      gb = self._flat.view(fc.bias, grad_buf)
+      check(L.mmt_col_reduce(ops._p(partials), nblk, 1, d, ops._p(gb), None, None, None, 0, stream), 'mmt_col_reduce')
+      grads += [gw if fc.weight.requires_grad else None, gb if fc.bias.requires_grad else None]
+    return grads
+
+  def video_embeddings(self, features, features_t, features_ind, features_maxpool):
+    """(B, M, d) L2-normalised expert embeddings of the video side (model.py:426-437, 485-587, 621-625)."""
+    mods = self.modalities
+    f0 = features[mods[0]]
+    if not f0.is_cuda:
+      raise RuntimeError('mmt_amd.CENet runs on the GPU only (no CPU fallback)')
+    dev = f0.device
+    bsz, t = f0.shape[0], f0.shape[1]
+    for mod in mods:
+      if features[mod].shape[1] != t:
+        raise NotImplementedError('all experts must share max_expert_tokens (as in every published config)')
+    self._prepare(dev)
+    key = (bsz, t, dev)
+    plan = self._plans.get(key)
+    if plan is None:
+      plan = self._plans[key] = _VideoPlan(self, bsz, t, dev)
+    plan.generation += 1
+    keep = []
+    for i, mod in enumerate(mods):
+      tensors = [features[mod], features_maxpool[mod], features_ind[mod], features_t[mod]]
+      tensors = [x.detach().to(device=dev, dtype=torch.float32).contiguous() for x in tensors]
+      keep.append(tensors)
+      io = plan.io[i]
+      io.feat, io.maxpool, io.ind, io.t = (x.data_ptr() for x in tensors)
+      io.x, io.y, io.dy = plan.x[mod].data_ptr(), plan.y[mod].data_ptr(), plan.dy[mod].data_ptr()
+      io.D, io.Dpad = self.expert_dims[mod]['dim'], plan.x[mod].shape[1]
+      io.type_idx, io.rows_pad = self.expert_dims[mod]['idx'], plan.src_rows_pad
+    plan.inputs = keep
+    feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
+    batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
+                        plan.rows, bsz, plan.seq, cu_seqlens=plan.cu, row_index=plan.row_index,
+                        n_rows_dev=plan.n_rows if self.pack_tokens else None)
+    last = self.vid_bert.run_engine(batch, feats)
+    vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
+    return vid.view(bsz, len(mods), self.same_dim)
+
+  # ---- text side (stock PyTorch-ROCm) --------------------------------------------------------------
+  def text_features(self, token_ids, device):
+    """model/model.py:349-379: (B, C, W, 2) -> (B*C, text_dim) via the text tower's [CLS]."""
+    b, c, w, f = token_ids.size()
+    tok = token_ids.view(b * c, w, f).to(device)
+    input_ids = tok[:, :, 0].long()
+    attention_mask = tok[:, :, 1].long()
+    position_ids = torch.arange(w, device=device).unsqueeze(0).expand(b * c, w)
+    token_type_ids = torch.zeros_like(input_ids)
+    out = self.txt_bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                        position_ids=position_ids, head_mask=None)
+    last_layer = out[0]
+    if self.post_agg == 'cls':
+      return last_layer[:, 0]
+    if self.post_agg == 'mxp':
+      return torch.max(last_layer[:, 1:], 1)[0]
+    return torch.mean(last_layer[:, 1:], 1)
+
+  def compute_weights_from_emb(self, embd):
+    """model/model.py:262-283 (text branch)."""
+    embd = self.moe_txt_dropout(embd)
+    b, k, d = embd.size()
+    flat = embd.view(b * k, d)
+    w = torch.cat([self.moe_fc_txt[mod](flat) for mod in self.modalities], dim=-1)
+    return F.softmax(w, dim=1).view(b, k, len(self.modalities))
+
+  def forward(self, token_ids, features, features_t, features_ind, features_avgpool, features_maxpool,
+              query_masks, out='conf', device=None, debug=None):
+    dev = features[self.modalities[0]].device if device is None else torch.device(device)
+    b, c = token_ids.size(0), token_ids.size(1)
+    m = len(self.modalities)
+    text = self.text_features(token_ids, dev)                                   # (B*C, text_dim)
+    text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417
+    text = text.view(b, c, -1)
+    vid_embds = self.video_embeddings(features, features_t, features_ind, features_maxpool)
+    vid_weights = F.normalize(torch.ones(b, m, device=dev), p=1, dim=-1)        # model.py:594,607
+    if self.txt_wgh == 'emb':
+      text_weights = self.compute_weights_from_emb(text)
+    else:
+      text_weights = torch.ones(b, c, m, device=dev)
+    text_weights = F.normalize(text_weights, p=1, dim=-1)                       # model.py:618
+    text_embds = torch.stack([F.normalize(t, dim=-1) for t in text_embd], 1)    # (B,M,C,d) model.py:623
+    merge = 'avg' if self.training else self.test_caption_mode                  # model.py:627-631
+    self.merge_caption_similarities = merge
+    if out == 'conf':
+      return {'modalities': self.modalities,
+              'cross_view_conf_matrix': cross_view_similarity(vid_embds, text_embds, vid_weights, text_weights, merge)}
+    return {'vid_embds': vid_embds, 'text_embds': text_embds, 'vid_weights': vid_weights,
+            'text_weights': text_weights}

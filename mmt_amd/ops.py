@@ -41,7 +41,7 @@ def dropout_params(p):
 
 
 def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, aux=None, colsum=None,
-            row_index=None, drop_key=0, drop_p=0.0, n_rows_dev=None, tile=0):
+            row_index=None, drop_key=0, drop_p=0.0, n_rows_dev=None, tile=0, seed_dev=None):
   """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue.  a/b bf16 row-major, rows padded to 128."""
   _need_cuda(a, b, out)
   M = a.shape[0] if m is None else m
@@ -56,6 +56,7 @@ def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, 
   thr, scale = dropout_params(drop_p)
   e.drop_key, e.drop_thr16, e.drop_scale = drop_key, thr, scale
   e.reserved = tile
+  e.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None
   rc = _lib.lib().mmt_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
                                    EPI[epilogue], ctypes.byref(e), _p(n_rows_dev), _stream())
   check(rc, 'mmt_gemm_nt_bf16')
@@ -92,7 +93,7 @@ def ln_fwd(z, gamma, beta, eps, rows=None, n_rows_dev=None, want_h32=True):
 
 
 def embed_ln_fwd(features, type_ids, pos_ids, type_emb, pos_emb, gamma, beta, eps, rows=None, drop_key=0,
-                 drop_p=0.0, row_index=None, n_rows_dev=None):
+                 drop_p=0.0, row_index=None, n_rows_dev=None, seed_dev=None):
   _need_cuda(features)
   R, d = features.shape
   rows = R if rows is None else rows
@@ -104,13 +105,13 @@ def embed_ln_fwd(features, type_ids, pos_ids, type_emb, pos_emb, gamma, beta, ep
   thr, scale = dropout_params(drop_p)
   check(_lib.lib().mmt_embed_ln_fwd(_p(features), _p(type_ids), _p(pos_ids), _p(type_emb), _p(pos_emb), _p(z),
                                     _p(gamma), _p(beta), eps, _p(h32), _p(h16), _p(mean), _p(rstd), rows, d,
-                                    _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _stream()),
+                                    _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _p(seed_dev), _stream()),
         'mmt_embed_ln_fwd')
   return z, h32, h16, mean, rstd
 
 
 def ln_bwd(dout, z, mean, rstd, gamma, rows=None, drop_mode=0, drop_key=0, drop_p=0.0, want_dy=True,
-           row_index=None, n_rows_dev=None):
+           row_index=None, n_rows_dev=None, seed_dev=None):
   """Returns dz (fp32), dy (bf16 or None), dgamma, dbeta, dbias (fp32 [d])."""
   _need_cuda(dout)
   R, d = z.shape
@@ -123,7 +124,7 @@ def ln_bwd(dout, z, mean, rstd, gamma, rows=None, drop_mode=0, drop_key=0, drop_
   partials = torch.empty(nblk, 3, d, device=z.device, dtype=torch.float32)
   thr, scale = dropout_params(drop_p)
   check(L.mmt_ln_bwd(_p(dout), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dy), _p(partials), rows, d,
-                     drop_mode, _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _stream()), 'mmt_ln_bwd')
+                     drop_mode, _p(n_rows_dev), _p(row_index), drop_key, thr, scale, _p(seed_dev), _stream()), 'mmt_ln_bwd')
   outs = [torch.empty(d, device=z.device, dtype=torch.float32) for _ in range(3)]
   check(L.mmt_col_reduce(_p(partials), nblk, 3, d, _p(outs[0]), _p(outs[1]), _p(outs[2]), None, 0, _stream()),
         'mmt_col_reduce')
@@ -140,7 +141,7 @@ def table_grad(g, ids, vocab, rows=None, n_rows_dev=None):
   return out
 
 
-def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0):
+def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0, seed_dev=None):
   _need_cuda(qkv)
   R, d3 = qkv.shape
   d = d3 // 3
@@ -148,11 +149,12 @@ def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p
   lse = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
   thr, sc = dropout_params(drop_p)
   check(_lib.lib().mmt_attn_fwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), B, S, H, d, scale,
-                                drop_key, thr, sc, _stream()), 'mmt_attn_fwd')
+                                drop_key, thr, sc, _p(seed_dev), _stream()), 'mmt_attn_fwd')
   return ctx, lse
 
 
-def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0):
+def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0,
+             seed_dev=None):
   _need_cuda(qkv)
   R, d3 = qkv.shape
   d = d3 // 3
@@ -160,12 +162,12 @@ def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, dr
   delta = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
   thr, sc = dropout_params(drop_p)
   check(_lib.lib().mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
-                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _stream()), 'mmt_attn_bwd')
+                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _stream()), 'mmt_attn_bwd')
   return dqkv
 
 
-def attn_dropout_mask(B, H, S, drop_key, drop_p, device='cuda'):
+def attn_dropout_mask(B, H, S, drop_key, drop_p, device='cuda', seed_dev=None):
   out = torch.empty(B, H, S, S, device=device, dtype=torch.uint8)
   thr, _ = dropout_params(drop_p)
-  check(_lib.lib().mmt_attn_dropout_mask(_p(out), B, H, S, drop_key, thr, _stream()), 'mmt_attn_dropout_mask')
+  check(_lib.lib().mmt_attn_dropout_mask(_p(out), B, H, S, drop_key, thr, _p(seed_dev), _stream()), 'mmt_attn_dropout_mask')
   return out

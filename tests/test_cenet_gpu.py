@@ -1,0 +1,244 @@
+"""GPU parity: the native CENet / BertModel / similarity / losses against the REAL reference's outputs
+(tests/golden, generated on CPU by oracle/gen_golden.py) and against the oracle on fresh inputs.
+
+Tolerances (bf16 MFMA operands, fp32 accumulate/LN/softmax/residual):
+  similarity matrix  atol 2e-3 (|sims| <= 1, margin 0.05)      loss        rel 2e-2
+  expert embeddings  atol 5e-3                                  gradients   cosine >= 0.995, norm ratio within 3%
+"""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.fixtures import load_cenet_fixture, load_npz, subsample
+from tests.test_host_cpu import build_native_cenet
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _to_dev(mb):
+  out = {}
+  for k, v in mb.items():
+    out[k] = {kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)
+  return out
+
+
+def _run(model, mb, text, out='conf'):
+  model.txt_bert.text = text.view(-1, text.shape[-1])
+  return model(mb['token_ids'], mb['features'], mb['features_t'], mb['features_ind'], mb['features_avgpool'],
+               mb['features_maxpool'], mb['query_masks'], out=out, device=DEV)
+
+
+def _cos(a, b):
+  a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+  return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize('name', ['tiny', 'configA', 'configB'])
+@pytest.mark.parametrize('pack', [False, True])
+def test_cenet_matches_reference(name, pack):
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from oracle import mmt_oracle as O
+  fx = load_cenet_fixture(name)
+  g = fx.gold
+  model = build_native_cenet(fx.meta, pack_tokens=pack)
+  model.load_state_dict(fx.state_dict)
+  model.to(DEV)
+  mb = _to_dev(fx.batch)
+  text = fx.text.to(DEV)
+  # ---- eval mode ----
+  model.eval()
+  with torch.no_grad():
+    sims = _run(model, mb, text)['cross_view_conf_matrix'].cpu().numpy()
+    emb = _run(model, mb, text, out='embds')
+  assert np.abs(sims - g['eval_sims']).max() < 2e-3
+  assert np.abs(emb['vid_embds'].cpu().numpy() - g['eval_vid_embds']).max() < 5e-3
+  assert np.abs(emb['text_embds'].cpu().numpy() - g['eval_text_embds']).max() < 1e-4
+  assert np.abs(emb['text_weights'].cpu().numpy() - g['eval_text_weights']).max() < 1e-5
+  assert np.abs(emb['vid_weights'].cpu().numpy() - g['eval_vid_weights']).max() < 1e-6
+  # R@K from the native sims (reference's metric code restated in the oracle) vs the reference's R@K.
+  # One query changing rank bucket moves R@K by 100/n, so allow that much where sims gaps are below tol.
+  n = sims.shape[0]
+  for key, fn in (('eval_t2v', O.t2v_metrics), ('eval_v2t', O.v2t_metrics)):
+    want = json.loads(str(g[key]))
+    got = fn(sims)
+    for k in ('R1', 'R5', 'R10'):
+      assert abs(got[k] - want[k]) <= 100.0 / n + 1e-6, (key, k, got[k], want[k])
+  # ---- train mode (dropout p = 0 in the fixtures), loss + backward ----
+  model.train()
+  loss_fn = MaxMarginRankingLoss(margin=0.05, fix_norm=True)
+  t = text.clone().requires_grad_(True)
+  tr = _run(model, mb, t)['cross_view_conf_matrix']
+  loss = loss_fn(tr)
+  loss.backward()
+  assert np.abs(tr.detach().cpu().numpy() - g['train_sims']).max() < 2e-3
+  assert abs(loss.item() - float(g['train_loss'])) <= 2e-2 * abs(float(g['train_loss']))
+  params = dict(model.named_parameters())
+  assert params['vid_bert.pooler.dense.weight'].grad is None
+  for key in g.files:
+    if not key.startswith('grad/'):
+      continue
+    pname = key[5:]
+    want, got = g[key], subsample(params[pname].grad)
+    wn = float(g['gradnorm/' + pname])
+    if np.linalg.norm(want) < 1e-9:
+      continue
+    c = _cos(got, want)
+    ratio = float(params[pname].grad.double().norm().item()) / wn
+    assert c > 0.995 and 0.97 < ratio < 1.03, (pname, c, ratio)
+  c = _cos(subsample(t.grad), g['train_text_grad'])
+  assert c > 0.995, ('text grad', c)
+  bn = model.state_dict()['text_GU.%s.cg.batch_norm.running_mean' % fx.meta['modalities'][0]].cpu().numpy()
+  assert np.abs(bn - g['bn_running_mean_after']).max() < 1e-4
+
+
+def test_packed_equals_dense_in_train_mode_with_dropout():
+  """Dropping padded tokens changes no consumed value; dropout masks are keyed on original coordinates,
+  so dense and packed runs agree even with dropout on (attention-probability dropout excepted: it is
+  keyed on packed positions, so it is switched off here)."""
+  fx = load_cenet_fixture('configA')
+  outs = []
+  for pack in (False, True):
+    torch.manual_seed(3)
+    model = build_native_cenet(fx.meta, pack_tokens=pack, dropout=0.1)
+    model.vid_bert.config.attention_probs_dropout_prob = 0.0
+    model.load_state_dict(fx.state_dict)
+    model.to(DEV).train()
+    for mod in model.text_GU.values():
+      mod.eval()
+    model.moe_txt_dropout.eval()
+    t = fx.text.to(DEV).clone().requires_grad_(True)
+    sims = _run(model, _to_dev(fx.batch), t)['cross_view_conf_matrix']
+    sims.sum().backward()
+    outs.append((sims.detach().cpu(), model.vid_bert.encoder.layer[0].intermediate.dense.weight.grad.cpu().clone()))
+  assert (outs[0][0] - outs[1][0]).abs().max() < 2e-4
+  assert _cos(outs[0][1].numpy(), outs[1][1].numpy()) > 0.9999
+
+
+def test_bert_standalone_matches_reference():
+  import types
+  from mmt_amd import synthetic
+  from mmt_amd.bert import BertModel
+  from tests.test_oracle_golden import _bert_shapes
+  g = load_npz('bert_standalone')
+  meta = json.loads(str(g['meta']))
+  vb = meta['vb']
+  model = BertModel(types.SimpleNamespace(**vb))
+  sd = synthetic.make_state_dict(meta['seed'], {('vid_bert.' + k): v for k, v in _bert_shapes(vb).items()})
+  model.load_state_dict({k[len('vid_bert.'):]: v for k, v in sd.items()})
+  model.to(DEV).eval()
+  b, s, d = meta['shape']
+  rs = np.random.RandomState(meta['seed'])
+  feats = torch.from_numpy(rs.randn(b, s, d).astype(np.float32)).to(DEV)
+  mask = torch.from_numpy((rs.rand(b, s) > 0.3).astype(np.int64))
+  mask[:, 0] = 1
+  types_ = torch.from_numpy(rs.randint(0, 19, size=(b, s)).astype(np.int64)).to(DEV)
+  pos = torch.from_numpy(rs.randint(0, 32, size=(b, s)).astype(np.int64)).to(DEV)
+  with torch.no_grad():
+    seq, pooled = model(types_, attention_mask=mask.to(DEV), token_type_ids=types_, position_ids=pos, features=feats)
+    seq_nopos = model(types_, attention_mask=mask.to(DEV), token_type_ids=types_, position_ids=None, features=feats)[0]
+  assert np.abs(seq.cpu().numpy() - g['sequence_output']).max() < 0.03   # hidden states, SURVEY 8c
+  assert np.abs(pooled.cpu().numpy() - g['pooled_output']).max() < 0.02
+  assert np.abs(seq_nopos.cpu().numpy() - g['sequence_output_nopos']).max() < 0.03
+  with pytest.raises(RuntimeError):
+    model(types_.cpu(), features=feats.cpu())
+
+
+def test_similarity_losses_match_reference():
+  from mmt_amd.loss import InfoNceLoss, MaxMarginRankingLoss
+  from mmt_amd.model import cross_view_similarity, sharded_cross_view_inner_product
+  import collections
+  g = load_npz('sim_loss_metric')
+  vid, txt = torch.from_numpy(g['sim_in_vid']), torch.from_numpy(g['sim_in_txt'])
+  vw, tw = torch.from_numpy(g['sim_in_vw']), torch.from_numpy(g['sim_in_tw'])
+  for mode in ('avg', 'indep'):
+    got = cross_view_similarity(vid.to(DEV), txt.to(DEV), vw.to(DEV), tw.to(DEV), mode)
+    assert np.abs(got.cpu().numpy() - g['sims_' + mode]).max() < 1e-5
+    # dict API on CPU tensors, as the trainer's eval path calls it (trainer.py:396)
+    mods = ['a', 'b', 'c']
+    got2 = sharded_cross_view_inner_product(
+        collections.OrderedDict((k, vid[:, i]) for i, k in enumerate(mods)),
+        collections.OrderedDict((k, txt[:, i]) for i, k in enumerate(mods)), vw, tw, mods, mode)
+    assert not got2.is_cuda and np.abs(got2.numpy() - g['sims_' + mode]).max() < 1e-5
+  with pytest.raises(ValueError):
+    cross_view_similarity(vid.to(DEV), txt.to(DEV), vw.to(DEV), tw.to(DEV), 'bogus')
+  # gradients of the similarity vs autograd through the oracle formula
+  from oracle import mmt_oracle as O
+  leaves = [x.clone().requires_grad_(True) for x in (vid, txt, vw, tw)]
+  w = torch.from_numpy(np.random.RandomState(1).randn(*g['sims_indep'].shape).astype(np.float32))
+  (O.cross_view_inner_product(*leaves, 'indep') * w).sum().backward()
+  dl = [x.clone().to(DEV).requires_grad_(True) for x in (vid, txt, vw, tw)]
+  (cross_view_similarity(*dl, 'indep') * w.to(DEV)).sum().backward()
+  for a, b, nm in zip(leaves, dl, ('vid', 'txt', 'vw', 'tw')):
+    assert torch.allclose(a.grad, b.grad.cpu(), rtol=1e-4, atol=2e-5), nm  # zero-weight row: grads ~1e6
+  # losses: known answers + random matrices with gradients
+  kat = torch.from_numpy(g['kat_x']).to(DEV)
+  assert abs(MaxMarginRankingLoss(0.05, True)(kat).item() - 0.15) < 1e-6
+  assert abs(MaxMarginRankingLoss(0.05, False)(kat).item() - 0.10) < 1e-6
+  assert abs(InfoNceLoss()(kat).item() - 1.407412) < 1e-5
+  for n in (3, 17, 64):
+    for fix in (1, 0):
+      x = torch.from_numpy(g['loss_x_%d' % n]).to(DEV).requires_grad_(True)
+      l = MaxMarginRankingLoss(0.05, bool(fix))(x)
+      l.backward()
+      assert abs(l.item() - float(g['mm_%d_%d' % (n, fix)])) < 1e-6
+      assert np.abs(x.grad.cpu().numpy() - g['mm_grad_%d_%d' % (n, fix)]).max() < 1e-7
+    x = torch.from_numpy(g['loss_x_%d' % n]).to(DEV).requires_grad_(True)
+    l = InfoNceLoss()(x)
+    l.backward()
+    assert abs(l.item() - float(g['nce_%d' % n])) < 1e-5
+    xr = torch.from_numpy(g['loss_x_%d' % n]).requires_grad_(True)
+    O.info_nce_loss(xr).backward()
+    assert (x.grad.cpu() - xr.grad).abs().max() < 1e-6
+
+
+def test_train_mode_dropout_replay_through_oracle():
+  """Dropout ON: export the masks the kernels draw, replay them through the CPU oracle, compare."""
+  import types
+  from mmt_amd import ops, synthetic
+  from mmt_amd.bert import BertModel
+  from oracle import mmt_oracle as O
+  from tests.test_oracle_golden import _bert_shapes
+  vb = synthetic.vid_bert_params(hidden=256, layers=2, heads=2, inter=512, dropout=0.1)
+  model = BertModel(types.SimpleNamespace(**vb))
+  sd = synthetic.make_state_dict(41, {('vid_bert.' + k): v for k, v in _bert_shapes(vb).items()})
+  model.load_state_dict({k[len('vid_bert.'):]: v for k, v in sd.items()})
+  model.to(DEV).train()
+  model.compute_pooler = False
+  b, s, d = 3, 20, 256
+  rs = np.random.RandomState(41)
+  feats = torch.from_numpy(rs.randn(b, s, d).astype(np.float32))
+  mask = torch.ones(b, s, dtype=torch.int64)
+  mask[1, 15:] = 0
+  types_ = torch.from_numpy(rs.randint(0, 19, size=(b, s)).astype(np.int64))
+  pos = torch.from_numpy(rs.randint(0, 32, size=(b, s)).astype(np.int64))
+  seq = model(types_.to(DEV), attention_mask=mask.to(DEV), token_type_ids=types_.to(DEV), position_ids=pos.to(DEV),
+              features=feats.to(DEV))[0]
+  # regenerate every mask from the same (site key, device seed) the engine used
+  seed = model._seed_dev
+  rows, R = b * s, ops.pad_rows(b * s)
+  masks = {}
+
+  def hidden_mask(layer, site):
+    # a GEMM epilogue with zero inputs leaves dropout(bias=1)+0: kept elements are non-zero
+    a = torch.zeros(R, 64, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(d, 64, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(R, d, device=DEV)
+    ops.gemm_nt(a, w, out, 'BIAS_DROP_RES', bias=torch.ones(d, device=DEV), res=torch.zeros(R, d, device=DEV),
+                drop_key=0x5eed0000 + layer * 16 + site, drop_p=0.1, seed_dev=seed)
+    return (out[:rows] != 0).float().view(b, s, d).cpu()
+
+  masks['emb'] = hidden_mask(0, 0)
+  for l in range(2):
+    masks['l%d.attn_out' % l] = hidden_mask(l, 2)
+    masks['l%d.ffn_out' % l] = hidden_mask(l, 3)
+    masks['l%d.probs' % l] = ops.attn_dropout_mask(b, 2, s, 0x5eed0000 + l * 16 + 1, 0.1, seed_dev=seed).float().cpu()
+  thr, _ = ops.dropout_params(0.1)
+  vbq = dict(vb, hidden_dropout_prob=thr / 65536.0, attention_probs_dropout_prob=thr / 65536.0)
+  with torch.no_grad():
+    ref = O.bert_model(sd, 'vid_bert.', vbq, mask, types_, pos, feats, masks=masks)
+  assert 0.85 < masks['emb'].mean().item() < 0.95
+  assert (seq.detach().cpu() - ref).abs().max() < 0.05

@@ -1,0 +1,128 @@
+"""CPU tests of the host logic: ABI coverage, reference-compatible state dict, flat parameter storage."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from tests.fixtures import load_npz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+  src = open(os.path.join(ROOT, 'include', 'mmt_hip.h')).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  out = {}
+  for m in re.finditer(r'\b(?:int|int64_t|const char\*)\s+(mmt_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+    args = m.group(2).strip()
+    out[m.group(1)] = 0 if args == 'void' else len([a for a in args.split(',') if a.strip()])
+  return out
+
+
+def test_library_exports_every_declared_symbol_and_bindings_match():
+  from mmt_amd import _lib
+  decl = _header_functions()
+  assert len(decl) >= 30
+  handle = ctypes.CDLL(_lib.LIB_PATH)  # loading needs no GPU
+  for name, nargs in decl.items():
+    assert hasattr(handle, name), 'declared in mmt_hip.h but not exported: ' + name
+    assert name in _lib.SIGNATURES, 'no ctypes signature for ' + name
+    assert len(_lib.SIGNATURES[name][1]) == nargs, 'arity mismatch for ' + name
+  assert set(_lib.SIGNATURES) == set(decl)
+  assert _lib.lib().mmt_abi_version() == 1
+  # struct layouts agree with the C side (sizes are what the kernels are compiled against)
+  assert ctypes.sizeof(_lib.MmtEpilogue) == 96
+  assert ctypes.sizeof(_lib.MmtPackItem) == 48
+  assert ctypes.sizeof(_lib.MmtExpertIO) == 72
+  assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
+  assert ctypes.sizeof(_lib.MmtBertBatch) == 80
+
+
+def test_product_path_refuses_cpu_tensors():
+  from mmt_amd import ops
+  from mmt_amd.loss import MaxMarginRankingLoss
+  with pytest.raises(RuntimeError):
+    ops.gemm_nt(torch.zeros(128, 64), torch.zeros(64, 64), torch.zeros(128, 64))
+  with pytest.raises(RuntimeError):
+    MaxMarginRankingLoss(0.05)(torch.zeros(4, 4))
+
+
+def _fake_txt_bert():
+  class Fake(torch.nn.Module):
+    def __init__(self):
+      super().__init__()
+      self.config = type('C', (), {'hidden_size': 768})()
+      self.embeddings = torch.nn.Module()
+      self.text = None
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None):
+      return (self.text[:, None, :],)
+  return Fake()
+
+
+def build_native_cenet(meta, pack_tokens=True, dropout=0.0):
+  from mmt_amd import synthetic
+  from mmt_amd.model import CENet
+  fx = meta['fixture']
+  vb = synthetic.vid_bert_params(dropout=dropout, **fx['vb'])
+  return CENet(l2renorm=False, expert_dims=synthetic.compute_dims(fx['modalities']), tokenizer=None,
+               keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn',
+               txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp',
+               vid_bert_params=vb, txt_pro='gbn', same_dim=fx['vb']['hidden'],
+               txt_bert_params={'hidden_dropout_prob': dropout, 'attention_probs_dropout_prob': dropout},
+               txt_bert=_fake_txt_bert(), pack_tokens=pack_tokens)
+
+
+@pytest.mark.parametrize('name', ['tiny', 'configB'])
+def test_state_dict_is_reference_compatible(name):
+  """Parameter names and shapes equal the REAL reference CENet's (recorded by gen_golden.py)."""
+  meta = json.loads(str(load_npz('cenet_' + name)['meta']))
+  model = build_native_cenet(meta)
+  ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+  assert ours == meta['param_shapes']
+
+
+def test_unsupported_modes_fail_loudly():
+  meta = json.loads(str(load_npz('cenet_tiny')['meta']))
+  from mmt_amd import synthetic
+  from mmt_amd.model import CENet
+  fx = meta['fixture']
+  with pytest.raises(NotImplementedError):
+    CENet(l2renorm=False, expert_dims=synthetic.compute_dims(fx['modalities']), tokenizer=None,
+          keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn',
+          txt_wgh='emb', vid_wgh='none', vid_cont='coll', vid_inp='both', pos_enc='tint', out_tok='mxp',
+          vid_bert_params=synthetic.vid_bert_params(**fx['vb']), txt_pro='gbn', same_dim=256,
+          txt_bert=_fake_txt_bert())
+
+
+def test_flat_params_survive_load_and_move():
+  from mmt_amd import synthetic
+  meta = json.loads(str(load_npz('cenet_tiny')['meta']))
+  model = build_native_cenet(meta)
+  flat = model._flat
+  before = {k: v.clone() for k, v in model.state_dict().items()}
+  assert flat.ensure('cpu') is True and flat.is_flat()
+  for k, v in model.state_dict().items():
+    assert torch.equal(v, before[k]), k
+  # q, k, v weights of a layer are one contiguous [3d, d] block (fused QKV GEMM)
+  att = model.vid_bert.encoder.layer[0].attention.self
+  d = att.query.weight.shape[0]
+  o = flat.offset(att.query.weight)
+  assert flat.offset(att.key.weight) == o + d * d and flat.offset(att.value.weight) == o + 2 * d * d
+  fused = flat.master[o:o + 3 * d * d].view(3 * d, d)
+  assert torch.equal(fused[d:2 * d], att.key.weight.data)
+  # load_state_dict copies INTO the views: still flat, values updated
+  sd = synthetic.make_state_dict(5, {k: tuple(v.shape) for k, v in model.state_dict().items()})
+  model.load_state_dict(sd)
+  assert flat.is_flat() and flat.ensure('cpu') is False
+  assert torch.equal(fused[:d], sd['vid_bert.encoder.layer.0.attention.self.query.weight'])
+  # module-level moves re-allocate .data: detected and re-flattened with values preserved
+  model.double().float()
+  assert not flat.is_flat()
+  assert flat.ensure('cpu') is True and flat.is_flat()
+  assert torch.equal(att.key.weight.data, sd['vid_bert.encoder.layer.0.attention.self.key.weight'])
+  # the pooler is not an engine parameter (never receives gradients)
+  assert all(not n.startswith('vid_bert.pooler') for n in flat.names)
