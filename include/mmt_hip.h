@@ -237,6 +237,12 @@ int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, flo
 int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast, float* dfeatures,
                       int training, void* stream);
 
+/* Measurement hook (bench.py): arm n pairs of caller-created hipEvent_t; each mmt_bert_forward then
+ * records one pair around layer 0's FFN up-projection GEMM launch (the dominant kernel) on its stream.
+ * The arrays must stay alive until the events have been read.  Pass NULL/0 to disarm. */
+int mmt_probe_arm(void** start_events, void** stop_events, int n);
+int mmt_probe_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,8 @@ SIGNATURES = {
     'mmt_bert_forward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_int, c_vp]),
     'mmt_bert_backward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp, c_int,
                                   c_vp]),
+    'mmt_probe_arm': (c_int, [c_vp, c_vp, c_int]),
+    'mmt_probe_count': (c_int, []),
 }
 
 _lib = None
