@@ -111,9 +111,10 @@ int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float
 int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,
                    float* out2, float* out3, int accumulate, void* stream);
 /* dtable[v] (+)= sum of g[row] over rows with ids[row] == v: gradient of nn.Embedding (bert.py:78-81)
- * as a deterministic segmented sum (no atomics). */
+ * as a deterministic segmented sum (no atomics); scratch = mmt_table_grad_scratch_floats() floats. */
+int64_t mmt_table_grad_scratch_floats(int vocab, int d);
 int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int vocab,
-                   const int32_t* n_rows_dev, float* dtable, int accumulate, void* stream);
+                   const int32_t* n_rows_dev, float* scratch, float* dtable, int accumulate, void* stream);
 /* partials[blk][c] = column sums of a bf16 matrix over 32-row blocks (bias gradients). */
 int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t* n_rows_dev,
                     float* partials, void* stream);
@@ -193,6 +194,44 @@ int mmt_maxmargin(const float* sims, int n, float margin, int fix_norm, float* p
                   float* grad, void* stream);
 /* InfoNceLoss.forward (loss.py:68-81); scratch = 3n floats. */
 int mmt_infonce(const float* sims, int n, float* scratch, float* loss, float* grad, void* stream);
+
+/* ---- text heads (texthead.hip), fp32 ------------------------------------------------------------------
+ * GatedEmbeddingUnit per expert (model.py:683-702, 736-750) + text MoE weights (model.py:262-283,618),
+ * batched over the M experts. */
+typedef struct MmtSgemm {      /* C_b[i][j] = beta*C_b[i][j] + sum_k A_b[i*sai + k*sak] * B_b[j*sbj + k*sbk] + bias_b[j] */
+  const float* A[MMT_MAX_EXPERTS];
+  const float* B[MMT_MAX_EXPERTS];
+  float* C[MMT_MAX_EXPERTS];
+  const float* bias[MMT_MAX_EXPERTS];
+  int64_t sai, sak, sbj, sbk, ldc;
+  int32_t batch, M, N, K;
+  float beta;
+  int32_t reserved;
+} MmtSgemm;
+int mmt_sgemm_batched(const MmtSgemm* g, void* stream);
+
+typedef struct MmtTextHeads {
+  const float *w1[MMT_MAX_EXPERTS], *b1[MMT_MAX_EXPERTS];            /* text_GU.<mod>.fc      [d,K],[d]   */
+  const float *w2[MMT_MAX_EXPERTS], *b2[MMT_MAX_EXPERTS];            /* text_GU.<mod>.cg.fc   [d,d],[d]   */
+  const float *bn_gamma[MMT_MAX_EXPERTS], *bn_beta[MMT_MAX_EXPERTS]; /* cg.batch_norm weight/bias         */
+  float *running_mean[MMT_MAX_EXPERTS], *running_var[MMT_MAX_EXPERTS];
+  const float *moe_w[MMT_MAX_EXPERTS], *moe_b[MMT_MAX_EXPERTS];      /* moe_fc_txt.<mod>      [1,K],[1]   */
+  float *g_w1[MMT_MAX_EXPERTS], *g_b1[MMT_MAX_EXPERTS], *g_w2[MMT_MAX_EXPERTS], *g_b2[MMT_MAX_EXPERTS];
+  float *g_bn_gamma[MMT_MAX_EXPERTS], *g_bn_beta[MMT_MAX_EXPERTS], *g_moe_w[MMT_MAX_EXPERTS], *g_moe_b[MMT_MAX_EXPERTS];
+} MmtTextHeads;
+int64_t mmt_text_heads_workspace_floats(int N, int M, int d);
+/* text [N = B*C, K] -> text_embds (B, M, C, d) L2-normalised, text_weights (B, C, M) (NULL: txt_wgh='none').
+ * use_bn: txt_pro 'gbn' (1) / 'gem' (0).  training: batch statistics + running-stat update.
+ * text_moe (nullable): the copy of text the MoE branch reads (after moe_txt_dropout, model.py:274). */
+int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M, int d,
+                       int K, int use_bn, int training, float* ws, float* text_embds, float* text_weights,
+                       void* stream);
+/* gradients are WRITTEN through the g_* pointers; dtext [N, K] (nullable) receives the gradient for the text
+ * tower; w1_all = the M fc.weight matrices contiguous as [M*d, K]. */
+int mmt_text_heads_bwd(const MmtTextHeads* h, const float* text, const float* text_moe, const float* w1_all, int N,
+                       int C, int M, int d, int K, int use_bn, int training, float* ws, const float* dtext_embds,
+                       const float* text_weights, const float* dtext_weights, float* dtext, float* dtext_moe,
+                       void* stream);
 
 /* ---- whole-encoder engine (bert_engine.hip) --------------------------------------------------------
  * One call runs every kernel of model/bert.py BertModel.forward (bert.py:371-414, without the unused

@@ -54,6 +54,24 @@ class MmtBertBatch(ctypes.Structure):
               [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')])
 
 
+_PTR16 = c_vp * 16
+
+
+class MmtSgemm(ctypes.Structure):
+  _fields_ = [('A', _PTR16), ('B', _PTR16), ('C', _PTR16), ('bias', _PTR16),
+              ('sai', c_i64), ('sak', c_i64), ('sbj', c_i64), ('sbk', c_i64), ('ldc', c_i64),
+              ('batch', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+              ('beta', c_f32), ('reserved', ctypes.c_int32)]
+
+
+_TEXT_HEAD_FIELDS = ['w1', 'b1', 'w2', 'b2', 'bn_gamma', 'bn_beta', 'running_mean', 'running_var', 'moe_w', 'moe_b',
+                     'g_w1', 'g_b1', 'g_w2', 'g_b2', 'g_bn_gamma', 'g_bn_beta', 'g_moe_w', 'g_moe_b']
+
+
+class MmtTextHeads(ctypes.Structure):
+  _fields_ = [(n, _PTR16) for n in _TEXT_HEAD_FIELDS]
+
+
 EPI = dict(BF16=0, BIAS_BF16=1, BIAS_GELU=2, BIAS_DROP_RES=3, DGELU=4, ADD_F32=5, F32=6, BIAS_F32=7)
 
 # name -> (restype, argtypes); must list every symbol declared in include/mmt_hip.h
@@ -71,7 +89,8 @@ SIGNATURES = {
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                            c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
-    'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    'mmt_table_grad_scratch_floats': (c_i64, [c_int, c_int]),
+    'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mmt_attn_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
                              c_f32, c_vp, c_vp]),
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
@@ -97,6 +116,12 @@ SIGNATURES = {
     'mmt_bert_forward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_int, c_vp]),
     'mmt_bert_backward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp, c_int,
                                   c_vp]),
+    'mmt_sgemm_batched': (c_int, [ctypes.POINTER(MmtSgemm), c_vp]),
+    'mmt_text_heads_workspace_floats': (c_i64, [c_int, c_int, c_int]),
+    'mmt_text_heads_fwd': (c_int, [ctypes.POINTER(MmtTextHeads), c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_text_heads_bwd': (c_int, [ctypes.POINTER(MmtTextHeads), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mmt_probe_arm': (c_int, [c_vp, c_vp, c_int]),
     'mmt_probe_count': (c_int, []),
 }

@@ -220,6 +220,8 @@ class BertModel(nn.Module):
       if self._flat.ensure(device):
         self._structs = {}
       self._flat.pack()
+      if torch.is_grad_enabled():
+        self._flat.select_grad_buffer()
     if self._seed_dev is None or self._seed_dev.device != torch.device(device):
       seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
       self._seed_dev = torch.tensor([seed], dtype=torch.int32, device=device)
@@ -291,7 +293,7 @@ class BertModel(nn.Module):
     if features.dtype != torch.float32 or not features.is_contiguous() or rows_alloc % ops.ROW_ALIGN:
       raise RuntimeError('engine features must be contiguous fp32 [rows padded to %d, hidden]' % ops.ROW_ALIGN)
     batch.features = features
-    grad_buf = self._flat.grads[self._flat._which]
+    grad_buf = self._flat.current_grad()
     m, _ = self._struct(grad_buf)
     if save:
       self._generation += 1
@@ -306,7 +308,7 @@ class BertModel(nn.Module):
 
   def _engine_backward(self, batch, dout, training):
     rows_alloc = batch.features.shape[0]
-    grad_buf = self._flat.grad_buffer()
+    grad_buf = self._flat.current_grad()
     m, _ = self._struct(grad_buf)
     ws = self._workspace(rows_alloc, True, m)
     dlast = dout.contiguous().clone()  # the engine uses it as scratch

@@ -19,7 +19,7 @@ struct Ws {
   float *z0, *mean0, *rstd0, *h32_in;
   char* h16_in;
   LayerWs layer[64];
-  float *dz, *dA, *delta, *ln_partials, *col_partials, *slabs;
+  float *dz, *dA, *delta, *ln_partials, *col_partials, *slabs, *table_scratch;
   char *dy, *dhpre, *dctx, *dqkv;
   size_t bytes;
 };
@@ -66,6 +66,8 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     if (need > slab) slab = need;
   }
   w->slabs = (float*)take(slab * 4);
+  const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
+  w->table_scratch = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
   w->bytes = off;
 }
 
@@ -216,7 +218,7 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
   TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials, rows, d, 2, nr,
                  b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
   TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, m->g_emb_ln_g, m->g_emb_ln_b, nullptr, nullptr, 0, stream));
-  TRY(mmt_table_grad(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, m->g_type_emb, 0, stream));
-  if (b->pos_ids) TRY(mmt_table_grad(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, m->g_pos_emb, 0, stream));
+  TRY(mmt_table_grad(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch, m->g_type_emb, 0, stream));
+  if (b->pos_ids) TRY(mmt_table_grad(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch, m->g_pos_emb, 0, stream));
   return 0;
 }

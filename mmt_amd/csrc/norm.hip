@@ -170,39 +170,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
-// out[j][c] (+)= sum_b partials[b][j][c]   (j < nvec; fixed summation order => deterministic)
+// out[j][c] (+)= sum_b partials[b][j][c]   (j < nvec).  Block = 64 columns x 4 row-groups; each thread sums
+// a strided quarter of the blocks, then a fixed-order LDS combine => deterministic.
 struct ColOuts { float* p[4]; };
-__global__ void col_reduce_kernel(const float* __restrict__ partials, int nblocks, int nvec, int d,
-                                  ColOuts outs, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nvec * d) return;
-  const int j = e / d, c = e % d;
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ partials, int nblocks, int nvec, int d,
+                                                         ColOuts outs, int accumulate) {
+  __shared__ float red[4][64];
+  const int chunks = (d + 63) / 64;
+  const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
   float* out = outs.p[j];
-  if (!out) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[((int64_t)b * nvec + j) * d + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (out && c < d)
+    for (int b = rg; b < nblocks; b += 4) s += partials[((int64_t)b * nvec + j) * d + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && out && c < d) {
+    const int t = threadIdx.x;
+    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    out[c] = accumulate ? out[c] + v : v;
+  }
 }
 
-// dtable[v][c] (+)= sum over rows with ids[row] == v of g[row][c].   grid = (vocab, d/256).
+// partial[chunk][v][c] = sum over the chunk's rows with ids[row] == v of g[row][c].  grid = (vocab, d/256, chunks);
+// the chunks are then summed by col_reduce_kernel (fixed order => deterministic, no atomics).
+#define TABLE_CHUNKS 32
 __global__ __launch_bounds__(256) void table_grad_kernel(
-    const float* __restrict__ g, const int32_t* __restrict__ ids, int rows, int d,
-    const int32_t* __restrict__ n_rows_dev, float* __restrict__ dtable, int accumulate) {
-  const int v = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+    const float* __restrict__ g, const int32_t* __restrict__ ids, int rows, int d, int vocab,
+    const int32_t* __restrict__ n_rows_dev, float* __restrict__ partial) {
+  const int v = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x, chunk = blockIdx.z;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int per = (nrows + TABLE_CHUNKS - 1) / TABLE_CHUNKS;
+  const int r_begin = chunk * per, r_end = min(nrows, r_begin + per);
   __shared__ int32_t sid[256];
   float s = 0.f;
-  for (int r0 = 0; r0 < nrows; r0 += 256) {
+  for (int r0 = r_begin; r0 < r_end; r0 += 256) {
     const int r = r0 + threadIdx.x;
-    sid[threadIdx.x] = r < nrows ? ids[r] : -1;
+    sid[threadIdx.x] = r < r_end ? ids[r] : -1;
     __syncthreads();
-    const int lim = min(256, nrows - r0);
+    const int lim = min(256, r_end - r0);
     for (int k = 0; k < lim; ++k)
       if (sid[k] == v) s += g[(int64_t)(r0 + k) * d + col];
     __syncthreads();
   }
-  float* o = dtable + (int64_t)v * d + col;
-  *o = accumulate ? *o + s : s;
+  partial[((int64_t)chunk * vocab + v) * d + col] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,17 +274,23 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
 extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,
                               float* out2, float* out3, int accumulate, void* stream) {
   if (!partials || nblocks <= 0 || nvec <= 0 || nvec > 4 || d <= 0) return MMT_ERR_ARG;
-  const int n = nvec * d;
   ColOuts outs = {{out0, out1, out2, out3}};
-  hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(nvec * ((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials,
                      nblocks, nvec, d, outs, accumulate);
   return (int)hipGetLastError();
 }
 
+extern "C" int64_t mmt_table_grad_scratch_floats(int vocab, int d) { return (int64_t)TABLE_CHUNKS * vocab * d; }
+
 extern "C" int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int vocab,
-                              const int32_t* n_rows_dev, float* dtable, int accumulate, void* stream) {
-  if (!g || !ids || !dtable || rows <= 0 || vocab <= 0 || d % 256) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(table_grad_kernel, dim3(vocab, d / 256), dim3(256), 0, (hipStream_t)stream, g, ids, rows,
-                     d, n_rows_dev, dtable, accumulate);
+                              const int32_t* n_rows_dev, float* scratch, float* dtable, int accumulate,
+                              void* stream) {
+  if (!g || !ids || !dtable || !scratch || rows <= 0 || vocab <= 0 || d % 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(table_grad_kernel, dim3(vocab, d / 256, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, ids,
+                     rows, d, vocab, n_rows_dev, scratch);
+  ColOuts outs = {{dtable, nullptr, nullptr, nullptr}};
+  const int n = vocab * d;
+  hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, TABLE_CHUNKS, 1,
+                     n, outs, accumulate);
   return (int)hipGetLastError();
 }

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__
   const int NO = side == 0 ? NV : NT;  // the other side's count
   const float* other = side == 0 ? vid : txt;
   const float* wother = side == 0 ? vw : tw;
-  for (int m = 0; m < M; ++m) {
+  {
+    const int m = blockIdx.y;
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -126,7 +127,6 @@ __global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < d; i += 256)
       dx[((int64_t)self * M + m) * d + i] = racc[0][i] + racc[1][i] + racc[2][i] + racc[3][i];
     if (threadIdx.x == 0) dwt[self * M + m] = rw[0] + rw[1] + rw[2] + rw[3];
-    __syncthreads();
   }
 }
 
@@ -246,9 +246,9 @@ extern "C" int mmt_sims_bwd(const float* txt, const float* vid, const float* tw,
                             float* dvw, void* stream) {
   if (!txt || !vid || !tw || !vw || !dots || !dsims || !dtxt || !dvid || !dtw || !dvw) return MMT_ERR_ARG;
   if (NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
+  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
                      NV, M, d, 0, dtxt, dtw);
-  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NV), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
+  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NV, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
                      NV, M, d, 1, dvid, dvw);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,399 @@
+// Text heads of CENet (gfx950, fp32): per-expert GatedEmbeddingUnit + text MoE weights,
+//   model/model.py:683-702 (GatedEmbeddingUnit), :736-750 (ContextGating + BatchNorm1d), :262-283,618 (MoE).
+// The reference issues ~50 ATen ops per expert; here the M experts are batched:
+//   sgemm_batched : C_b = [beta*C_b +] A_b . B_b^T(strided) [+ bias_b]   generic-stride fp32 GEMM (tiny N = B*C rows)
+//   bn_stats      : per (expert, column) batch mean / rstd (+ running-stat update, momentum 0.1)
+//   gate_norm     : e = F.normalize(y * sigmoid(BN(x1)))                  written in (B, M, C, d) layout
+//   moe           : softmax_m(text . w_m + b_m)
+// and the matching backward kernels.  Activations are [N, M, d] (row n contiguous over experts) so that
+// the text gradient is ONE GEMM over K = M*d.  Arithmetic is fp32 like the reference (the work is ~0.3 GFLOP).
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define TM 32
+#define TN 64
+#define TK 16
+
+__global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g) {
+  __shared__ float As[TK][TM + 1];
+  __shared__ float Bs[TK][TN + 4];
+  const int b = blockIdx.z;
+  const float* __restrict__ A = g.A[b];
+  const float* __restrict__ B = g.B[b];
+  float* __restrict__ C = g.C[b];
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < g.K; k0 += TK) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {  // A tile: 32 x 16
+      const int e = tid * 2 + r;
+      int i, k;
+      if (g.sak == 1) { i = e >> 4; k = e & 15; } else { k = e >> 5; i = e & 31; }
+      float v = 0.f;
+      if (i0 + i < g.M && k0 + k < g.K) v = A[(int64_t)(i0 + i) * g.sai + (int64_t)(k0 + k) * g.sak];
+      As[k][i] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // B tile: 64 x 16
+      const int e = tid * 4 + r;
+      int j, k;
+      if (g.sbk == 1) { j = e >> 4; k = e & 15; } else { k = e >> 6; j = e & 63; }
+      float v = 0.f;
+      if (j0 + j < g.N && k0 + k < g.K) v = B[(int64_t)(j0 + j) * g.sbj + (int64_t)(k0 + k) * g.sbk];
+      Bs[k][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      const float a0 = As[k][ty * 2], a1 = As[k][ty * 2 + 1];
+      const f32x4 bv = *(const f32x4*)(&Bs[k][tx * 4]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { acc[0][c] += a0 * bv[c]; acc[1][c] += a1 * bv[c]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = i0 + ty * 2 + r;
+    if (i >= g.M) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + tx * 4 + c;
+      if (j >= g.N) continue;
+      float v = acc[r][c];
+      if (g.bias[b]) v += g.bias[b][j];
+      float* dst = C + (int64_t)i * g.ldc + j;
+      *dst = g.beta != 0.f ? *dst * g.beta + v : v;
+    }
+  }
+}
+
+extern "C" int mmt_sgemm_batched(const MmtSgemm* g, void* stream) {
+  if (!g || g->batch <= 0 || g->batch > MMT_MAX_EXPERTS || g->M <= 0 || g->N <= 0 || g->K <= 0) return MMT_ERR_ARG;
+  for (int b = 0; b < g->batch; ++b)
+    if (!g->A[b] || !g->B[b] || !g->C[b]) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(sgemm_batched_kernel, dim3((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, g->batch), dim3(256), 0,
+                     (hipStream_t)stream, *g);
+  return (int)hipGetLastError();
+}
+
+// ---- BatchNorm statistics over the N rows: x1 [N, M, d] -----------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x1, int N, int M, int d, float eps,
+                                                       float momentum, MmtTextHeads h, float* __restrict__ mean_out,
+                                                       float* __restrict__ rstd_out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * d) return;
+  const int m = idx / d, c = idx % d;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += x1[((int64_t)n * M + m) * d + c];
+  const float mean = s / N;
+  float v = 0.f;
+  for (int n = 0; n < N; ++n) { const float t = x1[((int64_t)n * M + m) * d + c] - mean; v += t * t; }
+  const float var = v / N;
+  mean_out[idx] = mean;
+  rstd_out[idx] = 1.0f / sqrtf(var + eps);
+  if (h.running_mean[m]) {
+    h.running_mean[m][c] = (1.f - momentum) * h.running_mean[m][c] + momentum * mean;
+    h.running_var[m][c] = (1.f - momentum) * h.running_var[m][c] + momentum * (N > 1 ? v / (N - 1) : var);
+  }
+}
+
+// eval mode: mean/rstd from the running statistics
+__global__ void bn_running_kernel(int M, int d, float eps, MmtTextHeads h, float* __restrict__ mean_out,
+                                  float* __restrict__ rstd_out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * d) return;
+  const int m = idx / d, c = idx % d;
+  mean_out[idx] = h.running_mean[m][c];
+  rstd_out[idx] = 1.0f / sqrtf(h.running_var[m][c] + eps);
+}
+
+// one wave per (n, m): z = gamma*(x1-mean)*rstd+beta (use_bn) else x1; o = y*sigmoid(z); e = o/max(|o|,1e-12)
+// BWD: from de -> dyg (gate-path gradient wrt y) and dz
+template <bool BWD>
+__global__ __launch_bounds__(256) void gate_norm_kernel(const float* __restrict__ y, const float* __restrict__ x1,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        MmtTextHeads h, int N, int M, int d, int C, int use_bn,
+                                                        float* __restrict__ e_out, const float* __restrict__ de,
+                                                        float* __restrict__ dyg, float* __restrict__ dz) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (d + 255) >> 8;
+  for (int w = blockIdx.x * 4 + wave; w < N * M; w += gridDim.x * 4) {
+    const int n = w / M, m = w % M;
+    const int64_t src = ((int64_t)n * M + m) * d;
+    const int bb = n / C, cc = n % C;
+    const int64_t dst = (((int64_t)bb * M + m) * C + cc) * d;  // (B, M, C, d)
+    f32x4 o[4], sg[4], yy[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        if (col < d) {
+          yy[c] = *(const f32x4*)(y + src + col);
+          f32x4 z = *(const f32x4*)(x1 + src + col);
+          if (use_bn) {
+            const f32x4 mu = *(const f32x4*)(mean + m * d + col), rs = *(const f32x4*)(rstd + m * d + col);
+            const f32x4 ga = *(const f32x4*)(h.bn_gamma[m] + col), be = *(const f32x4*)(h.bn_beta[m] + col);
+            z = (z - mu) * rs * ga + be;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sg[c][k] = 1.0f / (1.0f + __expf(-z[k]));
+            o[c][k] = yy[c][k] * sg[c][k];
+            ss += o[c][k] * o[c][k];
+          }
+        }
+      }
+    const float nrm = sqrtf(wave_sum(ss));
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nch) {
+          const int col = c * 256 + lane * 4;
+          if (col < d) *(f32x4*)(e_out + dst + col) = o[c] * inv;
+        }
+    } else {
+      f32x4 g[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nch) {
+          const int col = c * 256 + lane * 4;
+          if (col < d) {
+            g[c] = *(const f32x4*)(de + dst + col);
+            dot += g[c][0] * o[c][0] + g[c][1] * o[c][1] + g[c][2] * o[c][2] + g[c][3] * o[c][3];
+          }
+        }
+      const float proj = nrm > 1e-12f ? wave_sum(dot) * inv * inv : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nch) {
+          const int col = c * 256 + lane * 4;
+          if (col < d) {
+            f32x4 dy_, dz_;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float dox = (g[c][k] - o[c][k] * proj) * inv;  // grad wrt o
+              dy_[k] = dox * sg[c][k];
+              dz_[k] = dox * yy[c][k] * sg[c][k] * (1.0f - sg[c][k]);
+            }
+            *(f32x4*)(dyg + src + col) = dy_;
+            *(f32x4*)(dz + src + col) = dz_;
+          }
+        }
+    }
+  }
+}
+
+// BatchNorm backward per (m, column): dz [N,M,d] -> dx1 (in place over dz), dgamma, dbeta, db2 = colsum(dx1)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x1, float* __restrict__ dz,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     MmtTextHeads h, int N, int M, int d, int use_bn, int training) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * d) return;
+  const int m = idx / d, c = idx % d;
+  if (!use_bn) {  // dx1 = dz; only the bias gradient of cg.fc is needed
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[((int64_t)n * M + m) * d + c];
+    if (h.g_b2[m]) h.g_b2[m][c] = s;
+    return;
+  }
+  const float mu = mean[idx], rs = rstd[idx], ga = h.bn_gamma[m][c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t p = ((int64_t)n * M + m) * d + c;
+    const float xh = (x1[p] - mu) * rs, g = dz[p];
+    s1 += g;
+    s2 += g * xh;
+  }
+  if (h.g_bn_gamma[m]) h.g_bn_gamma[m][c] = s2;
+  if (h.g_bn_beta[m]) h.g_bn_beta[m][c] = s1;
+  float sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t p = ((int64_t)n * M + m) * d + c;
+    float dx;
+    if (training) {
+      const float xh = (x1[p] - mu) * rs;
+      dx = ga * rs * (dz[p] - s1 / N - xh * s2 / N);
+    } else {
+      dx = ga * rs * dz[p];
+    }
+    dz[p] = dx;
+    sb += dx;
+  }
+  if (h.g_b2[m]) h.g_b2[m][c] = sb;
+}
+
+// column sums of dy [N, M*d] -> g_b1[m][c]
+__global__ void colsum_f32_kernel(const float* __restrict__ dy, int N, int M, int d, MmtTextHeads h) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * d) return;
+  const int m = idx / d, c = idx % d;
+  if (!h.g_b1[m]) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dy[(int64_t)n * M * d + idx];
+  h.g_b1[m][c] = s;
+}
+
+// MoE: one block per row n.  fwd: tw[n][m] = softmax_m(text[n].w_m + b_m).
+__global__ __launch_bounds__(256) void moe_fwd_kernel(const float* __restrict__ text, int K, int M, MmtTextHeads h,
+                                                      float* __restrict__ tw) {
+  __shared__ float logit[MMT_MAX_EXPERTS];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = wave; m < M; m += 4) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += text[(int64_t)n * K + k] * h.moe_w[m][k];
+    s = wave_sum(s);
+    if (lane == 0) logit[m] = s + h.moe_b[m][0];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = -INFINITY, sum = 0.f;
+    for (int m = 0; m < M; ++m) mx = fmaxf(mx, logit[m]);
+    for (int m = 0; m < M; ++m) sum += __expf(logit[m] - mx);
+    float l1 = 0.f;
+    for (int m = 0; m < M; ++m) { logit[m] = __expf(logit[m] - mx) / sum; l1 += fabsf(logit[m]); }
+    for (int m = 0; m < M; ++m) tw[(int64_t)n * M + m] = logit[m] / fmaxf(l1, 1e-12f);  // F.normalize(p=1), model.py:618
+  }
+}
+
+// bwd part 1 (block per row n): dlogit[n][m] = tw (dtw - sum_j tw_j dtw_j); dtext[n] += sum_m dlogit[n][m] w_m
+__global__ __launch_bounds__(256) void moe_bwd_row_kernel(const float* __restrict__ tw, const float* __restrict__ dtw, int K,
+                                                          int M, MmtTextHeads h, float* __restrict__ dlogit,
+                                                          float* __restrict__ dtext, int accumulate) {
+  __shared__ float dl[MMT_MAX_EXPERTS];
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float dot = 0.f;
+    for (int m = 0; m < M; ++m) dot += tw[(int64_t)n * M + m] * dtw[(int64_t)n * M + m];
+    for (int m = 0; m < M; ++m) {
+      dl[m] = tw[(int64_t)n * M + m] * (dtw[(int64_t)n * M + m] - dot);
+      dlogit[(int64_t)n * M + m] = dl[m];
+    }
+  }
+  __syncthreads();
+  if (dtext)
+    for (int k = threadIdx.x; k < K; k += 256) {
+      float s = 0.f;
+      for (int m = 0; m < M; ++m) s += dl[m] * h.moe_w[m][k];
+      dtext[(int64_t)n * K + k] = accumulate ? dtext[(int64_t)n * K + k] + s : s;
+    }
+}
+// bwd part 2 (block per expert m): g_moe_w[m][k] = sum_n dlogit[n][m] text[n][k]; g_moe_b[m] = sum_n dlogit[n][m]
+__global__ __launch_bounds__(256) void moe_bwd_w_kernel(const float* __restrict__ text, const float* __restrict__ dlogit,
+                                                        int N, int K, int M, MmtTextHeads h) {
+  const int m = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dlogit[(int64_t)n * M + m] * text[(int64_t)n * K + k];
+    if (h.g_moe_w[m]) h.g_moe_w[m][k] = s;
+  }
+  if (threadIdx.x == 0 && h.g_moe_b[m]) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dlogit[(int64_t)n * M + m];
+    h.g_moe_b[m][0] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_heads(const MmtTextHeads* h, const float* text, int N, int M, int d, int K) {
+  if (!h || !text || N <= 0 || M <= 0 || M > MMT_MAX_EXPERTS || d % 4 || d > 1024 || K <= 0) return MMT_ERR_ARG;
+  for (int m = 0; m < M; ++m)
+    if (!h->w1[m] || !h->b1[m] || !h->w2[m] || !h->b2[m]) return MMT_ERR_ARG;
+  return 0;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// ws layout (floats): y [N*M*d] | x1 [N*M*d] | mean [M*d] | rstd [M*d] | dyg [N*M*d] | dz [N*M*d] | dlogit [N*M]
+extern "C" int64_t mmt_text_heads_workspace_floats(int N, int M, int d) {
+  return 4LL * N * M * d + 2LL * M * d + (int64_t)N * M + 64;
+}
+
+extern "C" int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M,
+                                  int d, int K, int use_bn, int training, float* ws, float* text_embds,
+                                  float* text_weights, void* stream) {
+  TRY(check_heads(h, text, N, M, d, K));
+  if (!ws || !text_embds || C <= 0 || N % C) return MMT_ERR_ARG;
+  const int64_t nmd = (int64_t)N * M * d;
+  float *y = ws, *x1 = ws + nmd, *mean = ws + 2 * nmd, *rstd = mean + (int64_t)M * d;
+  hipStream_t s = (hipStream_t)stream;
+  MmtSgemm g = {};
+  g.batch = M; g.M = N; g.N = d; g.K = K; g.sai = K; g.sak = 1; g.sbj = K; g.sbk = 1; g.ldc = (int64_t)M * d;
+  for (int m = 0; m < M; ++m) { g.A[m] = text; g.B[m] = h->w1[m]; g.C[m] = y + (int64_t)m * d; g.bias[m] = h->b1[m]; }
+  TRY(mmt_sgemm_batched(&g, stream));                       // y = fc(text)                 model.py:698
+  g.K = d; g.sai = (int64_t)M * d; g.sbj = d;
+  for (int m = 0; m < M; ++m) { g.A[m] = y + (int64_t)m * d; g.B[m] = h->w2[m]; g.C[m] = x1 + (int64_t)m * d; g.bias[m] = h->b2[m]; }
+  TRY(mmt_sgemm_batched(&g, stream));                       // x1 = cg.fc(y)                model.py:745
+  if (use_bn) {
+    const int blocks = (M * d + 255) / 256;
+    if (training)
+      hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, s, x1, N, M, d, 1e-5f, 0.1f, *h, mean, rstd);
+    else
+      hipLaunchKernelGGL(bn_running_kernel, dim3(blocks), dim3(256), 0, s, M, d, 1e-5f, *h, mean, rstd);
+  }
+  int gb = (N * M + 3) / 4;
+  if (gb > 2048) gb = 2048;
+  hipLaunchKernelGGL(gate_norm_kernel<false>, dim3(gb), dim3(256), 0, s, y, x1, mean, rstd, *h, N, M, d, C, use_bn,
+                     text_embds, nullptr, nullptr, nullptr);
+  if (text_weights) {
+    for (int m = 0; m < M; ++m)
+      if (!h->moe_w[m] || !h->moe_b[m]) return MMT_ERR_ARG;
+    hipLaunchKernelGGL(moe_fwd_kernel, dim3(N), dim3(256), 0, s, text_moe ? text_moe : text, K, M, *h, text_weights);
+  }
+  return (int)hipGetLastError();
+}
+
+// w1_all: the M fc.weight matrices contiguous as [M*d, K] (flat layout) for the single text-gradient GEMM.
+extern "C" int mmt_text_heads_bwd(const MmtTextHeads* h, const float* text, const float* text_moe, const float* w1_all,
+                                  int N, int C, int M, int d, int K, int use_bn, int training, float* ws,
+                                  const float* dtext_embds, const float* text_weights, const float* dtext_weights,
+                                  float* dtext, float* dtext_moe, void* stream) {
+  TRY(check_heads(h, text, N, M, d, K));
+  if (!ws || !dtext_embds || C <= 0 || N % C) return MMT_ERR_ARG;
+  const int64_t nmd = (int64_t)N * M * d;
+  float *y = ws, *x1 = ws + nmd, *mean = ws + 2 * nmd, *rstd = mean + (int64_t)M * d;
+  float *dyg = rstd + (int64_t)M * d, *dz = dyg + nmd, *dlogit = dz + nmd;
+  hipStream_t s = (hipStream_t)stream;
+  int gb = (N * M + 3) / 4;
+  if (gb > 2048) gb = 2048;
+  hipLaunchKernelGGL(gate_norm_kernel<true>, dim3(gb), dim3(256), 0, s, y, x1, mean, rstd, *h, N, M, d, C, use_bn, nullptr,
+                     dtext_embds, dyg, dz);
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((M * d + 255) / 256), dim3(256), 0, s, x1, dz, mean, rstd, *h, N, M, d, use_bn,
+                     training);  // dz now holds dx1
+  MmtSgemm g = {};
+  // dy = dyg + dx1 . W2
+  g.batch = M; g.M = N; g.N = d; g.K = d; g.sai = (int64_t)M * d; g.sak = 1; g.sbj = 1; g.sbk = d;
+  g.ldc = (int64_t)M * d; g.beta = 1.f;
+  for (int m = 0; m < M; ++m) { g.A[m] = dz + (int64_t)m * d; g.B[m] = h->w2[m]; g.C[m] = dyg + (int64_t)m * d; g.bias[m] = nullptr; }
+  TRY(mmt_sgemm_batched(&g, stream));
+  // g_w2[m] = dx1[m]^T . y[m]
+  g.M = d; g.N = d; g.K = N; g.sai = 1; g.sak = (int64_t)M * d; g.sbj = 1; g.sbk = (int64_t)M * d; g.ldc = d; g.beta = 0.f;
+  bool any = false;
+  for (int m = 0; m < M; ++m) { g.A[m] = dz + (int64_t)m * d; g.B[m] = y + (int64_t)m * d; g.C[m] = h->g_w2[m]; any |= h->g_w2[m] != nullptr; }
+  if (any) TRY(mmt_sgemm_batched(&g, stream));
+  // g_w1[m] = dy[m]^T . text
+  g.M = d; g.N = K; g.K = N; g.sai = 1; g.sak = (int64_t)M * d; g.sbj = 1; g.sbk = K; g.ldc = K;
+  any = false;
+  for (int m = 0; m < M; ++m) { g.A[m] = dyg + (int64_t)m * d; g.B[m] = text; g.C[m] = h->g_w1[m]; any |= h->g_w1[m] != nullptr; }
+  if (any) TRY(mmt_sgemm_batched(&g, stream));
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((M * d + 255) / 256), dim3(256), 0, s, dyg, N, M, d, *h);
+  if (dtext) {  // dtext = dy_all [N, M*d] . W1_all [M*d, K]
+    if (!w1_all) return MMT_ERR_ARG;
+    MmtSgemm t = {};
+    t.batch = 1; t.M = N; t.N = K; t.K = M * d; t.sai = (int64_t)M * d; t.sak = 1; t.sbj = 1; t.sbk = K; t.ldc = K;
+    t.A[0] = dyg; t.B[0] = w1_all; t.C[0] = dtext;
+    TRY(mmt_sgemm_batched(&t, stream));
+  }
+  if (text_weights && dtext_weights) {
+    // the MoE branch may read a dropped-out copy of text (moe_txt_dropout, model.py:274): its input gradient then
+    // goes to dtext_moe (written); otherwise it is accumulated into dtext.
+    hipLaunchKernelGGL(moe_bwd_row_kernel, dim3(N), dim3(256), 0, s, text_weights, dtext_weights, K, M, *h, dlogit,
+                       dtext_moe ? dtext_moe : dtext, dtext_moe ? 0 : 1);
+    hipLaunchKernelGGL(moe_bwd_w_kernel, dim3(M), dim3(256), 0, s, text_moe ? text_moe : text, dlogit, N, K, M, *h);
+  }
+  return (int)hipGetLastError();
+}

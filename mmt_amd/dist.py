@@ -58,7 +58,7 @@ class GradSync:
       return
     handles = []
     if self.flat is not None:
-      g = self.flat.grads[self.flat._which]
+      g = self.flat.current_grad()
       handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
     grads = [p.grad for p in self.other if p.grad is not None]
     if grads:

@@ -88,8 +88,14 @@ class FlatParams:
     buf = self.master if buf is None else buf
     return buf.data_ptr() + 4 * self.offsets[id(p)]
 
-  def grad_buffer(self):
-    """A flat gradient buffer that no live `.grad` aliases (see module docstring of mmt_amd.bert)."""
+  def current_grad(self):
+    """The buffer every backward function of the current step writes (chosen by select_grad_buffer)."""
+    return self.grads[self._which]
+
+  def select_grad_buffer(self):
+    """Called once per forward (grad mode): pick a flat gradient buffer that no live `.grad` aliases, so
+    that when the caller accumulates gradients over several backward passes autograd's `+=` adds two
+    different buffers.  All backward functions of the step then use current_grad()."""
     cur = self.grads[self._which]
     lo, hi = cur.data_ptr(), cur.data_ptr() + 4 * self.count
     aliased = any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params[:4] + self.params[-4:])

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, ops
-from ._lib import MmtExpertIO, check
+from ._lib import MmtExpertIO, MmtTextHeads, check
 from .bert import BertModel, EngineBatch
 from .flat import FlatParams
 
@@ -144,6 +144,28 @@ class _SimsFn(torch.autograd.Function):
                                   ops._p(dsims.contiguous().float()), nt, nv, m, d, ops._p(dtxt), ops._p(dvid),
                                   ops._p(dtw), ops._p(dvw), ops._stream()), 'mmt_sims_bwd')
     return dtxt, dvid, dtw, dvw
+
+
+class _TextHeadsFn(torch.autograd.Function):
+  """text (B*C, K) -> text_embds (B, M, C, d), text_weights (B, C, M): the per-expert GatedEmbeddingUnits
+  (model.py:413-417, 683-750) and the text MoE softmax (model.py:262-283, 610-618) in one native pass."""
+
+  @staticmethod
+  def forward(ctx, net, text, text_moe, caps, *params):
+    tm = None if text_moe is None else text_moe.detach().contiguous().float()
+    out = net._text_heads_forward(text.detach().contiguous().float(), tm, caps)
+    ctx.net, ctx.caps, ctx.generation, ctx.training = net, caps, net._th_generation, net.training
+    ctx.need_dtext = text.requires_grad
+    ctx.need_dmoe = text_moe is not None and text_moe.requires_grad
+    return out
+
+  @staticmethod
+  def backward(ctx, de, dtw):
+    net = ctx.net
+    if net._th_generation != ctx.generation:
+      raise RuntimeError('mmt_amd.CENet: text-head buffers were overwritten by a later forward')
+    dtext, dmoe, grads = net._text_heads_backward(ctx.caps, de, dtw, ctx.need_dtext, ctx.need_dmoe, ctx.training)
+    return (None, dtext, dmoe, None) + tuple(grads)
 
 
 def cross_view_similarity(vid_embds, text_embds, vid_weights, text_weights, merge='avg'):
@@ -302,7 +324,23 @@ class CENet(nn.Module):
     for mod in self.modalities:
       named += [('video_dim_reduce.%s.fc.weight' % mod, self.video_dim_reduce[mod].fc.weight),
                 ('video_dim_reduce.%s.fc.bias' % mod, self.video_dim_reduce[mod].fc.bias)]
+    self._native_text_heads = txt_pro in ('gbn', 'gem')
+    if self._native_text_heads:
+      named += [('text_GU.%s.fc.weight' % mod, self.text_GU[mod].fc.weight) for mod in self.modalities]  # contiguous
+      for mod in self.modalities:
+        gu = self.text_GU[mod]
+        named += [('text_GU.%s.fc.bias' % mod, gu.fc.bias), ('text_GU.%s.cg.fc.weight' % mod, gu.cg.fc.weight),
+                  ('text_GU.%s.cg.fc.bias' % mod, gu.cg.fc.bias),
+                  ('text_GU.%s.cg.batch_norm.weight' % mod, gu.cg.batch_norm.weight),
+                  ('text_GU.%s.cg.batch_norm.bias' % mod, gu.cg.batch_norm.bias)]
+      if txt_wgh == 'emb':
+        for mod in self.modalities:
+          named += [('moe_fc_txt.%s.weight' % mod, self.moe_fc_txt[mod].weight),
+                    ('moe_fc_txt.%s.bias' % mod, self.moe_fc_txt[mod].bias)]
     self._flat = FlatParams(named)
+    self._th_generation = 0
+    self._th_ws = {}
+    self._nbt = None
     self.vid_bert.register_shadows(self._flat)
     for mod in self.modalities:
       dim = expert_dims[mod]['dim']
@@ -329,7 +367,10 @@ class CENet(nn.Module):
   def _prepare(self, device):
     if self._flat.ensure(device):
       self.vid_bert._structs = {}
+      self._th_ws = {}
     self._flat.pack(force=self.training and torch.is_grad_enabled())
+    if torch.is_grad_enabled():
+      self._flat.select_grad_buffer()
     self.vid_bert._ensure_ready(device)
 
   def _video_tokens_forward(self, plan):
@@ -354,7 +395,7 @@ class CENet(nn.Module):
     stream = ops._stream()
     check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(dfeat), stream),
           'mmt_video_scatter_bwd')
-    grad_buf = self._flat.grads[self._flat._which]  # the BERT backward (run just before) already picked it
+    grad_buf = self._flat.current_grad()
     grads = []
     nblk = (plan.src_rows + 31) // 32
     partials = torch.empty(nblk, d, device=dfeat.device, dtype=torch.float32)
@@ -410,6 +451,84 @@ class CENet(nn.Module):
     vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
     return vid.view(bsz, len(mods), self.same_dim)
 
+  # ---- text heads (native) -------------------------------------------------------------------------
+  def _text_head_params(self):
+    out = [self.text_GU[mod].fc.weight for mod in self.modalities]
+    for mod in self.modalities:
+      gu = self.text_GU[mod]
+      out += [gu.fc.bias, gu.cg.fc.weight, gu.cg.fc.bias, gu.cg.batch_norm.weight, gu.cg.batch_norm.bias]
+    if self.txt_wgh == 'emb':
+      for mod in self.modalities:
+        out += [self.moe_fc_txt[mod].weight, self.moe_fc_txt[mod].bias]
+    return out
+
+  def _text_heads_struct(self, grad_buf):
+    f, h = self._flat, MmtTextHeads()
+    for i, mod in enumerate(self.modalities):
+      gu, bn = self.text_GU[mod], self.text_GU[mod].cg.batch_norm
+      pairs = dict(w1=gu.fc.weight, b1=gu.fc.bias, w2=gu.cg.fc.weight, b2=gu.cg.fc.bias, bn_gamma=bn.weight,
+                   bn_beta=bn.bias)
+      if self.txt_wgh == 'emb':
+        pairs.update(moe_w=self.moe_fc_txt[mod].weight, moe_b=self.moe_fc_txt[mod].bias)
+      for name, p in pairs.items():
+        getattr(h, name)[i] = f.ptr(p)
+        if grad_buf is not None and p.requires_grad:
+          getattr(h, 'g_' + name)[i] = f.ptr(p, grad_buf)
+      h.running_mean[i] = bn.running_mean.data_ptr()
+      h.running_var[i] = bn.running_var.data_ptr()
+    return h
+
+  def _text_heads_forward(self, text, text_moe, caps):
+    n, k = text.shape
+    m, d = len(self.modalities), self.same_dim
+    L = _lib.lib()
+    key = (n, text.device)
+    ws = self._th_ws.get(key)
+    if ws is None:
+      ws = self._th_ws[key] = torch.zeros(L.mmt_text_heads_workspace_floats(n, m, d), device=text.device)
+    self._th_generation += 1
+    self._th_text, self._th_text_moe = text, text_moe
+    use_bn = int(self.txt_pro == 'gbn')
+    if self.training and use_bn:
+      if n <= 1:
+        raise ValueError('Expected more than 1 value per channel when training')  # as nn.BatchNorm1d does
+      if self._nbt is None or self._nbt.device != text.device or any(
+          self.text_GU[mod].cg.batch_norm.num_batches_tracked.data_ptr() != self._nbt[i].data_ptr()
+          for i, mod in enumerate(self.modalities)):
+        vals = [int(self.text_GU[mod].cg.batch_norm.num_batches_tracked) for mod in self.modalities]
+        self._nbt = torch.tensor(vals, dtype=torch.long, device=text.device)
+        for i, mod in enumerate(self.modalities):
+          self.text_GU[mod].cg.batch_norm.num_batches_tracked.data = self._nbt[i]
+      self._nbt.add_(1)
+    embds = torch.empty(n // caps, m, caps, d, device=text.device, dtype=torch.float32)
+    tw = torch.empty(n // caps, caps, m, device=text.device, dtype=torch.float32) if self.txt_wgh == 'emb' else None
+    h = self._text_heads_struct(None)
+    check(L.mmt_text_heads_fwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), n, caps, m, d, k, use_bn, int(self.training), ops._p(ws),
+                               ops._p(embds), ops._p(tw), ops._stream()), 'mmt_text_heads_fwd')
+    if tw is None:
+      tw = torch.full((n // caps, caps, m), 1.0 / m, device=text.device)  # ones, L1-normalised (model.py:612,618)
+    self._th_tw = tw
+    return embds, tw
+
+  def _text_heads_backward(self, caps, de, dtw, need_dtext, need_dmoe, training):
+    text, text_moe = self._th_text, self._th_text_moe
+    n, k = text.shape
+    m, d = len(self.modalities), self.same_dim
+    L = _lib.lib()
+    grad_buf = self._flat.current_grad()
+    h = self._text_heads_struct(grad_buf)
+    dtext = torch.empty_like(text) if need_dtext else None
+    dmoe = torch.empty_like(text) if (need_dmoe and text_moe is not None) else None
+    w1_all = self._flat.ptr(self.text_GU[self.modalities[0]].fc.weight)
+    has_moe = self.txt_wgh == 'emb'
+    check(L.mmt_text_heads_bwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), ctypes.c_void_p(w1_all), n, caps, m, d, k,
+                               int(self.txt_pro == 'gbn'), int(training), ops._p(self._th_ws[(n, text.device)]),
+                               ops._p(de.contiguous()), ops._p(self._th_tw) if has_moe else None,
+                               ops._p(dtw.contiguous()) if has_moe and dtw is not None else None, ops._p(dtext),
+                               ops._p(dmoe), ops._stream()), 'mmt_text_heads_bwd')
+    grads = [self._flat.view(p, grad_buf) if p.requires_grad else None for p in self._text_head_params()]
+    return dtext, dmoe, grads
+
   # ---- text side (stock PyTorch-ROCm) --------------------------------------------------------------
   def text_features(self, token_ids, device):
     """model/model.py:349-379: (B, C, W, 2) -> (B*C, text_dim) via the text tower's [CLS]."""
@@ -442,16 +561,20 @@ class CENet(nn.Module):
     b, c = token_ids.size(0), token_ids.size(1)
     m = len(self.modalities)
     text = self.text_features(token_ids, dev)                                   # (B*C, text_dim)
-    text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417
-    text = text.view(b, c, -1)
-    vid_embds = self.video_embeddings(features, features_t, features_ind, features_maxpool)
-    vid_weights = F.normalize(torch.ones(b, m, device=dev), p=1, dim=-1)        # model.py:594,607
-    if self.txt_wgh == 'emb':
-      text_weights = self.compute_weights_from_emb(text)
+    self._prepare(dev)
+    if self._native_text_heads:
+      text_moe = None
+      if self.txt_wgh == 'emb' and self.training and self.moe_txt_dropout.p > 0:
+        text_moe = self.moe_txt_dropout(text)  # model.py:274: dropout only in front of the MoE logits
+      text_embds, text_weights = _TextHeadsFn.apply(self, text, text_moe, c, *self._text_head_params())
     else:
-      text_weights = torch.ones(b, c, m, device=dev)
-    text_weights = F.normalize(text_weights, p=1, dim=-1)                       # model.py:618
-    text_embds = torch.stack([F.normalize(t, dim=-1) for t in text_embd], 1)    # (B,M,C,d) model.py:623
+      text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417
+      tv = text.view(b, c, -1)
+      text_weights = self.compute_weights_from_emb(tv) if self.txt_wgh == 'emb' else torch.ones(b, c, m, device=dev)
+      text_weights = F.normalize(text_weights, p=1, dim=-1)                       # model.py:618
+      text_embds = torch.stack([F.normalize(t, dim=-1) for t in text_embd], 1)    # (B,M,C,d) model.py:623
+    vid_embds = self.video_embeddings(features, features_t, features_ind, features_maxpool)
+    vid_weights = torch.full((b, m), 1.0 / m, device=dev)                       # ones, L1-normalised model.py:594,607
     merge = 'avg' if self.training else self.test_caption_mode                  # model.py:627-631
     self.merge_caption_similarities = merge
     if out == 'conf':

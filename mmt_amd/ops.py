@@ -136,7 +136,9 @@ def table_grad(g, ids, vocab, rows=None, n_rows_dev=None):
   R, d = g.shape
   rows = R if rows is None else rows
   out = torch.empty(vocab, d, device=g.device, dtype=torch.float32)
-  check(_lib.lib().mmt_table_grad(_p(g), _p(ids), rows, d, vocab, _p(n_rows_dev), _p(out), 0, _stream()),
+  L = _lib.lib()
+  scratch = torch.empty(L.mmt_table_grad_scratch_floats(vocab, d), device=g.device, dtype=torch.float32)
+  check(L.mmt_table_grad(_p(g), _p(ids), rows, d, vocab, _p(n_rows_dev), _p(scratch), _p(out), 0, _stream()),
         'mmt_table_grad')
   return out
 

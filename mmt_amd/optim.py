@@ -18,7 +18,7 @@ class FlatAdam:
 
   def _grad(self):
     f = self.flat
-    g = f.grads[f._which]
+    g = f.current_grad()
     lo, hi = g.data_ptr(), g.data_ptr() + 4 * f.count
     p0 = next((p for p in f.params if p.requires_grad), None)
     if p0 is not None and p0.grad is not None and not (lo <= p0.grad.data_ptr() < hi):

@@ -46,8 +46,14 @@ class GraphedTrainStep:
     self.use_graphs = use_graphs
     self.loss = None
     self._graphs = None
-    for _ in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
-      self._eager_step()
+    # Warm-up AND capture run on one dedicated side stream: autograd's AccumulateGrad nodes remember the
+    # stream they were created on, and a node bound to the default stream breaks capture of the backward.
+    self._stream = torch.cuda.Stream()
+    self._stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._stream):
+      for _ in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
+        self._eager_step()
+    torch.cuda.current_stream().wait_stream(self._stream)
     if use_graphs:
       self._capture()
 
@@ -107,17 +113,19 @@ class GraphedTrainStep:
     torch.cuda.synchronize()
     self._zero()
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ga):
+    with torch.cuda.graph(ga, stream=self._stream):
       e = self._forward()
     pool = ga.pool()
     if self.world > 1:
       self._gbuf = {k: torch.empty((self.world * v.shape[0],) + v.shape[1:], device=v.device, dtype=v.dtype)
                     for k, v in e.items()}
-    g = self._gather(e)
-    with torch.cuda.graph(gb, pool=pool):
+    with torch.cuda.stream(self._stream):
+      g = self._gather(e)
+    with torch.cuda.graph(gb, pool=pool, stream=self._stream):
       self.loss = self._loss_backward(e, g)
-    self.sync.sync()
-    with torch.cuda.graph(gc, pool=pool):
+    with torch.cuda.stream(self._stream):
+      self.sync.sync()
+    with torch.cuda.graph(gc, pool=pool, stream=self._stream):
       self._opt()
     self._graphs, self._e = (ga, gb, gc), e
     torch.cuda.synchronize()
