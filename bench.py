@@ -26,7 +26,7 @@ from mmt_amd import dist as mdist  # noqa: E402
 from mmt_amd import ops, synthetic  # noqa: E402
 from mmt_amd.loss import MaxMarginRankingLoss  # noqa: E402
 from mmt_amd.model import CENet, cross_view_similarity  # noqa: E402
-from mmt_amd.train_step import GraphedTrainStep  # noqa: E402
+from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER = 32, 30, 512, 4, 4, 3072
@@ -171,11 +171,9 @@ def main():
   batches = []
   for i in range(NBATCH):
     mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
-    mb = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in mb.items()}
-    mb['text'] = text.to(dev).view(-1, 768)
-    batches.append(mb)
-  static = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v.clone())
-            for k, v in batches[0].items()}
+    mb['text'] = text.view(-1, 768)
+    batches.append(FlatMinibatch(mb, dev))  # one contiguous HBM buffer per minibatch: load = ONE D2D copy
+  static = FlatMinibatch(batches[0], dev)
   model.txt_bert.text = static['text']
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
   runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager)

@@ -306,10 +306,14 @@ static int launch_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
   return (int)hipGetLastError();
 }
 
+int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                       int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
+
 template <int EPI>
 static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   // 128x128 when it still yields >= 2 tiles per CU or N is wide; otherwise 128x64 for more blocks.
+  if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   const long t128 = (long)((M + 127) / 128) * (N / 128);
   const bool want128 = e.reserved == 1 || (e.reserved == 0 && t128 >= 512);  // reserved: 1/2 force a tile (tests)
   if (N % 128 == 0 && want128) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

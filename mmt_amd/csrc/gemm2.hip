@@ -1,0 +1,287 @@
+// Wide-tile bf16 MFMA NT GEMM for the MMT hot path (gfx950):  C[M,N] = A[M,K] . B[N,K]^T (+ fused epilogue).
+//
+// Why a second kernel: a 128x128 tile moves (128+128)*64*2 B = 32 KiB from L2 into LDS per 64-deep K-step
+// and pays it back with 512 MFMA cycles per SIMD; the L2->CU path delivers ~64 B/clk/CU (34.5 TB/s / 256 CUs,
+// MI355X_MICROARCH.md), i.e. 512 clk for those 32 KiB -- the 128^2 tile is L2-bandwidth-bound at <= 50 % MFMA.
+// 256x128 / 256x256 tiles halve / quarter the bytes per flop.  Structure (cdna guide section 5, "glds, 2 LDS
+// buffers, BK=64, vmcnt(0) + one barrier per K-step"):
+//   * up to 8 waves, each owning a 64 x WTN sub-tile as 2 x (WTN/32) fragments of mfma_f32_32x32x16_bf16
+//     (operands swapped so a lane ends up with 4 consecutive output columns of one row);
+//   * LDS-DMA staging (global_load_lds_dwordx4), lane-linear image, XOR swizzle chunk ^ ((row>>1)&7) applied
+//     to the SOURCE address and to the fragment read: conflict-free for the 32-row ds_read_b128 fragments;
+//   * epilogue through LDS: the accumulators are transposed into a row-major fp32 image 64 rows at a time,
+//     and every global access of the epilogue (bias, residual, GELU aux, outputs) is then a row-contiguous
+//     8-16 B/lane access instead of a 32-byte-per-row scatter.
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+
+#define BK 64
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// erf-form GELU (model/bert.py:37-53) via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the
+// bf16 rounding of the stored activations).  One exp serves Phi(x) and phi(x).
+__device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  const float e = __expf(-0.5f * x * x);
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float half_erfc = 0.5f * t * p * e;  // 0.5 * erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu2(float x) {
+  float c, p;
+  gelu_cdf_pdf(x, c, p);
+  return x * c;
+}
+__device__ __forceinline__ float gelu2_grad(float x) {
+  float c, p;
+  gelu_cdf_pdf(x, c, p);
+  return fmaf(x, p, c);
+}
+
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage2(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
+                                       bf16_t* lds_tile, int wave, int lane) {
+  constexpr int PER = ROWS / 8 / NW;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int rbase = (wave * PER + i) * 8;  // 8 rows of 128 B per wave-instruction
+    const int r = rbase + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int gr = min(row0 + r, row_max);
+    const bf16_t* src = G + (int64_t)gr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * BK), 16, 0, 0);
+  }
+}
+
+template <int BM, int BN, int WGN, int EPI>
+__global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+    void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
+    const int32_t* __restrict__ n_rows_dev) {
+  constexpr int WGM = BM / 64, NW = WGM * WGN, NT = NW * 64, WTN = BN / WGN, NJ = WTN / 32;
+  constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
+  constexpr int CG = BN / 4;       // 4-column groups per row
+  constexpr int RG = NT / CG;      // rows covered per sweep of the block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;
+
+  const int tiles_n = N / BN;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nrows = n_rows_dev ? *n_rows_dev : M;
+  const int tid = threadIdx.x;
+  const int dbg = epi.reserved >> 8;  // lab only: 1 = no loads in the K-loop, 2 = no MFMA, 4 = no global stores, 8 = no epilogue
+  if (m0 >= nrows) {  // dead tile (variable-length packing)
+    if constexpr (EPI == MMT_EPI_DGELU) {
+      if (epi.colsum)
+        for (int h = 0; h < BM / 128; ++h)
+          if (m0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(m0 / 128 + h) * N + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr int STAGE = (BM + BN) * BK;
+  const int KT = K / BK;
+  const int amax = M - 1, bmax = N - 1;
+  stage2<BM, NW>(A, lda, m0, amax, 0, smem, wave, lane);
+  stage2<BN, NW>(B, ldb, n0, bmax, 0, smem + BM * BK, wave, lane);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT && !(dbg & 1)) {
+      stage2<BM, NW>(A, lda, m0, amax, (kt + 1) * BK, smem + (cur ^ 1) * STAGE, wave, lane);
+      stage2<BN, NW>(B, ldb, n0, bmax, (kt + 1) * BK, smem + (cur ^ 1) * STAGE + BM * BK, wave, lane);
+    }
+    const bf16_t* as = smem + cur * STAGE;
+    const bf16_t* bs = as + BM * BK;
+    if (dbg & 2) continue;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + lh;
+      bf16x8_t af[2], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        af[i] = *(const bf16x8_t*)(as + r * BK + ((c ^ ((r >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wn * WTN + j * 32 + l31;
+        bfr[j] = *(const bf16x8_t*)(bs + r * BK + ((c ^ ((r >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: 64 rows at a time through a row-major fp32 LDS image -------------------------------
+  float* st = (float*)smem_raw;
+  float* red = st + 64 * P;  // [RG][BN] column-sum scratch (DGELU)
+  const int cg = tid % CG, rg = tid / CG;
+  const int col = n0 + cg * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_BIAS_DROP_RES ||
+                EPI == MMT_EPI_BIAS_F32)
+    bias4 = *(const f32x4*)(epi.bias + col);
+  unsigned dkey = 0;
+  if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // every wave is done with the stage buffers
+  if (dbg & 8) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    return;
+  }
+#pragma unroll
+  for (int ch = 0; ch < WGM; ++ch) {
+    if (wm == ch) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(st + (i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh) = v;
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r0 = 0; r0 < 64; r0 += RG) {
+      const int r = r0 + rg;
+      const int row = m0 + ch * 64 + r;
+      if (row < M && !(dbg & 4)) {
+        f32x4 v = *(const f32x4*)(st + r * P + cg * 4);
+        v += bias4;
+        if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
+          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+        } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
+          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+          // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
+          const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
+          const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
+          u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
+          *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
+        } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+          if (epi.drop_thr16) {
+            const int orow = epi.row_index ? epi.row_index[row] : row;
+            bool k[4];
+            keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
+          }
+          v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+        } else if constexpr (EPI == MMT_EPI_DGELU) {
+          const u32x2 a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+          v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
+          v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
+          v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
+          v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
+          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+          if (row < nrows) {
+            csum[0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[1] += bf2f((bf16_t)(o[0] >> 16));
+            csum[2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[3] += bf2f((bf16_t)(o[1] >> 16));
+          }
+        } else if constexpr (EPI == MMT_EPI_ADD_F32) {
+          v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+        } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
+          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+        }
+      }
+    }
+    if constexpr (EPI == MMT_EPI_DGELU) {
+      if (epi.colsum && (ch & 1)) {  // one partial row of column sums per 128 output rows
+        *(f32x4*)(red + rg * BN + cg * 4) = (f32x4){csum[0], csum[1], csum[2], csum[3]};
+        csum[0] = csum[1] = csum[2] = csum[3] = 0.f;
+        __syncthreads();
+        const int half_row = m0 / 128 + (ch >> 1);
+        if (tid < BN && half_row * 128 < M) {
+          float s = 0.f;
+#pragma unroll
+          for (int g = 0; g < RG; ++g) s += red[g * BN + tid];
+          epi.colsum[(int64_t)half_row * N + n0 + tid] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int BM, int BN, int WGN, int EPI>
+static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  constexpr int NT = (BM / 64) * WGN * 64;
+  constexpr int RG = NT / (BN / 4);
+  constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * BK * 2;
+  constexpr size_t epi_bytes = (size_t)(64 * (BN + 4) + RG * BN) * 4;
+  constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGN, EPI>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return (int)rc;
+    configured = true;
+  }
+  const int grid = ((M + BM - 1) / BM) * (N / BN);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGN, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
+  return (int)hipGetLastError();
+}
+
+template <int EPI>
+static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                 int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  switch (tile & 0xff) {
+    case 3: if (N % 128 == 0) return launch2<256, 128, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
+    case 4: if (N % 256 == 0) return launch2<256, 256, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
+    case 5: if (N % 128 == 0) return launch2<128, 128, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
+    case 6: if (N % 256 == 0) return launch2<128, 256, 4, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
+  }
+  return MMT_ERR_ARG;
+}
+
+// tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved)
+int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                       int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  switch (epilogue) {
+    case MMT_EPI_BF16: return pick2<MMT_EPI_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_BF16: return pick2<MMT_EPI_BIAS_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_GELU: return pick2<MMT_EPI_BIAS_GELU>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_DROP_RES: return pick2<MMT_EPI_BIAS_DROP_RES>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_DGELU: return pick2<MMT_EPI_DGELU>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_ADD_F32: return pick2<MMT_EPI_ADD_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_F32: return pick2<MMT_EPI_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_F32: return pick2<MMT_EPI_BIAS_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
+  return MMT_ERR_ARG;
+}

@@ -10,62 +10,67 @@
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
-#define TM 32
-#define TN 64
-#define TK 16
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g) {
-  __shared__ float As[TK][TM + 1];
-  __shared__ float Bs[TK][TN + 4];
+// Generic-stride batched fp32 GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32: an fp32 fma chain, so
+// the arithmetic stays fp32 like the reference).  The text heads have only N = B*C (~32) rows, so a 32x32 output
+// tile per WAVE is the natural unit: each weight element is streamed from HBM exactly once.
+//   ksplit == 4 : the 4 waves of a block split the contraction of ONE tile and reduce through LDS (deep K);
+//   ksplit == 1 : the 4 waves own 4 neighbouring tiles (K = N rows for the weight gradients).
+__global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g, int ksplit) {
+  __shared__ float red[3][16][64];
   const int b = blockIdx.z;
   const float* __restrict__ A = g.A[b];
   const float* __restrict__ B = g.B[b];
   float* __restrict__ C = g.C[b];
-  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 0; k0 < g.K; k0 += TK) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {  // A tile: 32 x 16
-      const int e = tid * 2 + r;
-      int i, k;
-      if (g.sak == 1) { i = e >> 4; k = e & 15; } else { k = e >> 5; i = e & 31; }
-      float v = 0.f;
-      if (i0 + i < g.M && k0 + k < g.K) v = A[(int64_t)(i0 + i) * g.sai + (int64_t)(k0 + k) * g.sak];
-      As[k][i] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {  // B tile: 64 x 16
-      const int e = tid * 4 + r;
-      int j, k;
-      if (g.sbk == 1) { j = e >> 4; k = e & 15; } else { k = e >> 6; j = e & 63; }
-      float v = 0.f;
-      if (j0 + j < g.N && k0 + k < g.K) v = B[(int64_t)(j0 + j) * g.sbj + (int64_t)(k0 + k) * g.sbk];
-      Bs[k][j] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      const float a0 = As[k][ty * 2], a1 = As[k][ty * 2 + 1];
-      const f32x4 bv = *(const f32x4*)(&Bs[k][tx * 4]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { acc[0][c] += a0 * bv[c]; acc[1][c] += a1 * bv[c]; }
-    }
-    __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  int tile_n = blockIdx.x, kbeg = 0, kend = g.K;
+  if (ksplit == 4) {
+    const int per = (((g.K + 3) / 4) + 7) & ~7;
+    kbeg = wave * per;
+    kend = min(g.K, kbeg + per);
+  } else {
+    tile_n = blockIdx.x * 4 + wave;
   }
+  const int i0 = blockIdx.y * 32, j0 = tile_n * 32;
+  const int i = i0 + l31, j = j0 + l31;
+  const bool iok = i < g.M, jok = j < g.N;
+  const float* ap = A + (int64_t)min(i, g.M - 1) * g.sai;
+  const float* bp = B + (int64_t)min(j, g.N - 1) * g.sbj;
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int i = i0 + ty * 2 + r;
-    if (i >= g.M) continue;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kb = kbeg; kb < kend; kb += 8) {  // wave-uniform bounds; 4 MFMAs (8 contraction values) per iteration
+    float av[4], bv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int j = j0 + tx * 4 + c;
-      if (j >= g.N) continue;
-      float v = acc[r][c];
-      if (g.bias[b]) v += g.bias[b][j];
-      float* dst = C + (int64_t)i * g.ldc + j;
-      *dst = g.beta != 0.f ? *dst * g.beta + v : v;
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + 2 * u + h;
+      const bool kok = k < kend;
+      av[u] = (iok && kok) ? ap[(int64_t)k * g.sak] : 0.f;
+      bv[u] = (jok && kok) ? bp[(int64_t)k * g.sbk] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+  if (ksplit == 4) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+  }
+  if (!jok) return;
+  const float bias = g.bias[b] ? g.bias[b][j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {  // lane holds column j, rows (r&3) + 8*(r>>2) + 4*h
+    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row >= g.M) continue;
+    float* dst = C + (int64_t)row * g.ldc + j;
+    const float v = acc[r] + bias;
+    *dst = g.beta != 0.f ? *dst * g.beta + v : v;
   }
 }
 
@@ -73,8 +78,10 @@ extern "C" int mmt_sgemm_batched(const MmtSgemm* g, void* stream) {
   if (!g || g->batch <= 0 || g->batch > MMT_MAX_EXPERTS || g->M <= 0 || g->N <= 0 || g->K <= 0) return MMT_ERR_ARG;
   for (int b = 0; b < g->batch; ++b)
     if (!g->A[b] || !g->B[b] || !g->C[b]) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(sgemm_batched_kernel, dim3((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, g->batch), dim3(256), 0,
-                     (hipStream_t)stream, *g);
+  const int ksplit = g->K >= 128 ? 4 : 1;
+  const int tiles_n = (g->N + 31) / 32;
+  hipLaunchKernelGGL(sgemm_batched_kernel, dim3(ksplit == 4 ? tiles_n : (tiles_n + 3) / 4, (g->M + 31) / 32, g->batch),
+                     dim3(256), 0, (hipStream_t)stream, *g, ksplit);
   return (int)hipGetLastError();
 }
 

@@ -79,6 +79,20 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
   return out
 
 
+def sgemm_batched(As, Bs, Cs, M, N, K, sai, sak, sbj, sbk, ldc, biases=None, beta=0.0):
+  """C_b[i][j] = beta*C_b[i][j] + sum_k A_b[i*sai + k*sak] * B_b[j*sbj + k*sbk] (+ bias_b[j]); fp32, exact-fp32 MFMA."""
+  from ._lib import MmtSgemm
+  _need_cuda(*As, *Bs, *Cs)
+  g = MmtSgemm()
+  g.batch, g.M, g.N, g.K = len(As), M, N, K
+  g.sai, g.sak, g.sbj, g.sbk, g.ldc, g.beta = sai, sak, sbj, sbk, ldc, beta
+  for i in range(len(As)):
+    g.A[i], g.B[i], g.C[i] = As[i].data_ptr(), Bs[i].data_ptr(), Cs[i].data_ptr()
+    g.bias[i] = biases[i].data_ptr() if biases is not None and biases[i] is not None else None
+  check(_lib.lib().mmt_sgemm_batched(ctypes.byref(g), _stream()), 'mmt_sgemm_batched')
+  return Cs
+
+
 def ln_fwd(z, gamma, beta, eps, rows=None, n_rows_dev=None, want_h32=True):
   _need_cuda(z)
   R, d = z.shape

@@ -96,6 +96,70 @@ def test_gemm_nt_fused_epilogues(tile):
   _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
 
 
+@pytest.mark.parametrize('tile', [3, 4, 5, 6])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (777, 512, 192), (7168, 1536, 512)])
+def test_gemm_nt_wide_tiles(tile, M, N, K):
+  """gemm2.hip (256x128 / 256x256 / 128x128 / 128x256 tiles, 32x32x16 MFMA, LDS-staged epilogue): every epilogue."""
+  from mmt_amd import ops
+  R = ops.pad_rows(M)
+  a = _rand((R, K), seed=21, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.1, seed=22, dtype=torch.bfloat16)
+  bias, res = _rand((N,), seed=23), _rand((R, N), seed=24)
+  ref = a[:M].float() @ b.float().t()
+  pre = torch.full((R, N), 7.0, device=_dev(), dtype=torch.bfloat16)
+  act = torch.zeros_like(pre)
+  ops.gemm_nt(a, b, pre, 'BIAS_GELU', m=M, bias=bias, out2=act, tile=tile)
+  _close('gelu.pre', pre[:M], ref + bias, 2e-2, 1e-2)
+  _close('gelu.act', act[:M], _gelu(pre[:M].float()), 1e-2, 1e-2)
+  assert bool((pre[M:] == 7.0).all())  # rows beyond M are never written
+  z = torch.zeros(R, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, z, 'BIAS_DROP_RES', m=M, bias=bias, res=res, tile=tile)
+  _close('drop_res(p=0)', z[:M], ref + bias + res[:M], 1e-3, 1e-4)
+  z1 = torch.zeros_like(z)
+  ops.gemm_nt(a, b, z, 'BIAS_DROP_RES', m=M, bias=bias, res=res, drop_key=77, drop_p=0.1, tile=tile)
+  ops.gemm_nt(a, b, z1, 'BIAS_DROP_RES', m=M, bias=bias, res=res, drop_key=77, drop_p=0.1, tile=2)
+  _close('dropout mask identical across tile shapes', z[:M], z1[:M], 1e-3, 1e-4)
+  ops.gemm_nt(a, b, z, 'ADD_F32', m=M, res=res, tile=tile)
+  _close('add_f32', z[:M], ref + res[:M], 1e-3, 1e-4)
+  ops.gemm_nt(a, b, z, 'BIAS_F32', m=M, bias=bias, tile=tile)
+  _close('bias_f32', z[:M], ref + bias, 1e-3, 1e-4)
+  ops.gemm_nt(a, b, pre, 'BF16', m=M, tile=tile)
+  _close('bf16', pre[:M], ref, 2e-2, 1e-2)
+  aux = _rand((R, N), seed=25, dtype=torch.bfloat16)
+  live = torch.tensor([M - 37], device=_dev(), dtype=torch.int32)
+  colsum = torch.zeros((M + 127) // 128, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, b, pre, 'DGELU', m=M, aux=aux, colsum=colsum, n_rows_dev=live, tile=tile)
+  x = aux[:M].float().requires_grad_(True)
+  _gelu(x).sum().backward()
+  _close('dgelu', pre[:M - 37], (ref * x.grad)[:M - 37], 3e-2, 1.5e-2)
+  _close('dgelu.colsum (live rows only)', colsum.sum(0), pre[:M - 37].float().sum(0), 2e-2, 2e-4)
+
+
+@pytest.mark.parametrize('batch,M,N,K,trans', [(3, 6, 256, 768, False), (7, 32, 512, 512, False), (2, 300, 130, 6, True),
+                                               (1, 33, 96, 1000, True)])
+def test_sgemm_batched(batch, M, N, K, trans):
+  """fp32 MFMA batched GEMM with generic strides (text heads): C = beta*C + A.B^T + bias."""
+  from mmt_amd import ops
+  As, Bs, Cs, refs, biases = [], [], [], [], []
+  for i in range(batch):
+    if trans:  # contraction index is the slow one (weight-gradient form)
+      a, b = _rand((K, M), seed=30 + i), _rand((K, N), seed=40 + i)
+      A, B = a.t(), b.t()
+    else:
+      a, b = _rand((M, K), seed=30 + i), _rand((N, K), seed=40 + i)
+      A, B = a, b
+    bias = _rand((N,), seed=50 + i)
+    c = _rand((M, N), seed=60 + i)
+    refs.append(0.5 * c.double() + A.double() @ B.double().t() + bias.double())
+    As.append(a); Bs.append(b); Cs.append(c); biases.append(bias)
+  if trans:
+    ops.sgemm_batched(As, Bs, Cs, M, N, K, 1, M, 1, N, N, biases, beta=0.5)
+  else:
+    ops.sgemm_batched(As, Bs, Cs, M, N, K, K, 1, K, 1, N, biases, beta=0.5)
+  for c, r in zip(Cs, refs):
+    _close('sgemm', c, r.float(), 1e-4 * math.sqrt(K), 1e-5)
+
+
 def test_gemm_nt_live_rows_and_colsum_mask():
   from mmt_amd import ops
   M, N, K = 512, 128, 64
