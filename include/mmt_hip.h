@@ -81,6 +81,27 @@ int mmt_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
 int mmt_reduce_slabs(const float* ws, int splits, int64_t count, float* out, int accumulate,
                      void* stream);
 
+/* Grouped weight gradients: for every item, out[N_out, K2_out] = sum_rows A[rows,N]^T . B[rows,K2] written
+ * directly as fp32 (no split-K slabs), and bias_out[n] = sum_rows A[rows, n] (nullable) -- all items in ONE
+ * launch, one 128x128 tile per block.  Replaces autograd's weight AND bias gradients of the four nn.Linear of a
+ * BertLayer (bert.py:137-139,186,218,234) resp. of all ReduceDim.fc (model.py:724).  N % 128 == 0, K2 % 128 == 0
+ * (operands padded); N_out / K2_out / ldo (0 = N / K2 / K2_out) un-pad the stored result. */
+#define MMT_WGRAD_MAX 16
+typedef struct MmtWgradItem {
+  const void* A;   /* bf16 [rows, lda] : dY                                                          */
+  const void* B;   /* bf16 [rows, ldb] : X                                                           */
+  float* out;      /* fp32 [N_out, ldo]                                                              */
+  float* bias_out; /* fp32 [N_out] or NULL                                                           */
+  int64_t lda, ldb, ldo;
+  int32_t N, K2, N_out, K2_out, tile_begin, reserved;
+} MmtWgradItem;
+typedef struct MmtWgradGroup {
+  MmtWgradItem item[MMT_WGRAD_MAX];
+  const int32_t* n_rows_dev; /* nullable live row count on device                                    */
+  int32_t count, rows;
+} MmtWgradGroup;
+int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream);
+
 /* out[i] (+)= sum_s ws[s][i] over a [rows, cols_ws] slab keeping only the first cols_out columns
  * (un-pads the K-padded ReduceDim weight gradients). */
 int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int cols_ws, int cols_out, float* out,

@@ -24,6 +24,16 @@ class MmtPackItem(ctypes.Structure):
               ('reserved', ctypes.c_int32)]
 
 
+class MmtWgradItem(ctypes.Structure):
+  _fields_ = [('A', c_vp), ('B', c_vp), ('out', c_vp), ('bias_out', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldo', c_i64),
+              ('N', ctypes.c_int32), ('K2', ctypes.c_int32), ('N_out', ctypes.c_int32), ('K2_out', ctypes.c_int32),
+              ('tile_begin', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class MmtWgradGroup(ctypes.Structure):
+  _fields_ = [('item', MmtWgradItem * 16), ('n_rows_dev', c_vp), ('count', ctypes.c_int32), ('rows', ctypes.c_int32)]
+
+
 class MmtExpertIO(ctypes.Structure):
   _fields_ = [('feat', c_vp), ('maxpool', c_vp), ('ind', c_vp), ('t', c_vp), ('x', c_vp), ('y', c_vp), ('dy', c_vp),
               ('D', ctypes.c_int32), ('Dpad', ctypes.c_int32), ('type_idx', ctypes.c_int32),
@@ -81,6 +91,7 @@ SIGNATURES = {
     'mmt_gemm_nt_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
     'mmt_gemm_tn_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_wgrad_grouped': (c_int, [ctypes.POINTER(MmtWgradGroup), c_vp]),
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,

@@ -19,21 +19,12 @@ struct Ws {
   float *z0, *mean0, *rstd0, *h32_in;
   char* h16_in;
   LayerWs layer[64];
-  float *dz, *dA, *delta, *ln_partials, *col_partials, *slabs, *table_scratch;
-  char *dy, *dhpre, *dctx, *dqkv;
+  float *dz, *dA, *delta, *ln_partials, *table_scratch;
+  char *dy, *dy2, *dhpre, *dctx, *dqkv;
   size_t bytes;
 };
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-
-int tn_splits(int N, int K2, int rows) {
-  const int tiles = (N / 128) * (K2 / 128);
-  int s = (384 + tiles - 1) / tiles;
-  const int ktiles = (rows + 63) / 64;
-  if (s > ktiles) s = ktiles;
-  if (s > 16) s = 16;
-  return s < 1 ? 1 : s;
-}
 
 void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   const size_t d = m->hidden, I = m->inter, H = m->heads;
@@ -51,21 +42,10 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     L.h32 = (float*)take(R * d * 4); L.h16 = take(R * d * 2);
   }
   w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
-  w->dy = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
+  w->dy = take(R * d * 2); w->dy2 = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
   w->delta = (float*)take(R * H * 4);
   const size_t rpb = (size_t)mmt_ln_bwd_rows_per_block();
   w->ln_partials = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
-  size_t cp = (size_t)((R + 31) / 32) * 3 * d;            // colsum of dqkv
-  const size_t cp2 = (size_t)((R + 127) / 128) * I;       // DGELU epilogue column sums
-  if (cp2 > cp) cp = cp2;
-  w->col_partials = (float*)take(cp * 4);
-  size_t slab = 0;
-  const int shapes[4][2] = {{(int)(3 * d), (int)d}, {(int)d, (int)d}, {(int)I, (int)d}, {(int)d, (int)I}};
-  for (auto& s : shapes) {
-    const size_t need = (size_t)tn_splits(s[0], s[1], R) * s[0] * s[1];
-    if (need > slab) slab = need;
-  }
-  w->slabs = (float*)take(slab * 4);
   const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
   w->table_scratch = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
   w->bytes = off;
@@ -88,13 +68,6 @@ hipEvent_t* g_probe_stop = nullptr;
 int g_probe_n = 0, g_probe_i = 0;
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-
-int wgrad(const void* A, int N, const void* B, int K2, int rows, float* slabs, float* out, const int32_t* nr,
-          void* stream) {
-  const int splits = tn_splits(N, K2, rows);
-  TRY(mmt_gemm_tn_bf16(A, N, B, K2, slabs, rows, N, K2, splits, nr, stream));
-  return mmt_reduce_slabs(slabs, splits, (int64_t)N * K2, out, 0, stream);
-}
 
 }  // namespace
 
@@ -181,37 +154,44 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
     // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
-    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy, w.ln_partials, rows, d, 1, nr, b->row_index,
+    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy2, w.ln_partials, rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
-    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln2_g, P.g_ln2_b, P.g_b2, nullptr, 0, stream));
-    TRY(wgrad(w.dy, d, L.g, I, rows, w.slabs, P.g_w2, nr, stream));
+    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln2_g, P.g_ln2_b, nullptr, nullptr, 0, stream));
     MmtEpilogue e = {};
-    e.aux = L.hpre; e.ldaux = I; e.colsum = w.col_partials;
-    TRY(mmt_gemm_nt_bf16(w.dy, d, P.w2_t, d, w.dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
-    TRY(mmt_col_reduce(w.col_partials, (rows + 127) / 128, 1, I, P.g_b1, nullptr, nullptr, nullptr, 0, stream));
+    e.aux = L.hpre; e.ldaux = I;
+    TRY(mmt_gemm_nt_bf16(w.dy2, d, P.w2_t, d, w.dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
     // --- BertIntermediate: dense(d->I) ---
-    TRY(wgrad(w.dhpre, I, L.a16, d, rows, w.slabs, P.g_w1, nr, stream));
     e = {};
     e.res = w.dz; e.ldres = d;
     TRY(mmt_gemm_nt_bf16(w.dhpre, I, P.w1_t, I, w.dA, d, rows, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
     TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials, rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
-    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln1_g, P.g_ln1_b, P.g_bo, nullptr, 0, stream));
-    TRY(wgrad(w.dy, d, L.ctx, d, rows, w.slabs, P.g_wo, nr, stream));
+    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln1_g, P.g_ln1_b, nullptr, nullptr, 0, stream));
     e = {};
     TRY(mmt_gemm_nt_bf16(w.dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
     TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, w.dqkv, w.delta, b->batch, b->seq,
                      m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
-    TRY(mmt_colsum_bf16(w.dqkv, 3 * d, rows, 3 * d, nr, w.col_partials, stream));
-    TRY(mmt_col_reduce(w.col_partials, (rows + 31) / 32, 1, 3 * d, P.g_bqkv, nullptr, nullptr, nullptr, 0, stream));
-    TRY(wgrad(w.dqkv, 3 * d, hin16, d, rows, w.slabs, P.g_wqkv, nr, stream));
     e = {};
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.
     TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+    // --- all four weight gradients + bias gradients of the layer: ONE grouped launch (256 tiles at d=512, I=3072) ---
+    {
+      MmtWgradGroup g = {};
+      g.count = 4; g.rows = rows; g.n_rows_dev = nr;
+      g.item[0].A = w.dhpre; g.item[0].lda = I;     g.item[0].B = L.a16; g.item[0].ldb = d; g.item[0].N = I;     g.item[0].K2 = d;
+      g.item[0].out = P.g_w1;   g.item[0].bias_out = P.g_b1;
+      g.item[1].A = w.dy2;   g.item[1].lda = d;     g.item[1].B = L.g;   g.item[1].ldb = I; g.item[1].N = d;     g.item[1].K2 = I;
+      g.item[1].out = P.g_w2;   g.item[1].bias_out = P.g_b2;
+      g.item[2].A = w.dqkv;  g.item[2].lda = 3 * d; g.item[2].B = hin16; g.item[2].ldb = d; g.item[2].N = 3 * d; g.item[2].K2 = d;
+      g.item[2].out = P.g_wqkv; g.item[2].bias_out = P.g_bqkv;
+      g.item[3].A = w.dy;    g.item[3].lda = d;     g.item[3].B = L.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
+      g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo;
+      TRY(mmt_wgrad_grouped(&g, stream));
+    }
     dcur = dnext;
   }
   // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---

@@ -285,6 +285,128 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped weight gradients: every weight (and bias) gradient of one encoder layer -- or of all ReduceDim
+// experts -- in ONE launch.  Each block owns one 128x128 tile of one dW and contracts over ALL live rows, so
+// there are no split-K slabs and no reduce kernels; with d=512, I=3072 a layer has exactly
+// 48 + 16 + 96 + 96 = 256 tiles = one per CU.  Tiles in the first tile-column also produce the bias gradient
+// (column sums of the bf16 dY operand) with one extra MFMA per fragment against an all-ones operand.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(MmtWgradGroup g) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128];
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < g.count; ++q)
+    if (id >= g.item[q].tile_begin) p = q;
+  const MmtWgradItem& it = g.item[p];
+  const bf16_t* __restrict__ A = (const bf16_t*)it.A;
+  const bf16_t* __restrict__ B = (const bf16_t*)it.B;
+  const int64_t lda = it.lda, ldb = it.ldb;
+  const int tile = id - it.tile_begin;
+  const int tiles_k = it.K2 / 128;
+  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int nrows = g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows;
+  const int ktiles = (nrows + 63) / 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const bool want_bias = it.bias_out != nullptr && tk == 0 && wn == 0;
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  constexpr int TSTAGE = 2 * 64 * 128;
+
+  if (ktiles > 0) {
+    stage_tn(A, lda, 0, n0, smem, wave, lane);
+    stage_tn(B, ldb, 0, k0, smem + 64 * 128, wave, lane);
+  }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < ktiles) {
+      stage_tn(A, lda, (kt + 1) * 64, n0, smem + (cur ^ 1) * TSTAGE, wave, lane);
+      stage_tn(B, ldb, (kt + 1) * 64, k0, smem + (cur ^ 1) * TSTAGE + 64 * 128, wave, lane);
+    }
+    bf16_t* at = smem + cur * TSTAGE;
+    bf16_t* bt = at + 64 * 128;
+    const int live = nrows - kt * 64;
+    if (live < 64) {  // ragged tail: zero the dead rows of both operands
+      for (int e = tid; e < (64 - live) * 32; e += 256) {
+        const int r = live + e / 32, q = e % 32;
+        u32x4 z = {0, 0, 0, 0};
+        if (q < 16) *(u32x4*)(at + r * 128 + q * 8) = z;
+        else *(u32x4*)(bt + r * 128 + (q - 16) * 8) = z;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_frag(at, ks, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(bt, ks, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+      }
+    }
+  }
+  float* __restrict__ out = it.out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wm * 64 + i * 16 + li;
+    if (n >= it.N_out) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k2 = k0 + wn * 64 + j * 16 + lg * 4;
+      if (k2 + 3 < it.K2_out && !(it.ldo & 3)) {
+        *(f32x4*)(out + (int64_t)n * it.ldo + k2) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k2 + e < it.K2_out) out[(int64_t)n * it.ldo + k2 + e] = acc[i][j][e];
+      }
+    }
+    if (want_bias && lg == 0) it.bias_out[n] = accb[i][0];
+  }
+}
+
+extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
+  if (!g || g->count <= 0 || g->count > MMT_WGRAD_MAX || g->rows <= 0) return MMT_ERR_ARG;
+  MmtWgradGroup h = *g;
+  int tiles = 0;
+  for (int q = 0; q < h.count; ++q) {
+    MmtWgradItem& it = h.item[q];
+    if (!it.A || !it.B || !it.out || it.N <= 0 || it.K2 <= 0 || it.N % 128 || it.K2 % 128) return MMT_ERR_ARG;
+    if ((it.lda % 8) || (it.ldb % 8) || ((uintptr_t)it.A & 15) || ((uintptr_t)it.B & 15) || ((uintptr_t)it.out & 15))
+      return MMT_ERR_ALIGN;
+    if (it.N_out <= 0 || it.N_out > it.N) it.N_out = it.N;
+    if (it.K2_out <= 0 || it.K2_out > it.K2) it.K2_out = it.K2;
+    if (it.ldo <= 0) it.ldo = it.K2_out;
+    it.tile_begin = tiles;
+    tiles += (it.N / 128) * (it.K2 / 128);
+  }
+  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, h);
+  return (int)hipGetLastError();
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, int splits, int64_t count4,
                                     float* __restrict__ out, int accumulate) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count4;

@@ -173,21 +173,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 // out[j][c] (+)= sum_b partials[b][j][c]   (j < nvec).  Block = 64 columns x 4 row-groups; each thread sums
 // a strided quarter of the blocks, then a fixed-order LDS combine => deterministic.
 struct ColOuts { float* p[4]; };
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ partials, int nblocks, int nvec, int d,
-                                                         ColOuts outs, int accumulate) {
-  __shared__ float red[4][64];
+#define CR_RG 16
+__global__ __launch_bounds__(64 * CR_RG) void col_reduce_kernel(const float* __restrict__ partials, int nblocks, int nvec,
+                                                                int d, ColOuts outs, int accumulate) {
+  __shared__ float red[CR_RG][64];
   const int chunks = (d + 63) / 64;
   const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   float* out = outs.p[j];
   float s = 0.f;
   if (out && c < d)
-    for (int b = rg; b < nblocks; b += 4) s += partials[((int64_t)b * nvec + j) * d + c];
+    for (int b = rg; b < nblocks; b += CR_RG) s += partials[((int64_t)b * nvec + j) * d + c];
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
   if (rg == 0 && out && c < d) {
     const int t = threadIdx.x;
-    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CR_RG; ++g) v += red[g][t];
     out[c] = accumulate ? out[c] + v : v;
   }
 }
@@ -249,7 +252,7 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_ln_bwd_rows_per_block(void) { return 32; }
+extern "C" int mmt_ln_bwd_rows_per_block(void) { return 16; }
 
 extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
                           const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
@@ -258,7 +261,7 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
                           void* stream) {
   if (!dout || !z || !mean || !rstd || !gamma || !partials || rows <= 0) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
-  const int rpb = 32, grid = (rows + rpb - 1) / rpb;
+  const int rpb = 16, grid = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(MODE)                                                                            \
   hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), 0, s, dout, z, mean, rstd, gamma, dz, \
@@ -275,7 +278,7 @@ extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int 
                               float* out2, float* out3, int accumulate, void* stream) {
   if (!partials || nblocks <= 0 || nvec <= 0 || nvec > 4 || d <= 0) return MMT_ERR_ARG;
   ColOuts outs = {{out0, out1, out2, out3}};
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(nvec * ((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partials,
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(nvec * ((d + 63) / 64)), dim3(64 * CR_RG), 0, (hipStream_t)stream, partials,
                      nblocks, nvec, d, outs, accumulate);
   return (int)hipGetLastError();
 }
@@ -290,7 +293,7 @@ extern "C" int mmt_table_grad(const float* g, const int32_t* ids, int rows, int 
                      rows, d, vocab, n_rows_dev, scratch);
   ColOuts outs = {{dtable, nullptr, nullptr, nullptr}};
   const int n = vocab * d;
-  hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, TABLE_CHUNKS, 1,
+  hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 63) / 64), dim3(64 * CR_RG), 0, (hipStream_t)stream, scratch, TABLE_CHUNKS, 1,
                      n, outs, accumulate);
   return (int)hipGetLastError();
 }

@@ -396,23 +396,13 @@ class CENet(nn.Module):
     check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(dfeat), stream),
           'mmt_video_scatter_bwd')
     grad_buf = self._flat.current_grad()
-    grads = []
-    nblk = (plan.src_rows + 31) // 32
-    partials = torch.empty(nblk, d, device=dfeat.device, dtype=torch.float32)
-    for mod in self.modalities:
+    grads, items = [], []
+    for mod in self.modalities:  # every ReduceDim weight + bias gradient in ONE grouped launch
       fc = self.video_dim_reduce[mod].fc
-      dim, dpad = self.expert_dims[mod]['dim'], plan.x[mod].shape[1]
-      splits = max(1, min(8, plan.src_rows // 64))
-      slabs = torch.empty(splits, d, dpad, device=dfeat.device, dtype=torch.float32)
-      check(L.mmt_gemm_tn_bf16(ops._p(plan.dy[mod]), d, ops._p(plan.x[mod]), dpad, ops._p(slabs), plan.src_rows, d,
-                               dpad, splits, None, stream), 'mmt_gemm_tn_bf16')
-      gw = self._flat.view(fc.weight, grad_buf)
-      check(L.mmt_reduce_slabs_2d(ops._p(slabs), splits, d, dpad, dim, ops._p(gw), 0, stream), 'mmt_reduce_slabs_2d')
-      check(L.mmt_colsum_bf16(ops._p(plan.dy[mod]), d, plan.src_rows, d, None, ops._p(partials), stream),
-            'mmt_colsum_bf16')
-      gb = self._flat.view(fc.bias, grad_buf)
-      check(L.mmt_col_reduce(ops._p(partials), nblk, 1, d, ops._p(gb), None, None, None, 0, stream), 'mmt_col_reduce')
+      gw, gb = self._flat.view(fc.weight, grad_buf), self._flat.view(fc.bias, grad_buf)
+      items.append((plan.dy[mod], plan.x[mod], gw, gb))
       grads += [gw if fc.weight.requires_grad else None, gb if fc.bias.requires_grad else None]
+    ops.wgrad_grouped(items, plan.src_rows)
     return grads
 
   def video_embeddings(self, features, features_t, features_ind, features_maxpool):

@@ -79,6 +79,23 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
   return out
 
 
+def wgrad_grouped(items, rows, n_rows_dev=None):
+  """items: list of (a [rows,N] bf16, b [rows,K2] bf16, out fp32 [N_out,K2_out], bias_out fp32 [N_out] or None).
+  One launch: out = a^T @ b (fp32), bias_out = column sums of a."""
+  from ._lib import MmtWgradGroup
+  g = MmtWgradGroup()
+  g.count, g.rows = len(items), rows
+  g.n_rows_dev = n_rows_dev.data_ptr() if n_rows_dev is not None else None
+  for i, (a, b, out, bias) in enumerate(items):
+    _need_cuda(a, b, out)
+    it = g.item[i]
+    it.A, it.B, it.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    it.bias_out = bias.data_ptr() if bias is not None else None
+    it.lda, it.ldb, it.ldo = a.stride(0), b.stride(0), out.stride(0)
+    it.N, it.K2, it.N_out, it.K2_out = a.shape[1], b.shape[1], out.shape[0], out.shape[1]
+  check(_lib.lib().mmt_wgrad_grouped(ctypes.byref(g), _stream()), 'mmt_wgrad_grouped')
+
+
 def sgemm_batched(As, Bs, Cs, M, N, K, sai, sak, sbj, sbk, ldc, biases=None, beta=0.0):
   """C_b[i][j] = beta*C_b[i][j] + sum_k A_b[i*sai + k*sak] * B_b[j*sbj + k*sbk] (+ bias_b[j]); fp32, exact-fp32 MFMA."""
   from ._lib import MmtSgemm

@@ -193,6 +193,32 @@ def test_gemm_tn_weight_gradient(rows, N, K2, splits, live):
   _close('tn accumulate', acc, ref + 1.0, 2e-3 * math.sqrt(n / 256.0), 2e-4)
 
 
+@pytest.mark.parametrize('live', [None, 333])
+def test_wgrad_grouped(live):
+  """One launch for several dW = dY^T X (+ bias gradient = column sums of dY), incl. an un-padded output."""
+  from mmt_amd import ops
+  rows = 512
+  shapes = [(256, 128, 128, 128), (128, 384, 128, 300), (384, 128, 384, 128)]  # (N, K2, N_out, K2_out)
+  items, refs = [], []
+  for i, (N, K2, n_out, k_out) in enumerate(shapes):
+    a = _rand((rows, N), seed=70 + i, dtype=torch.bfloat16)
+    b = _rand((rows, K2), 0.1, seed=80 + i, dtype=torch.bfloat16)
+    if live is not None:  # garbage beyond the live rows must not leak in
+      a[live:] = float('nan')
+      b[live:] = float('nan')
+    n = rows if live is None else live
+    out = torch.full((n_out, k_out), 5.0, device=_dev())
+    bias = torch.full((n_out,), 5.0, device=_dev()) if i != 2 else None
+    items.append((a, b, out, bias))
+    refs.append(((a[:n].float().t() @ b[:n].float())[:n_out, :k_out], a[:n].float().sum(0)[:n_out]))
+  nr = None if live is None else torch.tensor([live], device=_dev(), dtype=torch.int32)
+  ops.wgrad_grouped(items, rows, n_rows_dev=nr)
+  for (a, b, out, bias), (rw, rb) in zip(items, refs):
+    _close('wgrad', out, rw, 4e-3, 2e-4)
+    if bias is not None:
+      _close('bias grad', bias, rb, 1e-3, 1e-5)
+
+
 @pytest.mark.parametrize('d', [256, 512, 1024])
 def test_layernorm_fwd_bwd(d):
   from mmt_amd import ops
