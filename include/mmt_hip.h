@@ -131,11 +131,24 @@ int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float
 /* out_j[c] (+)= sum_b partials[b][j][c], j < nvec <= 4 (NULL outputs are skipped); fixed order. */
 int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,
                    float* out2, float* out3, int accumulate, void* stream);
+/* Batched form: every job j writes out[k][c] = sum_b partials[b][k][c] (k < nout <= nvec) in ONE launch. */
+#define MMT_COLRED_MAX 32
+typedef struct MmtColReduceJob {
+  const float* partials; /* [nblocks][nvec][d]                                                      */
+  float* out[4];         /* nout outputs of d floats each (NULL entries are skipped)                */
+  int32_t nblocks, nvec, nout, d;
+} MmtColReduceJob;
+int mmt_col_reduce_multi(const MmtColReduceJob* jobs, int n, void* stream);
 /* dtable[v] (+)= sum of g[row] over rows with ids[row] == v: gradient of nn.Embedding (bert.py:78-81)
  * as a deterministic segmented sum (no atomics); scratch = mmt_table_grad_scratch_floats() floats. */
 int64_t mmt_table_grad_scratch_floats(int vocab, int d);
 int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int vocab,
                    const int32_t* n_rows_dev, float* scratch, float* dtable, int accumulate, void* stream);
+/* The two halves of mmt_table_grad: chunk partials [mmt_table_grad_chunks()][vocab*d] into `scratch`, to be summed
+ * by mmt_col_reduce / mmt_col_reduce_multi (nvec = 1, d = vocab*d). */
+int mmt_table_grad_partials(const float* g, const int32_t* ids, int rows, int d, int vocab,
+                            const int32_t* n_rows_dev, float* scratch, void* stream);
+int mmt_table_grad_chunks(void);
 /* partials[blk][c] = column sums of a bf16 matrix over 32-row blocks (bias gradients). */
 int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t* n_rows_dev,
                     float* partials, void* stream);

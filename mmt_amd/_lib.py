@@ -34,6 +34,11 @@ class MmtWgradGroup(ctypes.Structure):
   _fields_ = [('item', MmtWgradItem * 16), ('n_rows_dev', c_vp), ('count', ctypes.c_int32), ('rows', ctypes.c_int32)]
 
 
+class MmtColReduceJob(ctypes.Structure):
+  _fields_ = [('partials', c_vp), ('out', c_vp * 4), ('nblocks', ctypes.c_int32), ('nvec', ctypes.c_int32),
+              ('nout', ctypes.c_int32), ('d', ctypes.c_int32)]
+
+
 class MmtExpertIO(ctypes.Structure):
   _fields_ = [('feat', c_vp), ('maxpool', c_vp), ('ind', c_vp), ('t', c_vp), ('x', c_vp), ('y', c_vp), ('dy', c_vp),
               ('D', ctypes.c_int32), ('Dpad', ctypes.c_int32), ('type_idx', ctypes.c_int32),
@@ -100,6 +105,9 @@ SIGNATURES = {
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                            c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'mmt_col_reduce_multi': (c_int, [ctypes.POINTER(MmtColReduceJob), c_int, c_vp]),
+    'mmt_table_grad_partials': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_table_grad_chunks': (c_int, []),
     'mmt_table_grad_scratch_floats': (c_i64, [c_int, c_int]),
     'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mmt_attn_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,

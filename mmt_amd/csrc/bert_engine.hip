@@ -19,7 +19,7 @@ struct Ws {
   float *z0, *mean0, *rstd0, *h32_in;
   char* h16_in;
   LayerWs layer[64];
-  float *dz, *dA, *delta, *ln_partials, *table_scratch;
+  float *dz, *dA, *delta, *ln_partials[2 * 64 + 1], *table_scratch[2];
   char *dy, *dy2, *dhpre, *dctx, *dqkv;
   size_t bytes;
 };
@@ -45,9 +45,9 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   w->dy = take(R * d * 2); w->dy2 = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
   w->delta = (float*)take(R * H * 4);
   const size_t rpb = (size_t)mmt_ln_bwd_rows_per_block();
-  w->ln_partials = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
+  for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
   const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
-  w->table_scratch = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
+  for (int i = 0; i < 2; ++i) w->table_scratch[i] = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
   w->bytes = off;
 }
 
@@ -148,15 +148,23 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
   const int ln_blocks = (rows + rpb - 1) / rpb;
   const int32_t* nr = b->n_rows_dev;
 
+  // LayerNorm gamma/beta and embedding-table partial sums stay in per-site buffers; ONE batched reduction at the end
+  MmtColReduceJob jobs[2 * 64 + 3];
+  int njobs = 0;
+  auto add_job = [&](const float* partials, int nblocks, int nvec, int nout, int dd, float* o0, float* o1) {
+    MmtColReduceJob& j = jobs[njobs++];
+    j = {};
+    j.partials = partials; j.nblocks = nblocks; j.nvec = nvec; j.nout = nout; j.d = dd; j.out[0] = o0; j.out[1] = o1;
+  };
   float* dcur = dlast;  // gradient wrt the current layer's output
   for (int l = m->layers - 1; l >= 0; --l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
     // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
-    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy2, w.ln_partials, rows, d, 1, nr, b->row_index,
+    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
-    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln2_g, P.g_ln2_b, nullptr, nullptr, 0, stream));
+    add_job(w.ln_partials[2 * l + 2], ln_blocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
     MmtEpilogue e = {};
     e.aux = L.hpre; e.ldaux = I;
     TRY(mmt_gemm_nt_bf16(w.dy2, d, P.w2_t, d, w.dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
@@ -165,9 +173,9 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     e.res = w.dz; e.ldres = d;
     TRY(mmt_gemm_nt_bf16(w.dhpre, I, P.w1_t, I, w.dA, d, rows, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
-    TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials, rows, d, 1, nr, b->row_index,
+    TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
-    TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, P.g_ln1_g, P.g_ln1_b, nullptr, nullptr, 0, stream));
+    add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
     e = {};
     TRY(mmt_gemm_nt_bf16(w.dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
@@ -195,10 +203,15 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     dcur = dnext;
   }
   // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---
-  TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials, rows, d, 2, nr,
+  TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials[0], rows, d, 2, nr,
                  b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
-  TRY(mmt_col_reduce(w.ln_partials, ln_blocks, 3, d, m->g_emb_ln_g, m->g_emb_ln_b, nullptr, nullptr, 0, stream));
-  TRY(mmt_table_grad(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch, m->g_type_emb, 0, stream));
-  if (b->pos_ids) TRY(mmt_table_grad(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch, m->g_pos_emb, 0, stream));
-  return 0;
+  add_job(w.ln_partials[0], ln_blocks, 3, 2, d, m->g_emb_ln_g, m->g_emb_ln_b);
+  const int chunks = mmt_table_grad_chunks();
+  TRY(mmt_table_grad_partials(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch[0], stream));
+  add_job(w.table_scratch[0], chunks, 1, 1, m->type_vocab * d, m->g_type_emb, nullptr);
+  if (b->pos_ids) {
+    TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], stream));
+    add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
+  }
+  return mmt_col_reduce_multi(jobs, njobs, stream);
 }

@@ -434,11 +434,13 @@ int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const
 template <int EPI>
 static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-  // 128x128 when it still yields >= 2 tiles per CU or N is wide; otherwise 128x64 for more blocks.
+  // Measured on MI355X (tools/gemm_lab.py, profiles/r01_gemm_lab.txt): wide outputs (N >= 1024: QKV, FFN up-projection,
+  // dGELU) run best on gemm2's 128x128 tile (32x32x16 MFMA, coalesced LDS-staged epilogue); the N = 512 GEMMs have
+  // too few 128x128 tiles for 256 CUs and stay on the 128x64 tile.  reserved: 1/2 force the gemm.hip tiles, >= 3 gemm2.
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  const long t128 = (long)((M + 127) / 128) * (N / 128);
-  const bool want128 = e.reserved == 1 || (e.reserved == 0 && t128 >= 512);  // reserved: 1/2 force a tile (tests)
-  if (N % 128 == 0 && want128) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (e.reserved == 0 && N >= 1024 && N % 128 == 0 && M >= 512)
+    return mmt_gemm2_dispatch(5, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (N % 128 == 0 && e.reserved == 1) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   return launch_nt<128, 64, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
 }
 

@@ -58,7 +58,12 @@ __device__ __forceinline__ void stage2(const bf16_t* __restrict__ G, int64_t ld,
   }
 }
 
-template <int BM, int BN, int WGN, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WGN, int NS, int EPI>
 __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
@@ -76,7 +81,6 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   const int m0 = tm * BM, n0 = tn * BN;
   const int nrows = n_rows_dev ? *n_rows_dev : M;
   const int tid = threadIdx.x;
-  const int dbg = epi.reserved >> 8;  // lab only: 1 = no loads in the K-loop, 2 = no MFMA, 4 = no global stores, 8 = no epilogue
   if (m0 >= nrows) {  // dead tile (variable-length packing)
     if constexpr (EPI == MMT_EPI_DGELU) {
       if (epi.colsum)
@@ -98,21 +102,33 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   constexpr int STAGE = (BM + BN) * BK;
+  constexpr int L = (BM + BN) / 8 / NW;  // LDS-DMA instructions per wave per stage
   const int KT = K / BK;
   const int amax = M - 1, bmax = N - 1;
-  stage2<BM, NW>(A, lda, m0, amax, 0, smem, wave, lane);
-  stage2<BN, NW>(B, ldb, n0, bmax, 0, smem + BM * BK, wave, lane);
+  // NS-deep LDS ring, counted vmcnt: stage kt+NS-1 is issued while stage kt is consumed and the DMA queue is never
+  // drained inside the loop (raw s_barrier -- __syncthreads() would add vmcnt(0), cdna guide section 5).
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < KT) {
+      stage2<BM, NW>(A, lda, m0, amax, s0 * BK, smem + s0 * STAGE, wave, lane);
+      stage2<BN, NW>(B, ldb, n0, bmax, s0 * BK, smem + s0 * STAGE + BM * BK, wave, lane);
+    }
+  int cur = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < KT && !(dbg & 1)) {
-      stage2<BM, NW>(A, lda, m0, amax, (kt + 1) * BK, smem + (cur ^ 1) * STAGE, wave, lane);
-      stage2<BN, NW>(B, ldb, n0, bmax, (kt + 1) * BK, smem + (cur ^ 1) * STAGE + BM * BK, wave, lane);
+    const int ahead = min(KT - kt - 1, NS - 2);  // stages issued after kt that may stay in flight
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < KT) {
+      int nxt = cur + NS - 1;
+      if (nxt >= NS) nxt -= NS;
+      stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
+      stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
     const bf16_t* as = smem + cur * STAGE;
     const bf16_t* bs = as + BM * BK;
-    if (dbg & 2) continue;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = kk * 2 + lh;
@@ -133,6 +149,7 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
   // ---- epilogue: 64 rows at a time through a row-major fp32 LDS image -------------------------------
@@ -148,15 +165,6 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // every wave is done with the stage buffers
-  if (dbg & 8) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-    return;
-  }
 #pragma unroll
   for (int ch = 0; ch < WGM; ++ch) {
     if (wm == ch) {
@@ -175,7 +183,7 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
     for (int r0 = 0; r0 < 64; r0 += RG) {
       const int r = r0 + rg;
       const int row = m0 + ch * 64 + r;
-      if (row < M && !(dbg & 4)) {
+      if (row < M) {
         f32x4 v = *(const f32x4*)(st + r * P + cg * 4);
         v += bias4;
         if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
@@ -237,23 +245,23 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   }
 }
 
-template <int BM, int BN, int WGN, int EPI>
+template <int BM, int BN, int WGN, int NS, int EPI>
 static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   constexpr int NT = (BM / 64) * WGN * 64;
   constexpr int RG = NT / (BN / 4);
-  constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * BK * 2;
+  constexpr size_t stage_bytes = (size_t)NS * (BM + BN) * BK * 2;
   constexpr size_t epi_bytes = (size_t)(64 * (BN + 4) + RG * BN) * 4;
   constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static bool configured = false;
   if (!configured) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGN, EPI>,
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGN, NS, EPI>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
   const int grid = ((M + BM - 1) / BM) * (N / BN);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGN, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGN, NS, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
@@ -261,12 +269,15 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
 template <int EPI>
 static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
                  int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+#define G2(BM_, BN_, WGN_, NS_) return launch2<BM_, BN_, WGN_, NS_, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s)
   switch (tile & 0xff) {
-    case 3: if (N % 128 == 0) return launch2<256, 128, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
-    case 4: if (N % 256 == 0) return launch2<256, 256, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
-    case 5: if (N % 128 == 0) return launch2<128, 128, 2, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
-    case 6: if (N % 256 == 0) return launch2<128, 256, 4, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s); break;
+    case 3: if (N % 128 == 0) G2(256, 128, 2, 3); break;
+    case 4: if (N % 256 == 0) G2(256, 256, 2, 2); break;
+    case 5: if (N % 128 == 0) G2(128, 128, 2, 2); break;
+    case 7: if (N % 64 == 0) G2(128, 64, 2, 3); break;
+    case 10: if (N % 128 == 0) G2(256, 128, 2, 2); break;
   }
+#undef G2
   return MMT_ERR_ARG;
 }
 

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows, int d, int rows_per_block,
     const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
     uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
-  __shared__ float red[4][3][MAXC * 256];
+  extern __shared__ __attribute__((aligned(16))) float red_raw[];  // [4 waves][3][d]
   const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
@@ -93,16 +93,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = dbias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(nrows, r_begin + rows_per_block);
+  // software prefetch: the next row's dout / z are in flight while the current row is reduced
+  f32x4 go_n[MAXC], zz_n[MAXC];
+  float mean_n = 0.f, rstd_n = 0.f;
+  int orow_n = 0;
+  auto fetch = [&](int row) {
+    mean_n = mean_in[row]; rstd_n = rstd_in[row];
+    orow_n = row_index ? row_index[row] : row;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < nch) {
+        const int col = c * 256 + lane * 4;
+        go_n[c] = *(const f32x4*)(dout + (int64_t)row * d + col);
+        zz_n[c] = *(const f32x4*)(z + (int64_t)row * d + col);
+      }
+  };
+  if (r_begin + wave < r_end) fetch(r_begin + wave);
   for (int row = r_begin + wave; row < r_end; row += 4) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const int orow = row_index ? row_index[row] : row;
-    f32x4 xh[MAXC], g[MAXC];
+    const float mean = mean_n, rstd = rstd_n;
+    const int orow = orow_n;
+    f32x4 xh[MAXC], g[MAXC], go_c[MAXC], zz_c[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { go_c[c] = go_n[c]; zz_c[c] = zz_n[c]; }
+    if (row + 4 < r_end) fetch(row + 4);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
       if (c < nch) {
         const int col = c * 256 + lane * 4;
-        f32x4 go = *(const f32x4*)(dout + (int64_t)row * d + col);
+        f32x4 go = go_c[c];
         if constexpr (DROP == 2) {
           if (thr16) {
             bool kp[4];
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
             for (int k = 0; k < 4; ++k) go[k] = kp[k] ? go[k] * drop_scale : 0.f;
           }
         }
-        const f32x4 zz = *(const f32x4*)(z + (int64_t)row * d + col);
+        const f32x4 zz = zz_c[c];
         const f32x4 gm = *(const f32x4*)(gamma + col);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -157,16 +176,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int col = c * 256 + lane * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        red[wave][0][col + k] = dg[c][k];
-        red[wave][1][col + k] = db[c][k];
-        red[wave][2][col + k] = dbias[c][k];
+        red_raw[(wave * 3 + 0) * d + col + k] = dg[c][k];
+        red_raw[(wave * 3 + 1) * d + col + k] = db[c][k];
+        red_raw[(wave * 3 + 2) * d + col + k] = dbias[c][k];
       }
     }
   __syncthreads();
   for (int e = threadIdx.x; e < 3 * d; e += 256) {
     const int which = e / d, col = e % d;
     partials[((int64_t)blockIdx.x * 3 + which) * d + col] =
-        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+        red_raw[(0 * 3 + which) * d + col] + red_raw[(1 * 3 + which) * d + col] + red_raw[(2 * 3 + which) * d + col] +
+        red_raw[(3 * 3 + which) * d + col];
   }
 }
 
@@ -192,6 +212,34 @@ __global__ __launch_bounds__(64 * CR_RG) void col_reduce_kernel(const float* __r
 #pragma unroll
     for (int g = 0; g < CR_RG; ++g) v += red[g][t];
     out[c] = accumulate ? out[c] + v : v;
+  }
+}
+
+// The same reduction for up to MMT_COLRED_MAX independent jobs in one launch (blockIdx.y = job): the backward pass
+// leaves every site's partials in its own buffer and sums them all at the end instead of paying one ~6 us
+// launch-latency-bound kernel per LayerNorm.
+struct ColJobs { MmtColReduceJob job[MMT_COLRED_MAX]; };
+__global__ __launch_bounds__(64 * CR_RG) void col_reduce_multi_kernel(ColJobs jobs) {
+  __shared__ float red[CR_RG][64];
+  const MmtColReduceJob& jb = jobs.job[blockIdx.y];
+  const int d = jb.d, nvec = jb.nvec, nblocks = jb.nblocks;
+  const int chunks = (d + 63) / 64;
+  if ((int)blockIdx.x >= jb.nout * chunks) return;
+  const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float* out = jb.out[j];
+  const float* __restrict__ partials = jb.partials;
+  float s = 0.f;
+  if (out && c < d)
+    for (int b = rg; b < nblocks; b += CR_RG) s += partials[((int64_t)b * nvec + j) * d + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && out && c < d) {
+    const int t = threadIdx.x;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CR_RG; ++g) v += red[g][t];
+    out[c] = v;
   }
 }
 
@@ -264,7 +312,7 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
   const int rpb = 16, grid = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(MODE)                                                                            \
-  hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), 0, s, dout, z, mean, rstd, gamma, dz, \
+  hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), (size_t)4 * 3 * d * sizeof(float), s, dout, z, mean, rstd, gamma, dz, \
                      (bf16_t*)dy, partials, rows, d, rpb, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev)
   if (drop_mode == 0) LN_BWD_LAUNCH(0);
   else if (drop_mode == 1) LN_BWD_LAUNCH(1);
@@ -282,6 +330,35 @@ extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int 
                      nblocks, nvec, d, outs, accumulate);
   return (int)hipGetLastError();
 }
+
+extern "C" int mmt_col_reduce_multi(const MmtColReduceJob* jobs, int n, void* stream) {
+  if (!jobs || n <= 0) return MMT_ERR_ARG;
+  for (int base = 0; base < n; base += MMT_COLRED_MAX) {
+    ColJobs tab;
+    const int cnt = n - base < MMT_COLRED_MAX ? n - base : MMT_COLRED_MAX;
+    int gx = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const MmtColReduceJob& jb = jobs[base + i];
+      if (!jb.partials || jb.nblocks <= 0 || jb.nvec <= 0 || jb.nout <= 0 || jb.nout > 4 || jb.nout > jb.nvec || jb.d <= 0)
+        return MMT_ERR_ARG;
+      tab.job[i] = jb;
+      const int g = jb.nout * ((jb.d + 63) / 64);
+      gx = g > gx ? g : gx;
+    }
+    hipLaunchKernelGGL(col_reduce_multi_kernel, dim3(gx, cnt), dim3(64 * CR_RG), 0, (hipStream_t)stream, tab);
+  }
+  return (int)hipGetLastError();
+}
+
+// table_grad split in two so that the final sum can join a mmt_col_reduce_multi batch: partials only.
+extern "C" int mmt_table_grad_partials(const float* g, const int32_t* ids, int rows, int d, int vocab,
+                                       const int32_t* n_rows_dev, float* scratch, void* stream) {
+  if (!g || !ids || !scratch || rows <= 0 || vocab <= 0 || d % 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(table_grad_kernel, dim3(vocab, d / 256, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, ids,
+                     rows, d, vocab, n_rows_dev, scratch);
+  return (int)hipGetLastError();
+}
+extern "C" int mmt_table_grad_chunks(void) { return TABLE_CHUNKS; }
 
 extern "C" int64_t mmt_table_grad_scratch_floats(int vocab, int d) { return (int64_t)TABLE_CHUNKS * vocab * d; }
 

@@ -15,22 +15,24 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Generic-stride batched fp32 GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32: an fp32 fma chain, so
 // the arithmetic stays fp32 like the reference).  The text heads have only N = B*C (~32) rows, so a 32x32 output
 // tile per WAVE is the natural unit: each weight element is streamed from HBM exactly once.
-//   ksplit == 4 : the 4 waves of a block split the contraction of ONE tile and reduce through LDS (deep K);
-//   ksplit == 1 : the 4 waves own 4 neighbouring tiles (K = N rows for the weight gradients).
-__global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g, int ksplit) {
-  __shared__ float red[3][16][64];
+//   ksplit == SG_WAVES : the 16 waves of a block split the contraction of ONE tile and reduce through LDS (deep K:
+//                        the 64-cycle fp32 MFMA chain per wave stays short, 16x more waves stream the weights);
+//   ksplit == 1        : the 16 waves own 16 neighbouring tiles (K = N rows for the weight gradients).
+#define SG_WAVES 16
+__global__ __launch_bounds__(64 * SG_WAVES) void sgemm_batched_kernel(MmtSgemm g, int ksplit) {
+  __shared__ float red[SG_WAVES - 1][16][64];
   const int b = blockIdx.z;
   const float* __restrict__ A = g.A[b];
   const float* __restrict__ B = g.B[b];
   float* __restrict__ C = g.C[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   int tile_n = blockIdx.x, kbeg = 0, kend = g.K;
-  if (ksplit == 4) {
-    const int per = (((g.K + 3) / 4) + 7) & ~7;
+  if (ksplit > 1) {
+    const int per = (((g.K + SG_WAVES - 1) / SG_WAVES) + 7) & ~7;
     kbeg = wave * per;
     kend = min(g.K, kbeg + per);
   } else {
-    tile_n = blockIdx.x * 4 + wave;
+    tile_n = blockIdx.x * SG_WAVES + wave;
   }
   const int i0 = blockIdx.y * 32, j0 = tile_n * 32;
   const int i = i0 + l31, j = j0 + l31;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g, int kspl
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
-  if (ksplit == 4) {
+  if (ksplit > 1) {
     if (wave > 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(256) void sgemm_batched_kernel(MmtSgemm g, int kspl
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    for (int w = 0; w < SG_WAVES - 1; ++w)  // fixed order => deterministic
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
   }
   if (!jok) return;
   const float bias = g.bias[b] ? g.bias[b][j] : 0.f;
@@ -78,10 +82,11 @@ extern "C" int mmt_sgemm_batched(const MmtSgemm* g, void* stream) {
   if (!g || g->batch <= 0 || g->batch > MMT_MAX_EXPERTS || g->M <= 0 || g->N <= 0 || g->K <= 0) return MMT_ERR_ARG;
   for (int b = 0; b < g->batch; ++b)
     if (!g->A[b] || !g->B[b] || !g->C[b]) return MMT_ERR_ARG;
-  const int ksplit = g->K >= 128 ? 4 : 1;
+  const int ksplit = g->K >= 128 ? SG_WAVES : 1;
   const int tiles_n = (g->N + 31) / 32;
-  hipLaunchKernelGGL(sgemm_batched_kernel, dim3(ksplit == 4 ? tiles_n : (tiles_n + 3) / 4, (g->M + 31) / 32, g->batch),
-                     dim3(256), 0, (hipStream_t)stream, *g, ksplit);
+  hipLaunchKernelGGL(sgemm_batched_kernel,
+                     dim3(ksplit > 1 ? tiles_n : (tiles_n + SG_WAVES - 1) / SG_WAVES, (g->M + 31) / 32, g->batch),
+                     dim3(64 * SG_WAVES), 0, (hipStream_t)stream, *g, ksplit);
   return (int)hipGetLastError();
 }
 
@@ -293,12 +298,13 @@ __global__ __launch_bounds__(256) void moe_bwd_row_kernel(const float* __restric
 __global__ __launch_bounds__(256) void moe_bwd_w_kernel(const float* __restrict__ text, const float* __restrict__ dlogit,
                                                         int N, int K, int M, MmtTextHeads h) {
   const int m = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += 256) {
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k < K) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += dlogit[(int64_t)n * M + m] * text[(int64_t)n * K + k];
     if (h.g_moe_w[m]) h.g_moe_w[m][k] = s;
   }
-  if (threadIdx.x == 0 && h.g_moe_b[m]) {
+  if (blockIdx.y == 0 && threadIdx.x == 0 && h.g_moe_b[m]) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += dlogit[(int64_t)n * M + m];
     h.g_moe_b[m][0] = s;
@@ -400,7 +406,7 @@ extern "C" int mmt_text_heads_bwd(const MmtTextHeads* h, const float* text, cons
     // goes to dtext_moe (written); otherwise it is accumulated into dtext.
     hipLaunchKernelGGL(moe_bwd_row_kernel, dim3(N), dim3(256), 0, s, text_weights, dtext_weights, K, M, *h, dlogit,
                        dtext_moe ? dtext_moe : dtext, dtext_moe ? 0 : 1);
-    hipLaunchKernelGGL(moe_bwd_w_kernel, dim3(M), dim3(256), 0, s, text_moe ? text_moe : text, dlogit, N, K, M, *h);
+    hipLaunchKernelGGL(moe_bwd_w_kernel, dim3(M, (K + 255) / 256), dim3(256), 0, s, text_moe ? text_moe : text, dlogit, N, K, M, *h);
   }
   return (int)hipGetLastError();
 }

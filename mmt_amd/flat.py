@@ -43,6 +43,7 @@ class FlatParams:
     self.shadows = []      # (key, src_param_list, rows, cols, dst_ld, dst, dst_t)
     self._shadow_by_key = {}
     self._packed_versions = None
+    self._dirty = True  # set by writers that bypass torch's version counters (FlatAdam's raw-pointer kernel)
     self.device = None
 
   # ---- layout ----------------------------------------------------------------------------------
@@ -77,6 +78,7 @@ class FlatParams:
     for sh in self.shadows:
       sh['dst'] = None
     self._packed_versions = None
+    self._dirty = True
     return True
 
   def view(self, p, buf=None):
@@ -124,7 +126,7 @@ class FlatParams:
   def pack(self, force=False):
     """(Re)generate the bf16 shadows if any source weight changed since the last pack."""
     ver = self._versions()
-    if not force and ver == self._packed_versions and all(sh['dst'] is not None for sh in self.shadows):
+    if not force and not self._dirty and ver == self._packed_versions and all(sh['dst'] is not None for sh in self.shadows):
       return False
     items = (MmtPackItem * len(self.shadows))()
     for i, sh in enumerate(self.shadows):
@@ -147,4 +149,5 @@ class FlatParams:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     check(_lib.lib().mmt_pack_weights(items, len(self.shadows), stream), 'mmt_pack_weights')
     self._packed_versions = ver
+    self._dirty = False
     return True

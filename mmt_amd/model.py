@@ -368,7 +368,7 @@ class CENet(nn.Module):
     if self._flat.ensure(device):
       self.vid_bert._structs = {}
       self._th_ws = {}
-    self._flat.pack(force=self.training and torch.is_grad_enabled())
+    self._flat.pack()  # no-op unless a weight changed (version counters / FlatAdam's dirty flag)
     if torch.is_grad_enabled():
       self._flat.select_grad_buffer()
     self.vid_bert._ensure_ready(device)

@@ -47,6 +47,7 @@ class FlatAdam:
     check(_lib.lib().mmt_adam_step(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
                                    f.count, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                    ops._p(self.step_dev), ops._stream()), 'mmt_adam_step')
+    f._dirty = True  # the bf16 shadows are stale now (the kernel wrote through raw pointers)
 
 
 def build_optimizers(model, lr=5e-5, **kw):
