@@ -39,17 +39,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 fragments per wave in m / n
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
   const int tiles_n = N / BN;
-  const int nblk = gridDim.x;
-  const int id = xcd_remap(blockIdx.x, nblk);
-  const int tm = id / tiles_n, tn = id % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
   const int nrows = n_rows_dev ? *n_rows_dev : M;
-  if (m0 >= nrows) {  // dead tile (variable-length packing): contributes zeros to the column sums
+  // variable-length packing: remap over the LIVE tiles only, so that every XCD gets live work (see gemm2.hip)
+  const int live_tiles = min((int)gridDim.x, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
+  if ((int)blockIdx.x >= live_tiles) {  // dead tile: contributes zeros to the column sums
     if constexpr (EPI == MMT_EPI_DGELU) {
-      if (epi.colsum && threadIdx.x < BN) epi.colsum[(int64_t)tm * N + n0 + threadIdx.x] = 0.f;
+      const int dtm = (int)blockIdx.x / tiles_n, dn0 = ((int)blockIdx.x % tiles_n) * BN;
+      if (epi.colsum && threadIdx.x < BN) epi.colsum[(int64_t)dtm * N + dn0 + threadIdx.x] = 0.f;
     }
     return;
   }
+  const int id = xcd_remap(blockIdx.x, live_tiles);
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;

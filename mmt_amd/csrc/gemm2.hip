@@ -76,19 +76,25 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   bf16_t* smem = (bf16_t*)smem_raw;
 
   const int tiles_n = N / BN;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = id / tiles_n, tn = id % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
   const int nrows = n_rows_dev ? *n_rows_dev : M;
   const int tid = threadIdx.x;
-  if (m0 >= nrows) {  // dead tile (variable-length packing)
+  // Variable-length packing: only the first ceil(nrows/BM) tile rows are live.  The XCD-aware remap runs over the
+  // LIVE tiles only -- remapping the whole (dense-sized) grid would hand every live tile to the first few XCDs
+  // and leave the others with nothing but dead tiles.
+  const int live_tiles = min((int)gridDim.x, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
+  if ((int)blockIdx.x >= live_tiles) {  // dead tile: nothing to compute
     if constexpr (EPI == MMT_EPI_DGELU) {
-      if (epi.colsum)
+      if (epi.colsum) {
+        const int dm0 = ((int)blockIdx.x / tiles_n) * BM, dn0 = ((int)blockIdx.x % tiles_n) * BN;
         for (int h = 0; h < BM / 128; ++h)
-          if (m0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(m0 / 128 + h) * N + n0 + tid] = 0.f;
+          if (dm0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(dm0 / 128 + h) * N + dn0 + tid] = 0.f;
+      }
     }
     return;
   }
+  const int id = xcd_remap(blockIdx.x, live_tiles);
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, lh = lane >> 5;

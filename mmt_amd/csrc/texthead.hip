@@ -42,14 +42,26 @@ __global__ __launch_bounds__(64 * SG_WAVES) void sgemm_batched_kernel(MmtSgemm g
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int kb = kbeg; kb < kend; kb += 8) {  // wave-uniform bounds; 4 MFMAs (8 contraction values) per iteration
-    float av[4], bv[4];
+  // 8 contraction values per iteration = 4 MFMAs; lane half h feeds k = kb + 4h + u to MFMA u.  A K-contiguous
+  // operand is fetched as ONE 16-byte load per lane (4-byte row-strided gathers are TA-bound: 32 lines / load).
+  const bool avec = g.sak == 1 && !(g.sai & 3) && !((uintptr_t)A & 15);
+  const bool bvec = g.sbk == 1 && !(g.sbj & 3) && !((uintptr_t)B & 15);
+  for (int kb = kbeg; kb < kend; kb += 8) {  // wave-uniform bounds
+    const int k0 = kb + 4 * h;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+    if (iok) {
+      if (avec && k0 + 3 < kend) av = *(const f32x4*)(ap + k0);
+      else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kb + 2 * u + h;
-      const bool kok = k < kend;
-      av[u] = (iok && kok) ? ap[(int64_t)k * g.sak] : 0.f;
-      bv[u] = (jok && kok) ? bp[(int64_t)k * g.sbk] : 0.f;
+        for (int u = 0; u < 4; ++u) if (k0 + u < kend) av[u] = ap[(int64_t)(k0 + u) * g.sak];
+      }
+    }
+    if (jok) {
+      if (bvec && k0 + 3 < kend) bv = *(const f32x4*)(bp + k0);
+      else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k0 + u < kend) bv[u] = bp[(int64_t)(k0 + u) * g.sbk];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);

@@ -21,10 +21,24 @@ def main():
   ap.add_argument('db')
   ap.add_argument('--csv')
   ap.add_argument('--top', type=int, default=50)
+  ap.add_argument('--by-grid', action='store_true', help='separate rows per launch geometry')
+  ap.add_argument('--sequence', type=int, default=0, help='print the last N dispatches in order with gaps')
   args = ap.parse_args()
   c = sqlite3.connect(args.db)
   cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
-  rows = c.execute('select name, (end - start) from kernels').fetchall()
+  if args.sequence:
+    seq = c.execute('select name, start, end, grid_x, workgroup_x, stream_id from kernels order by start').fetchall()[-args.sequence:]
+    prev_end = None
+    for name, st, en, gx, wx, sid in seq:
+      gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+      print('%8.1f us  gap %7.1f  s%-3s %5d x %4d  %s' % ((en - st) / 1e3, gap, sid, gx // max(wx, 1), wx, short(name)[:70]))
+      prev_end = max(en, prev_end or 0)
+    return
+  if args.by_grid:
+    rows = [('%s [%d x %d]' % (short(n), gx // max(wx, 1), wx), d) for n, d, gx, wx in
+            c.execute('select name, (end - start), grid_x, workgroup_x from kernels')]
+  else:
+    rows = c.execute('select name, (end - start) from kernels').fetchall()
   agg = {}
   for name, dur in rows:
     a = agg.setdefault(name, [0, 0, 1 << 62, 0])
