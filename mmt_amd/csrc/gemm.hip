@@ -294,8 +294,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
 // 48 + 16 + 96 + 96 = 256 tiles = one per CU.  Tiles in the first tile-column also produce the bias gradient
 // (column sums of the bf16 dY operand) with one extra MFMA per fragment against an all-ones operand.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(MmtWgradGroup g) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128];
+// 8 waves per tile: wave group kg = wave >> 2 contracts the even / odd 64-row units of the token dimension with its
+// own LDS ring (intra-block split-K), so a CU that owns ONE tile still has two independent load/MFMA streams in
+// flight; the two partial tiles are summed through LDS at the end (fixed order => deterministic).
+__global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  bf16_t* smem = (bf16_t*)wg_smem;  // [2 stages][2 groups][A 64x128 | B 64x128]
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
 #pragma unroll 1
@@ -310,9 +314,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(MmtWgradGroup g) 
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   const int nrows = g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows;
-  const int ktiles = (nrows + 63) / 64;
+  const int units = (nrows + 63) / 64;     // 64-row units of the contraction
+  const int steps = (units + 1) / 2;       // each step: group 0 takes unit 2s, group 1 unit 2s+1
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int kg = wave8 >> 2, wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const bool want_bias = it.bias_out != nullptr && tk == 0 && wn == 0;
@@ -326,49 +332,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(MmtWgradGroup g) 
   bf16x8_t ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  constexpr int TSTAGE = 2 * 64 * 128;
+  constexpr int GSTAGE = 2 * 64 * 128;      // one group's [A | B] tiles
+  constexpr int TSTAGE = 2 * GSTAGE;        // both groups
 
-  if (ktiles > 0) {
-    stage_tn(A, lda, 0, n0, smem, wave, lane);
-    stage_tn(B, ldb, 0, k0, smem + 64 * 128, wave, lane);
-  }
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int cur = kt & 1;
+  auto stage = [&](int step, int st) {
+    const int unit = 2 * step + kg;
+    if (unit < units) {
+      bf16_t* base = smem + st * TSTAGE + kg * GSTAGE;
+      stage_tn(A, lda, unit * 64, n0, base, wave, lane);
+      stage_tn(B, ldb, unit * 64, k0, base + 64 * 128, wave, lane);
+    }
+  };
+  if (steps > 0) stage(0, 0);
+  for (int s = 0; s < steps; ++s) {
+    const int cur = s & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < ktiles) {
-      stage_tn(A, lda, (kt + 1) * 64, n0, smem + (cur ^ 1) * TSTAGE, wave, lane);
-      stage_tn(B, ldb, (kt + 1) * 64, k0, smem + (cur ^ 1) * TSTAGE + 64 * 128, wave, lane);
-    }
-    bf16_t* at = smem + cur * TSTAGE;
+    if (s + 1 < steps) stage(s + 1, cur ^ 1);
+    const int unit = 2 * s + kg;
+    bf16_t* at = smem + cur * TSTAGE + kg * GSTAGE;
     bf16_t* bt = at + 64 * 128;
-    const int live = nrows - kt * 64;
-    if (live < 64) {  // ragged tail: zero the dead rows of both operands
-      for (int e = tid; e < (64 - live) * 32; e += 256) {
-        const int r = live + e / 32, q = e % 32;
-        u32x4 z = {0, 0, 0, 0};
-        if (q < 16) *(u32x4*)(at + r * 128 + q * 8) = z;
-        else *(u32x4*)(bt + r * 128 + (q - 16) * 8) = z;
+    const int live = nrows - unit * 64;       // rows of this unit that exist (<= 0: nothing to do)
+    if (2 * s + 1 >= units || nrows - (2 * s + 1) * 64 < 64) {  // last step: ragged tails (block-uniform condition)
+      if (live > 0 && live < 64) {
+        for (int e = wave * 64 + lane; e < (64 - live) * 32; e += 256) {
+          const int r = live + e / 32, q = e % 32;
+          u32x4 z = {0, 0, 0, 0};
+          if (q < 16) *(u32x4*)(at + r * 128 + q * 8) = z;
+          else *(u32x4*)(bt + r * 128 + (q - 16) * 8) = z;
+        }
       }
       __syncthreads();
     }
+    if (live > 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[4], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = tr_frag(at, ks, wm * 64 + i * 16, lane);
+        for (int i = 0; i < 4; ++i) af[i] = tr_frag(at, ks, wm * 64 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(bt, ks, wn * 64 + j * 16, lane);
+        for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(bt, ks, wn * 64 + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      if (want_bias) {
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+        }
       }
     }
+  }
+  // ---- sum the two wave groups through LDS (group 1 -> group 0), then store ----
+  __syncthreads();
+  f32x4* xch = (f32x4*)wg_smem;  // [20][256] f32x4 = 80 KiB
+  const int t4 = wave * 64 + lane;
+  if (kg == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xch[(i * 4 + j) * 256 + t4] = acc[i][j];
+      xch[(16 + i) * 256 + t4] = accb[i];
+    }
+  }
+  __syncthreads();
+  if (kg == 1) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] += xch[(i * 4 + j) * 256 + t4];
+    accb[i] += xch[(16 + i) * 256 + t4];
   }
   float* __restrict__ out = it.out;
 #pragma unroll
@@ -405,7 +439,14 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
     it.tile_begin = tiles;
     tiles += (it.N / 128) * (it.K2 / 128);
   }
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, h);
+  constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;  // 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
+  static bool configured = false;
+  if (!configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)wgrad_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (rc != hipSuccess) return (int)rc;
+    configured = true;
+  }
+  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }
 
