@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmmt_hip.so')
+LIB_PATH = os.environ.get('MMT_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmmt_hip.so')  # env override: lab builds only
 
 c_int, c_i64, c_u32, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p
 

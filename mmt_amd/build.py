@@ -27,7 +27,12 @@ def _newest(paths):
   return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, instr=False):
+  """instr=True builds a separate lab library (cycle counters inside gemm2's K-loop, tools/gemm_instr.py)."""
+  global OBJ, LIB, FLAGS
+  if instr:
+    OBJ, LIB = os.path.join(HERE, 'lib', 'obj_instr'), os.path.join(HERE, 'lib', 'libmmt_hip_instr.so')
+    FLAGS = FLAGS + ['-DMMT_GEMM2_INSTR']
   os.makedirs(OBJ, exist_ok=True)
   sources = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
   headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))
@@ -62,4 +67,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv, verbose=True))
+  print(build(force='--force' in sys.argv, verbose=True, instr='--instr' in sys.argv))

@@ -63,15 +63,20 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGN, int NS, int EPI>
-__global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
     const int32_t* __restrict__ n_rows_dev) {
-  constexpr int WGM = BM / 64, NW = WGM * WGN, NT = NW * 64, WTN = BN / WGN, NJ = WTN / 32;
+  constexpr int NW = WGM * WGN, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
   constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
   constexpr int CG = BN / 4;       // 4-column groups per row
   constexpr int RG = NT / CG;      // rows covered per sweep of the block
+  constexpr int CH = BM < 64 ? BM : 64;  // rows per epilogue chunk
+  // 8-wave blocks run as two groups in opposite phase (waves w and w+4 share a SIMD): group 0 issues the next
+  // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
+  // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
+  constexpr bool STAG = NW == 8 && NS >= 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;
 
@@ -84,7 +89,7 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   const int live_tiles = min((int)gridDim.x, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
   if ((int)blockIdx.x >= live_tiles) {  // dead tile: nothing to compute
     if constexpr (EPI == MMT_EPI_DGELU) {
-      if (epi.colsum) {
+      if (epi.colsum && BM >= 128) {
         const int dm0 = ((int)blockIdx.x / tiles_n) * BM, dn0 = ((int)blockIdx.x % tiles_n) * BN;
         for (int h = 0; h < BM / 128; ++h)
           if (dm0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(dm0 / 128 + h) * N + dn0 + tid] = 0.f;
@@ -98,10 +103,11 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
+  const bool late_issue = STAG && wave >= NW / 2;
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -119,48 +125,81 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
       stage2<BM, NW>(A, lda, m0, amax, s0 * BK, smem + s0 * STAGE, wave, lane);
       stage2<BN, NW>(B, ldb, n0, bmax, s0 * BK, smem + s0 * STAGE + BM * BK, wave, lane);
     }
+  // per-lane LDS offsets of this wave's fragments (row r, 16-byte chunk c lives at chunk c ^ ((r>>1)&7))
+  int aoff[MI], boff[NJ], asw[MI], bsw[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WTM + i * 32 + l31;
+    aoff[i] = r * BK; asw[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int r = wn * WTN + j * 32 + l31;
+    boff[j] = BM * BK + r * BK; bsw[j] = (r >> 1) & 7;
+  }
   int cur = 0;
+#ifdef MMT_GEMM2_INSTR
+  long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t0 = clock64(), tp = t0;
+#define TICK(acc) do { const long long tn_ = clock64(); acc += tn_ - tp; tp = tn_; } while (0)
+#else
+#define TICK(acc) do {} while (0)
+#endif
   for (int kt = 0; kt < KT; ++kt) {
     const int ahead = min(KT - kt - 1, NS - 2);  // stages issued after kt that may stay in flight
     if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
+    TICK(t_wait);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < KT) {
-      int nxt = cur + NS - 1;
-      if (nxt >= NS) nxt -= NS;
+    TICK(t_bar);
+    int nxt = cur + NS - 1;
+    if (nxt >= NS) nxt -= NS;
+    const bool do_issue = kt + NS - 1 < KT;
+    if (do_issue && !late_issue) {
       stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
       stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
-    const bf16_t* as = smem + cur * STAGE;
-    const bf16_t* bs = as + BM * BK;
+    TICK(t_issue);
+    const bf16_t* st = smem + cur * STAGE;
+    // fragment reads software-pipelined one k-substep ahead of the MFMAs that consume them
+    bf16x8_t af[2][MI], bfr[2][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[0][i] = *(const bf16x8_t*)(st + aoff[i] + ((lh ^ asw[i]) << 3));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bfr[0][j] = *(const bf16x8_t*)(st + boff[j] + ((lh ^ bsw[j]) << 3));
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk * 2 + lh;
-      bf16x8_t af[2], bfr[NJ];
+      if (kk < 3) {
+        const int c = (kk + 1) * 2 + lh;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = wm * 64 + i * 32 + l31;
-        af[i] = *(const bf16x8_t*)(as + r * BK + ((c ^ ((r >> 1) & 7)) << 3));
+        for (int i = 0; i < MI; ++i) af[(kk + 1) & 1][i] = *(const bf16x8_t*)(st + aoff[i] + ((c ^ asw[i]) << 3));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[(kk + 1) & 1][j] = *(const bf16x8_t*)(st + boff[j] + ((c ^ bsw[j]) << 3));
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int r = wn * WTN + j * 32 + l31;
-        bfr[j] = *(const bf16x8_t*)(bs + r * BK + ((c ^ ((r >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0);
+    }
+    if (do_issue && late_issue) {
+      stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
+      stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
+#ifdef MMT_GEMM2_INSTR
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[MI - 1][NJ - 1][15]));
+#endif
+    TICK(t_comp);
   }
+#ifdef MMT_GEMM2_INSTR
+  const long long t_loop_end = clock64();
+#endif
 
   // ---- epilogue: 64 rows at a time through a row-major fp32 LDS image -------------------------------
   float* st = (float*)smem_raw;
-  float* red = st + 64 * P;  // [RG][BN] column-sum scratch (DGELU)
+  float* red = st + CH * P;  // [RG][BN] column-sum scratch (DGELU)
   const int cg = tid % CG, rg = tid / CG;
   const int col = n0 + cg * 4;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -172,23 +211,23 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // every wave is done with the stage buffers
 #pragma unroll
-  for (int ch = 0; ch < WGM; ++ch) {
-    if (wm == ch) {
+  for (int ch = 0; ch < BM / CH; ++ch) {
+    if ((wm * WTM) / CH == ch) {  // this wave's rows belong to chunk ch
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *(f32x4*)(st + (i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh) = v;
+            *(f32x4*)(st + ((wm * WTM) % CH + i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh) = v;
           }
     }
     __syncthreads();
 #pragma unroll
-    for (int r0 = 0; r0 < 64; r0 += RG) {
+    for (int r0 = 0; r0 < CH; r0 += RG) {
       const int r = r0 + rg;
-      const int row = m0 + ch * 64 + r;
+      const int row = m0 + ch * CH + r;
       if (row < M) {
         f32x4 v = *(const f32x4*)(st + r * P + cg * 4);
         v += bias4;
@@ -234,7 +273,7 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
       }
     }
     if constexpr (EPI == MMT_EPI_DGELU) {
-      if (epi.colsum && (ch & 1)) {  // one partial row of column sums per 128 output rows
+      if (epi.colsum && BM >= 128 && (ch & 1)) {  // one partial row of column sums per 128 output rows
         *(f32x4*)(red + rg * BN + cg * 4) = (f32x4){csum[0], csum[1], csum[2], csum[3]};
         csum[0] = csum[1] = csum[2] = csum[3] = 0.f;
         __syncthreads();
@@ -249,25 +288,35 @@ __global__ __launch_bounds__((BM / 64) * WGN * 64) void gemm2_kernel(
     }
     __syncthreads();
   }
+#ifdef MMT_GEMM2_INSTR
+  if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
+    long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)blockIdx.x * 8;
+    dbgbuf[0] = t_wait; dbgbuf[1] = t_bar; dbgbuf[2] = t_issue; dbgbuf[3] = t_comp;
+    dbgbuf[4] = t_loop_end - t0; dbgbuf[5] = clock64() - t_loop_end; dbgbuf[6] = t0; dbgbuf[7] = KT;
+  }
+#endif
 }
 
-template <int BM, int BN, int WGN, int NS, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
 static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-  constexpr int NT = (BM / 64) * WGN * 64;
+  constexpr int NT = WGM * WGN * 64;
   constexpr int RG = NT / (BN / 4);
+  constexpr int CH = BM < 64 ? BM : 64;
+  static_assert(CH % RG == 0 && (BM + BN) % (8 * WGM * WGN) == 0 && BM % (8 * WGM * WGN) == 0 && BN % (8 * WGM * WGN) == 0,
+                "tile geometry");
   constexpr size_t stage_bytes = (size_t)NS * (BM + BN) * BK * 2;
-  constexpr size_t epi_bytes = (size_t)(64 * (BN + 4) + RG * BN) * 4;
+  constexpr size_t epi_bytes = (size_t)(CH * (BN + 4) + RG * BN) * 4;
   constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static bool configured = false;
   if (!configured) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGN, NS, EPI>,
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, NS, EPI>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
   const int grid = ((M + BM - 1) / BM) * (N / BN);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGN, NS, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
@@ -275,13 +324,18 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
 template <int EPI>
 static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
                  int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-#define G2(BM_, BN_, WGN_, NS_) return launch2<BM_, BN_, WGN_, NS_, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s)
+#define G2(BM_, BN_, WGM_, WGN_, NS_) \
+  return launch2<BM_, BN_, WGM_, WGN_, NS_, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s)
+  if (EPI == MMT_EPI_DGELU && e.colsum && (tile & 0xff) == 12) return MMT_ERR_ARG;  // 64-row tiles: no column sums
   switch (tile & 0xff) {
-    case 3: if (N % 128 == 0) G2(256, 128, 2, 3); break;
-    case 4: if (N % 256 == 0) G2(256, 256, 2, 2); break;
-    case 5: if (N % 128 == 0) G2(128, 128, 2, 2); break;
-    case 7: if (N % 64 == 0) G2(128, 64, 2, 3); break;
-    case 10: if (N % 128 == 0) G2(256, 128, 2, 2); break;
+    case 3: if (N % 128 == 0) G2(256, 128, 4, 2, 3); break;   // 8 waves, staggered
+    case 4: if (N % 256 == 0) G2(256, 256, 4, 2, 2); break;   // 8 waves
+    case 5: if (N % 128 == 0) G2(128, 128, 2, 2, 2); break;   // 4 waves, 2 blocks/CU
+    case 7: if (N % 64 == 0) G2(128, 64, 2, 2, 3); break;     // 4 waves
+    case 10: if (N % 128 == 0) G2(256, 128, 4, 2, 2); break;  // 8 waves, in phase
+    case 11: if (N % 128 == 0) G2(128, 128, 2, 4, 3); break;  // 8 waves on 128x128 (wave 64x32), staggered
+    case 12: if (N % 128 == 0) G2(64, 128, 2, 4, 3); break;   // 8 waves on 64x128 (wave 32x32), staggered, 2 blocks/CU
+    case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
   }
 #undef G2
   return MMT_ERR_ARG;

@@ -96,7 +96,7 @@ def test_gemm_nt_fused_epilogues(tile):
   _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
 
 
-@pytest.mark.parametrize('tile', [3, 4, 5, 7, 10])
+@pytest.mark.parametrize('tile', [3, 4, 5, 7, 10, 11, 12, 13])
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (777, 512, 192), (7168, 1536, 512)])
 def test_gemm_nt_wide_tiles(tile, M, N, K):
   """gemm2.hip (256x128 / 256x256 / 128x128 / 128x256 tiles, 32x32x16 MFMA, LDS-staged epilogue): every epilogue."""
@@ -127,12 +127,13 @@ def test_gemm_nt_wide_tiles(tile, M, N, K):
   _close('bf16', pre[:M], ref, 2e-2, 1e-2)
   aux = _rand((R, N), seed=25, dtype=torch.bfloat16)
   live = torch.tensor([M - 37], device=_dev(), dtype=torch.int32)
-  colsum = torch.zeros((M + 127) // 128, N, device=_dev(), dtype=torch.float32)
+  colsum = torch.zeros((M + 127) // 128, N, device=_dev(), dtype=torch.float32) if tile != 12 else None  # 64-row tiles: none
   ops.gemm_nt(a, b, pre, 'DGELU', m=M, aux=aux, colsum=colsum, n_rows_dev=live, tile=tile)
   x = aux[:M].float().requires_grad_(True)
   _gelu(x).sum().backward()
   _close('dgelu', pre[:M - 37], (ref * x.grad)[:M - 37], 3e-2, 1.5e-2)
-  _close('dgelu.colsum (live rows only)', colsum.sum(0), pre[:M - 37].float().sum(0), 2e-2, 2e-4)
+  if colsum is not None:
+    _close('dgelu.colsum (live rows only)', colsum.sum(0), pre[:M - 37].float().sum(0), 2e-2, 2e-4)
 
 
 @pytest.mark.parametrize('batch,M,N,K,trans', [(3, 6, 256, 768, False), (7, 32, 512, 512, False), (2, 300, 130, 6, True),
