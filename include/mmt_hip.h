@@ -72,6 +72,16 @@ int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
                      int M, int N, int K, int epilogue, const MmtEpilogue* epi,
                      const int32_t* n_rows_dev, void* stream);
 
+/* Several independent C_i[M_i,N_i] = A_i . B_i^T (+ bias_i) in ONE launch (epilogue MMT_EPI_BIAS_F32 / MMT_EPI_F32):
+ * the per-expert ReduceDim.fc projections of model/model.py:426-437 (seven GEMMs with different K). */
+#define MMT_GEMM_GROUP_MAX 16
+typedef struct MmtGemmItem {
+  const void* A; const void* B; void* C; const float* bias; /* bf16 [M,lda], bf16 [N,ldb], fp32 [M,ldc], fp32 [N] */
+  int64_t lda, ldb, ldc;
+  int32_t M, N, K, tile_begin;
+} MmtGemmItem;
+int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue, void* stream);
+
 /* dW[N,K2] (+)= sum_rows A[rows,N]^T . B[rows,K2]   (weight gradients: contraction over tokens).
  * A, B are row-major bf16 [rows, *]; the result is written as fp32 `splits` partial slabs
  * ws[splits][N*K2] which mmt_reduce_slabs sums.  Replaces autograd's weight-gradient mm for every

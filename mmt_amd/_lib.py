@@ -24,6 +24,11 @@ class MmtPackItem(ctypes.Structure):
               ('reserved', ctypes.c_int32)]
 
 
+class MmtGemmItem(ctypes.Structure):
+  _fields_ = [('A', c_vp), ('B', c_vp), ('C', c_vp), ('bias', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldc', c_i64),
+              ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('tile_begin', ctypes.c_int32)]
+
+
 class MmtWgradItem(ctypes.Structure):
   _fields_ = [('A', c_vp), ('B', c_vp), ('out', c_vp), ('bias_out', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldo', c_i64),
               ('N', ctypes.c_int32), ('K2', ctypes.c_int32), ('N_out', ctypes.c_int32), ('K2_out', ctypes.c_int32),
@@ -96,6 +101,7 @@ SIGNATURES = {
     'mmt_gemm_nt_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
     'mmt_gemm_tn_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_gemm_nt_grouped': (c_int, [ctypes.POINTER(MmtGemmItem), c_int, c_int, c_vp]),
     'mmt_wgrad_grouped': (c_int, [ctypes.POINTER(MmtWgradGroup), c_vp]),
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),

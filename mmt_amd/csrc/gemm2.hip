@@ -64,10 +64,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
+__device__ __forceinline__ void gemm2_body(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-    void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
-    const int32_t* __restrict__ n_rows_dev) {
+    void* __restrict__ Cout, int64_t ldc, int M, int N, int K, const MmtEpilogue& epi,
+    const int32_t* __restrict__ n_rows_dev, const int bid, const int nblk) {
   constexpr int NW = WGM * WGN, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
   constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
   constexpr int CG = BN / 4;       // 4-column groups per row
@@ -86,18 +86,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
   // Variable-length packing: only the first ceil(nrows/BM) tile rows are live.  The XCD-aware remap runs over the
   // LIVE tiles only -- remapping the whole (dense-sized) grid would hand every live tile to the first few XCDs
   // and leave the others with nothing but dead tiles.
-  const int live_tiles = min((int)gridDim.x, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
-  if ((int)blockIdx.x >= live_tiles) {  // dead tile: nothing to compute
+  const int live_tiles = min(nblk, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
+  if (bid >= live_tiles) {  // dead tile: nothing to compute
     if constexpr (EPI == MMT_EPI_DGELU) {
       if (epi.colsum && BM >= 128) {
-        const int dm0 = ((int)blockIdx.x / tiles_n) * BM, dn0 = ((int)blockIdx.x % tiles_n) * BN;
+        const int dm0 = (bid / tiles_n) * BM, dn0 = (bid % tiles_n) * BN;
         for (int h = 0; h < BM / 128; ++h)
           if (dm0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(dm0 / 128 + h) * N + dn0 + tid] = 0.f;
       }
     }
     return;
   }
-  const int id = xcd_remap(blockIdx.x, live_tiles);
+  const int id = xcd_remap(bid, live_tiles);
   const int tm = id / tiles_n, tn = id % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = tid & 63, wave = tid >> 6;
@@ -290,11 +290,75 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
   }
 #ifdef MMT_GEMM2_INSTR
   if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
-    long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)blockIdx.x * 8;
+    long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 8;
     dbgbuf[0] = t_wait; dbgbuf[1] = t_bar; dbgbuf[2] = t_issue; dbgbuf[3] = t_comp;
     dbgbuf[4] = t_loop_end - t0; dbgbuf[5] = clock64() - t_loop_end; dbgbuf[6] = t0; dbgbuf[7] = KT;
   }
 #endif
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+    void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
+    const int32_t* __restrict__ n_rows_dev) {
+  gemm2_body<BM, BN, WGM, WGN, NS, EPI>(A, lda, B, ldb, Cout, ldc, M, N, K, epi, n_rows_dev, (int)blockIdx.x,
+                                        (int)gridDim.x);
+}
+
+// Several independent small GEMMs (the per-expert ReduceDim projections, model/model.py:426-437) in ONE launch:
+// block -> (problem, tile) through a prefix table; each problem keeps its own XCD-aware tile order.
+struct GemmGroupTable { MmtGemmItem item[MMT_GEMM_GROUP_MAX]; int count; };
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_grouped_kernel(GemmGroupTable tab) {
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < tab.count; ++q)
+    if ((int)blockIdx.x >= tab.item[q].tile_begin) p = q;
+  const MmtGemmItem& it = tab.item[p];
+  MmtEpilogue e = {};
+  e.bias = it.bias;
+  const int nblk = ((it.M + BM - 1) / BM) * (it.N / BN);
+  gemm2_body<BM, BN, WGM, WGN, NS, EPI>((const bf16_t*)it.A, it.lda, (const bf16_t*)it.B, it.ldb, it.C, it.ldc, it.M, it.N,
+                                        it.K, e, nullptr, (int)blockIdx.x - it.tile_begin, nblk);
+}
+
+extern "C" int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue, void* stream) {
+  if (!items || n <= 0 || n > MMT_GEMM_GROUP_MAX) return MMT_ERR_ARG;
+  if (epilogue != MMT_EPI_BIAS_F32 && epilogue != MMT_EPI_F32) return MMT_ERR_ARG;
+  constexpr int BM = 128, BN = 64, WGM = 4, WGN = 2, NS = 3;
+  GemmGroupTable tab;
+  tab.count = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    MmtGemmItem it = items[i];
+    if (!it.A || !it.B || !it.C || it.M <= 0 || it.N <= 0 || it.K <= 0 || it.K % BK || it.N % BN) return MMT_ERR_ARG;
+    if (epilogue == MMT_EPI_BIAS_F32 && !it.bias) return MMT_ERR_ARG;
+    if ((it.lda % 8) || (it.ldb % 8) || (it.ldc % 4) || ((uintptr_t)it.A & 15) || ((uintptr_t)it.B & 15) ||
+        ((uintptr_t)it.C & 15))
+      return MMT_ERR_ALIGN;
+    it.tile_begin = tiles;
+    tiles += ((it.M + BM - 1) / BM) * (it.N / BN);
+    tab.item[i] = it;
+  }
+  constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<BM, BN, WGM, WGN, NS, MMT_EPI_BIAS_F32>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<BM, BN, WGM, WGN, NS, MMT_EPI_F32>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return (int)rc;
+    configured = true;
+  }
+  if (epilogue == MMT_EPI_BIAS_F32)
+    hipLaunchKernelGGL((gemm2_grouped_kernel<BM, BN, WGM, WGN, NS, MMT_EPI_BIAS_F32>), dim3(tiles), dim3(512), lds,
+                       (hipStream_t)stream, tab);
+  else
+    hipLaunchKernelGGL((gemm2_grouped_kernel<BM, BN, WGM, WGN, NS, MMT_EPI_F32>), dim3(tiles), dim3(512), lds,
+                       (hipStream_t)stream, tab);
+  return (int)hipGetLastError();
 }
 
 template <int BM, int BN, int WGM, int WGN, int NS, int EPI>

@@ -382,9 +382,8 @@ class CENet(nn.Module):
                            ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
                            stream), 'mmt_video_plan')
     check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, stream), 'mmt_video_cast')
-    for mod in self.modalities:
-      w, _ = self._flat.shadow(('reduce', mod))
-      ops.gemm_nt(plan.x[mod], w, plan.y[mod], 'BIAS_F32', m=plan.src_rows, bias=self.video_dim_reduce[mod].fc.bias)
+    ops.gemm_nt_grouped([(plan.x[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
+                          self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows)
     feats = torch.empty(plan.rows_alloc, d, device=plan.slot.device, dtype=torch.float32)
     check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(feats), stream),
           'mmt_video_scatter')

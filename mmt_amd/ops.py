@@ -79,6 +79,20 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
   return out
 
 
+def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32'):
+  """items: list of (a [M,K] bf16, b [N,K] bf16, out [M,N] fp32, bias [N] fp32 or None): all in ONE launch."""
+  from ._lib import MmtGemmItem
+  arr = (MmtGemmItem * len(items))()
+  for i, (a, b, out, bias) in enumerate(items):
+    _need_cuda(a, b, out)
+    it = arr[i]
+    it.A, it.B, it.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    it.bias = bias.data_ptr() if bias is not None else None
+    it.lda, it.ldb, it.ldc = a.stride(0), b.stride(0), out.stride(0)
+    it.M, it.N, it.K = (a.shape[0] if m is None else m), b.shape[0], b.shape[1]
+  check(_lib.lib().mmt_gemm_nt_grouped(arr, len(items), EPI[epilogue], _stream()), 'mmt_gemm_nt_grouped')
+
+
 def wgrad_grouped(items, rows, n_rows_dev=None):
   """items: list of (a [rows,N] bf16, b [rows,K2] bf16, out fp32 [N_out,K2_out], bias_out fp32 [N_out] or None).
   One launch: out = a^T @ b (fp32), bias_out = column sums of a."""

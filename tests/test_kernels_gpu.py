@@ -194,6 +194,24 @@ def test_gemm_tn_weight_gradient(rows, N, K2, splits, live):
   _close('tn accumulate', acc, ref + 1.0, 2e-3 * math.sqrt(n / 256.0), 2e-4)
 
 
+def test_gemm_nt_grouped():
+  """Seven ReduceDim-shaped GEMMs (different K) + bias in one launch."""
+  from mmt_amd import ops
+  M, R, N = 992, 1024, 512
+  items, refs = [], []
+  for i, K in enumerate([512, 384, 2048, 1024, 2304, 384, 128]):
+    a = _rand((R, K), seed=90 + i, dtype=torch.bfloat16)
+    b = _rand((N, K), 0.05, seed=100 + i, dtype=torch.bfloat16)
+    bias = _rand((N,), seed=110 + i)
+    out = torch.full((R, N), 3.0, device=_dev())
+    items.append((a, b, out, bias))
+    refs.append(a[:M].float() @ b.float().t() + bias)
+  ops.gemm_nt_grouped(items, m=M)
+  for (a, b, out, bias), r in zip(items, refs):
+    _close('grouped gemm', out[:M], r, 2e-3, 2e-4)
+    assert bool((out[M:] == 3.0).all())
+
+
 @pytest.mark.parametrize('live', [None, 333])
 def test_wgrad_grouped(live):
   """One launch for several dW = dY^T X (+ bias gradient = column sums of dY), incl. an un-padded output."""
