@@ -59,6 +59,12 @@ FIXTURES = {
     # BASELINE.json configs[1]: 7 experts x 30 tokens, d512, L4, batch 32
     'configB': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=32, max_tokens=30,
                     vb=dict(hidden=512, layers=4, heads=4, inter=3072, max_pos=32), seed=13),
+    # BASELINE.json configs[3] shape (long sequences): 7 experts x 100 tokens -> S = 708, max_pos 102; small batch
+    'config4': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=4, max_tokens=100,
+                    vb=dict(hidden=512, layers=4, heads=4, inter=3072, max_pos=102), seed=14),
+    # BASELINE.json configs[4] encoder shape (HowTo100M-scale): d1024, 6 layers, 8 heads, I = 6144; small batch
+    'config5': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=4, max_tokens=10,
+                    vb=dict(hidden=1024, layers=6, heads=8, inter=6144, max_pos=32), seed=15),
 }
 
 
@@ -313,10 +319,13 @@ def main():
   os.makedirs(GOLDEN, exist_ok=True)
   R = load_reference()
   torch.set_num_threads(os.cpu_count())
-  run_sim_loss_metric_fixtures(R)
-  run_bert_fixture(R)
+  only = [a for a in sys.argv[1:] if not a.startswith('-')]
+  if not only:
+    run_sim_loss_metric_fixtures(R)
+    run_bert_fixture(R)
   for name, fx in FIXTURES.items():
-    run_cenet_fixture(R, name, fx)
+    if not only or name in only:
+      run_cenet_fixture(R, name, fx)
 
 
 if __name__ == '__main__':
