@@ -239,6 +239,19 @@ int mmt_maxmargin(const float* sims, int n, float margin, int fix_norm, float* p
 /* InfoNceLoss.forward (loss.py:68-81); scratch = 3n floats. */
 int mmt_infonce(const float* sims, int n, float* scratch, float* loss, float* grad, void* stream);
 
+/* ---- evaluation path at scale (retrieval.hip): SURVEY.md 8f.1 ------------------------------------------------
+ * Replaces the CPU-side sharded_cross_view_inner_product + numpy ranking of trainer/trainer.py:396-447.
+ * mmt_sims_eval: same maths as mmt_sims_fwd but as one exact-fp32 MFMA GEMM over K = M*d (no [NT,NV,M] tensor, no
+ * backward); ws = mmt_sims_eval_workspace_floats() floats.  Text rows are b*C + cap (model.py:805,822). */
+int64_t mmt_sims_eval_workspace_floats(int NT, int NV, int M, int d);
+int mmt_sims_eval(const float* txt, const float* vid, const float* tw, const float* vw, int NT, int NV, int M, int d,
+                  float* ws, float* sims, void* stream);
+/* Tie-averaged retrieval ranks (0-based, model/metric.py:90-121, 153-243) of sims [NQ = NV*cpv, NV]:
+ * t2v_rank[q] for every text query; v2t_rank[i] = best rank among video i's unmasked captions (+inf if none).
+ * qmask (nullable) uint8 [NQ]: 1 = real caption (query_masks).  scratch: NQ floats. */
+int mmt_retrieval_ranks(const float* sims, const uint8_t* qmask, int NQ, int NV, float* t2v_rank, float* v2t_rank,
+                        float* scratch, void* stream);
+
 /* ---- text heads (texthead.hip), fp32 ------------------------------------------------------------------
  * GatedEmbeddingUnit per expert (model.py:683-702, 736-750) + text MoE weights (model.py:262-283,618),
  * batched over the M experts. */

@@ -242,3 +242,41 @@ def test_train_mode_dropout_replay_through_oracle():
     ref = O.bert_model(sd, 'vid_bert.', vbq, mask, types_, pos, feats, masks=masks)
   assert 0.85 < masks['emb'].mean().item() < 0.95
   assert (seq.detach().cpu() - ref).abs().max() < 0.05
+
+
+def test_eval_path_on_device_metrics_match_reference():
+  """N_text x N_video similarity + tie-averaged R@K on the device vs the reference's metric code.
+  (a) the golden metric cases produced by the REAL reference's model/metric.py; (b) 1000 videos x 3 captions with
+  ties and masked captions against the oracle restatement (pinned to the reference by those same cases)."""
+  from mmt_amd import metric as NM
+  from oracle import mmt_oracle as O
+  g = load_npz('sim_loss_metric')
+  cases = json.loads(str(g['metric_cases']))
+  for key, want in cases.items():
+    sims = g['metric_sims_' + key]
+    qm = g['metric_qm_' + key] if ('metric_qm_' + key) in g.files else None
+    t2v, v2t = NM.t2v_metrics(sims, qm), NM.v2t_metrics(torch.from_numpy(sims).to(DEV), qm)
+    for got, ref in ((t2v, want['t2v']), (v2t, want['v2t'])):
+      for k, v in ref.items():
+        assert abs(got[k] - v) < 1e-5, (key, k, got[k], v)  # the reference stores float32 percentages
+  rs = np.random.RandomState(5)
+  nv, cpv, m, d = 1000, 3, 7, 512
+  vid = torch.nn.functional.normalize(torch.from_numpy(rs.randn(nv, m, d).astype(np.float32)), dim=-1)
+  txt = torch.nn.functional.normalize(torch.from_numpy(rs.randn(nv, m, cpv, d).astype(np.float32)) +
+                                      2.0 * vid[:, :, None, :], dim=-1)  # captions correlated with their video
+  tw = torch.softmax(torch.from_numpy(rs.randn(nv, cpv, m).astype(np.float32)), -1)
+  vw = torch.full((nv, m), 1.0 / m)
+  tw[3, 1] = 0.0  # a zero-weight query: the 1e-5 branch of model.py:816
+  ref_sims = O.cross_view_inner_product(vid, txt, vw, tw, 'indep').numpy()
+  sims = NM.eval_similarity(vid.to(DEV), txt.to(DEV), vw.to(DEV), tw.to(DEV))
+  assert sims.shape == (nv * cpv, nv) and np.abs(sims.cpu().numpy() - ref_sims).max() < 2e-6
+  qm = (rs.rand(nv, cpv) > 0.2).astype(np.float32)
+  qm[:, 0] = 1.0
+  quant = np.round(ref_sims * 50.0) / 50.0  # heavy ties
+  for s_np, mask in ((ref_sims, None), (ref_sims, qm), (quant, qm)):
+    for got, ref in ((NM.t2v_metrics(torch.from_numpy(s_np).to(DEV), mask), O.t2v_metrics(s_np.copy(), mask)),
+                     (NM.v2t_metrics(torch.from_numpy(s_np).to(DEV), mask), O.v2t_metrics(s_np.copy(), mask))):
+      for k, v in ref.items():
+        assert abs(got[k] - v) < 1e-9, (k, got[k], v)
+  both = NM.retrieval_metrics(vid.to(DEV), txt.to(DEV), vw.to(DEV), tw.to(DEV), qm)
+  assert both['t2v_metrics']['R1'] > 50.0 and set(both) == {'t2v_metrics', 'v2t_metrics'}
