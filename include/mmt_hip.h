@@ -103,7 +103,8 @@ typedef struct MmtWgradItem {
   float* out;      /* fp32 [N_out, ldo]                                                              */
   float* bias_out; /* fp32 [N_out] or NULL                                                           */
   int64_t lda, ldb, ldo;
-  int32_t N, K2, N_out, K2_out, tile_begin, reserved;
+  int32_t N, K2, N_out, K2_out, tile_begin;
+  int32_t reserved; /* > 0: this item contracts over exactly `reserved` rows (overrides rows / n_rows_dev)     */
 } MmtWgradItem;
 typedef struct MmtWgradGroup {
   MmtWgradItem item[MMT_WGRAD_MAX];
@@ -130,6 +131,13 @@ int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32
                      int rows, int d, const int32_t* n_rows_dev, const int32_t* row_index,
                      uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
                      void* stream);
+/* Compact-row variant: LN over `rows` compact rows; fp32 row i goes to h32[dst_rows[i]] (h16 compact, nullable). */
+int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, float eps, float* h32,
+                       const int32_t* dst_rows, void* h16, float* mean, float* rstd, int rows, int d, void* stream);
+/* dst[i] = src[rows[i]] (+ idx_out[i] = idx_in ? idx_in[rows[i]] : rows[i]) / dst[rows[i]] = src[i]; fp32 rows of d. */
+int mmt_rows_gather(const float* src, const int32_t* rows, int n, int d, float* dst, const int32_t* idx_in,
+                    int32_t* idx_out, void* stream);
+int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, void* stream);
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
  * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */
@@ -175,6 +183,16 @@ int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_b
                  const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H, int d,
                  float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
                  const uint32_t* seed_dev, void* stream);
+/* Query-subset attention (last encoder layer: only the rows that are read out need a context vector): queries are the
+ * rows qsel[b*nq + i]; ctx / lse / dctx / delta are compact [B*nq, .]; qkv / dqkv keep the full layout.  dqkv must be
+ * zero on entry in the Q section of the non-selected rows. */
+int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
+                      void* ctx, float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
+                      float drop_scale, const uint32_t* seed_dev, void* stream);
+int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
+                      const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
+                      int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                      const uint32_t* seed_dev, void* stream);
 /* Test helper: the keep-mask mmt_attn_fwd draws, uint8 [B,H,S,S] (dense layout). */
 int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,
                           const uint32_t* seed_dev, void* stream);
@@ -320,6 +338,12 @@ typedef struct MmtBertBatch {
   const int32_t* n_rows_dev;  /* live row count on device or NULL (= rows)                              */
   const uint32_t* seed_dev;   /* per-step dropout seed on device or NULL                                */
   int32_t rows, rows_alloc, batch, seq;
+  /* Optional: the only rows of sequence_output the caller will read (CENet: the AGG token of every expert,
+   * model.py:583-587), out_rows[b*n_out_per_sample + i], each sample's in ascending order.  The last layer then runs
+   * everything after the K/V projection on those rows only (exact: all of it is row-wise); the other rows of out_last are
+   * left unwritten and only those rows of `dlast` are read.  NULL = every row. */
+  const int32_t* out_rows;
+  int32_t n_out_per_sample, reserved;
 } MmtBertBatch;
 
 int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc);

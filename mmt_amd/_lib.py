@@ -71,7 +71,8 @@ class MmtBertModel(ctypes.Structure):
 class MmtBertBatch(ctypes.Structure):
   _fields_ = ([(n, c_vp) for n in ('features', 'type_ids', 'pos_ids', 'mask_bias', 'cu_seqlens', 'row_index',
                                    'n_rows_dev', 'seed_dev')] +
-              [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')])
+              [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')] +
+              [('out_rows', c_vp), ('n_out_per_sample', ctypes.c_int32), ('reserved', ctypes.c_int32)])
 
 
 _PTR16 = c_vp * 16
@@ -120,6 +121,13 @@ SIGNATURES = {
                              c_f32, c_vp, c_vp]),
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
                              c_u32, c_u32, c_f32, c_vp, c_vp]),
+    'mmt_attn_fwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
+                                  c_f32, c_vp, c_vp]),
+    'mmt_attn_bwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                  c_f32, c_u32, c_u32, c_f32, c_vp, c_vp]),
+    'mmt_ln_fwd_scatter': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    'mmt_rows_gather': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_rows_scatter': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_attn_dropout_mask': (c_int, [c_vp, c_int, c_int, c_int, c_u32, c_u32, c_vp, c_vp]),
     'mmt_reduce_slabs_2d': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_colsum_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -114,10 +114,13 @@ class EngineBatch:
   """Device-side description of one minibatch for the engine (token rows may be packed)."""
 
   def __init__(self, features, type_ids, pos_ids, mask_bias, rows, batch, seq, cu_seqlens=None,
-               row_index=None, n_rows_dev=None):
+               row_index=None, n_rows_dev=None, out_rows=None, n_out_per_sample=0):
     self.features, self.type_ids, self.pos_ids, self.mask_bias = features, type_ids, pos_ids, mask_bias
     self.rows, self.batch, self.seq = rows, batch, seq
     self.cu_seqlens, self.row_index, self.n_rows_dev = cu_seqlens, row_index, n_rows_dev
+    # optional: the only rows of sequence_output the caller reads (int32 [batch * n_out_per_sample]); the last layer
+    # is then evaluated on those rows only and the other rows of the returned tensor are undefined
+    self.out_rows, self.n_out_per_sample = out_rows, n_out_per_sample
     self.save = False
 
 
@@ -275,6 +278,8 @@ class BertModel(nn.Module):
     b.n_rows_dev = batch.n_rows_dev.data_ptr() if batch.n_rows_dev is not None else None
     b.seed_dev = self._seed_dev.data_ptr()
     b.rows, b.rows_alloc, b.batch, b.seq = batch.rows, rows_alloc, batch.batch, batch.seq
+    if batch.out_rows is not None and batch.n_out_per_sample > 0:
+      b.out_rows, b.n_out_per_sample = batch.out_rows.data_ptr(), batch.n_out_per_sample
     return b
 
   def _workspace(self, rows_alloc, save, model_struct):

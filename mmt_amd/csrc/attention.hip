@@ -39,6 +39,20 @@ __device__ __forceinline__ void stage64x128(const bf16_t* __restrict__ G, int64_
   }
 }
 
+// same tile, rows gathered through an index list: row i of the tile = G[sel[min(i0 + i, n - 1)]]
+__device__ __forceinline__ void stage64x128_sel(const bf16_t* __restrict__ G, int64_t ld, const int32_t* __restrict__ sel,
+                                                int i0, int n, bf16_t* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rbase = (wave * 4 + i) * 4;
+    const int rr = rbase + (lane >> 4);
+    const int c = (lane & 15) ^ swz16(rr);
+    const int gr = sel[min(i0 + rr, n - 1)];
+    const bf16_t* src = G + (int64_t)gr * ld + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * 128), 16, 0, 0);
+  }
+}
+
 __device__ __forceinline__ bf16x8_t frag_b128(const bf16_t* tile, int r, int chunk) {
   return *(const bf16x8_t*)(tile + r * 128 + ((chunk ^ swz16(r)) << 3));
 }
@@ -81,6 +95,10 @@ struct AttnArgs {
   int H, d; float scale;
   uint32_t drop_key, thr16; float drop_scale; int S4;
   const uint32_t* seed_dev;
+  // Query subset (last encoder layer: only the rows that are read out need a context vector).  qsel[b*nq + i] is
+  // the row of sample b's i-th selected query; ctx / lse / dctx / delta are then COMPACT [B*nq, .] buffers, while
+  // qkv / dqkv keep the full token layout (every key still participates).
+  const int32_t* qsel; int nq;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -93,15 +111,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int q0 = blockIdx.x * 64;
-  if (q0 >= Sb) return;
+  const int nqs = a.qsel ? a.nq : Sb;  // queries of this sample
+  if (q0 >= nqs || Sb <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
   const int nkt = (Sb + 63) >> 6;
   const bf16_t* Kg = a.qkv + a.d + h * 128;
   const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
 
-  const int q_local = q0 + wave * 16 + li;
-  const int qrow = off + min(q_local, Sb - 1);
+  const int qi = q0 + wave * 16 + li;
+  const int qic = min(qi, nqs - 1);
+  const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
+  const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / lse
+  const int q_local = a.qsel ? qrow - off : qi;
   bf16x8_t qf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
@@ -177,15 +199,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 1, fd * 16, lane), pb1, o[fd], 0, 0, 0);
     }
   }
-  if (q_local < Sb) {
+  if (qi < nqs) {
     const float inv = 1.0f / l_run;
-    bf16_t* dst = a.ctx + (int64_t)qrow * a.ldc + h * 128 + 4 * lg;
+    bf16_t* dst = a.ctx + (int64_t)crow * a.ldc + h * 128 + 4 * lg;
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       u32x2 v = {pack_bf2(o[fd][0] * inv, o[fd][1] * inv), pack_bf2(o[fd][2] * inv, o[fd][3] * inv)};
       *(u32x2*)(dst + fd * 16) = v;
     }
-    if (lg == 0) a.lse[(int64_t)qrow * a.H + h] = (m_run + log2f(l_run)) * LN2;
+    if (lg == 0) a.lse[(int64_t)crow * a.H + h] = (m_run + log2f(l_run)) * LN2;
   }
 }
 
@@ -200,30 +222,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int q0 = blockIdx.x * 64;
-  if (q0 >= Sb) return;
+  const int nqs = a.qsel ? a.nq : Sb;
+  if (q0 >= nqs || Sb <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
   const int nkt = (Sb + 63) >> 6;
   const bf16_t* Kg = a.qkv + a.d + h * 128;
   const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
-  const int q_local = q0 + wave * 16 + li;
-  const bool q_ok = q_local < Sb;
-  const int qrow = off + min(q_local, Sb - 1);
+  const int qi = q0 + wave * 16 + li;
+  const bool q_ok = qi < nqs;
+  const int qic = min(qi, nqs - 1);
+  const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
+  const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / dctx / lse / delta
+  const int q_local = a.qsel ? qrow - off : qi;
   bf16x8_t qf[4], dof[4];
   float dl = 0.f;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
-    const u16x8 dv = *(const u16x8*)(a.dctx + (int64_t)qrow * a.ldc + h * 128 + kk * 32 + lg * 8);
-    const u16x8 ov = *(const u16x8*)(a.ctx + (int64_t)qrow * a.ldc + h * 128 + kk * 32 + lg * 8);
+    const u16x8 dv = *(const u16x8*)(a.dctx + (int64_t)crow * a.ldc + h * 128 + kk * 32 + lg * 8);
+    const u16x8 ov = *(const u16x8*)(a.ctx + (int64_t)crow * a.ldc + h * 128 + kk * 32 + lg * 8);
     dof[kk] = __builtin_bit_cast(bf16x8_t, dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dl += bf2f(dv[e]) * bf2f(ov[e]);
   }
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
-  if (q_ok && lg == 0) a.delta[(int64_t)qrow * a.H + h] = dl;
-  const float lse2 = a.lse[(int64_t)qrow * a.H + h] * LOG2E;
+  if (q_ok && lg == 0) a.delta[(int64_t)crow * a.H + h] = dl;
+  const float lse2 = a.lse[(int64_t)crow * a.H + h] * LOG2E;
   const unsigned rowkey = attn_rowkey(eff_key(a.drop_key, a.seed_dev), (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
   const float c1 = a.scale * LOG2E;
 
@@ -305,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   if (k0 >= Sb) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
-  const int nqt = (Sb + 63) >> 6;
+  const int nqs = a.qsel ? a.nq : Sb;
+  const int nqt = (nqs + 63) >> 6;
   const bf16_t* Qg = a.qkv + h * 128;
   const bf16_t* dOg = a.dctx + h * 128;
   const int key_local = k0 + wave * 16 + li;
@@ -328,15 +355,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   auto stage = [&](int qt, int st) {
     bf16_t* base = smem + st * (2 * 64 * 128);
-    stage64x128(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
-    stage64x128(dOg, a.ldc, off + qt * 64, row_last, base + 64 * 128, wave, lane);
+    if (a.qsel) {
+      stage64x128_sel(Qg, a.ld, a.qsel + b * a.nq, qt * 64, a.nq, base, wave, lane);
+      stage64x128(dOg, a.ldc, b * a.nq + qt * 64, b * a.nq + a.nq - 1, base + 64 * 128, wave, lane);
+    } else {
+      stage64x128(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
+      stage64x128(dOg, a.ldc, off + qt * 64, row_last, base + 64 * 128, wave, lane);
+    }
     if (tid < 64) {
       const int q = qt * 64 + tid;
-      const int row = off + min(q, Sb - 1);
+      const int qc = min(q, nqs - 1);
+      const int row = a.qsel ? b * a.nq + qc : off + qc;               // row in lse / delta
+      const int qpos = a.qsel ? a.qsel[b * a.nq + qc] - off : q;       // position inside the sample (RNG coordinate)
       float* ax = aux_s + st * 192;
-      ax[tid] = q < Sb ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
+      ax[tid] = q < nqs ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
       ax[64 + tid] = a.delta[(int64_t)row * a.H + h];
-      ax[128 + tid] = __uint_as_float(attn_rowkey(dkey, bh, (unsigned)a.S4, (unsigned)q));
+      ax[128 + tid] = __uint_as_float(attn_rowkey(dkey, bh, (unsigned)a.S4, (unsigned)qpos));
     }
   };
   stage(0, 0);
@@ -445,6 +479,41 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   const dim3 grid((S + 63) / 64, H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// Query-subset variants: only the rows qsel[b*nq + i] act as queries (all rows of a sample remain keys/values).
+// ctx / lse / dctx / delta are compact [B*nq, .]; dqkv is the full [rows, 3d] buffer and must be ZERO on entry for the
+// Q section of non-selected rows (the kernels write dQ of the selected rows and dK / dV of every row).
+extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel,
+                                 int nq, void* ctx, float* lse, int B, int S, int H, int d, float scale,
+                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
+                                 void* stream) {
+  if (int e = check_args(qkv, B, S, H, d)) return e;
+  if (!mask_bias || !ctx || !lse || !qsel || nq <= 0) return MMT_ERR_ARG;
+  AttnArgs a = {};
+  a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.qsel = qsel; a.nq = nq;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel,
+                                 int nq, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta,
+                                 int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
+                                 float drop_scale, const uint32_t* seed_dev, void* stream) {
+  if (int e = check_args(qkv, B, S, H, d)) return e;
+  if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta || !qsel || nq <= 0) return MMT_ERR_ARG;
+  AttnArgs a = {};
+  a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
+  a.delta = delta; a.H = H; a.d = d; a.scale = scale;
+  a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.qsel = qsel; a.nq = nq;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

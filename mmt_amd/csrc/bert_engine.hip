@@ -15,7 +15,15 @@ struct LayerWs {
   char *qkv, *ctx, *a16, *hpre, *g, *h16;
   float *lse, *z1, *mean1, *rstd1, *a32, *z2, *mean2, *rstd2, *h32;
 };
+// Compact buffers of the last layer when only `out_rows` are needed (rows_c = B * n_out_per_sample).
+struct TailWs {
+  char *ctx, *a16, *hpre, *g, *dy2, *dy, *dhpre, *dctx;
+  float *lse, *res32, *z1, *mean1, *rstd1, *a32, *z2, *mean2, *rstd2, *dcur, *dz, *dA, *delta;
+  int32_t* rowidx;
+  int cap;  // rows the buffers can hold
+};
 struct Ws {
+  TailWs t;
   float *z0, *mean0, *rstd0, *h32_in;
   char* h16_in;
   LayerWs layer[64];
@@ -47,6 +55,18 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   const size_t rpb = (size_t)mmt_ln_bwd_rows_per_block();
   for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
   const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
+  {  // tail buffers: B*M read-out rows are at most a quarter of the token rows for T >= 3 (else: full path)
+    const size_t C = ((size_t)R / 4 + 255) & ~(size_t)255;
+    TailWs& t = w->t;
+    t.cap = (int)C;
+    t.ctx = take(C * d * 2); t.a16 = take(C * d * 2); t.hpre = take(C * I * 2); t.g = take(C * I * 2);
+    t.dy2 = take(C * d * 2); t.dy = take(C * d * 2); t.dhpre = take(C * I * 2); t.dctx = take(C * d * 2);
+    t.lse = (float*)take(C * H * 4); t.res32 = (float*)take(C * d * 4); t.z1 = (float*)take(C * d * 4);
+    t.mean1 = (float*)take(C * 4); t.rstd1 = (float*)take(C * 4); t.a32 = (float*)take(C * d * 4);
+    t.z2 = (float*)take(C * d * 4); t.mean2 = (float*)take(C * 4); t.rstd2 = (float*)take(C * 4);
+    t.dcur = (float*)take(C * d * 4); t.dz = (float*)take(C * d * 4); t.dA = (float*)take(C * d * 4);
+    t.delta = (float*)take(C * H * 4); t.rowidx = (int32_t*)take(C * 4);
+  }
   for (int i = 0; i < 2; ++i) w->table_scratch[i] = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
   w->bytes = off;
 }
@@ -68,6 +88,13 @@ hipEvent_t* g_probe_stop = nullptr;
 int g_probe_n = 0, g_probe_i = 0;
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// rows of the compact last layer, or 0 when the full path must be used
+int tail_rows(const MmtBertBatch* b, const Ws& w) {
+  if (!b->out_rows || b->n_out_per_sample <= 0) return 0;
+  const long n = (long)b->batch * b->n_out_per_sample;
+  return (n > 0 && n <= w.t.cap) ? (int)n : 0;
+}
 
 }  // namespace
 
@@ -103,12 +130,37 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
                        b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
   const float* hin32 = w.h32_in;
   const char* hin16 = w.h16_in;
+  const int nc = tail_rows(b, w);
   for (int l = 0; l < m->layers; ++l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     MmtEpilogue e = {};
     e.bias = P.bqkv;
     TRY(mmt_gemm_nt_bf16(hin16, d, P.wqkv, d, L.qkv, 3 * d, rows, 3 * d, d, MMT_EPI_BIAS_BF16, &e, b->n_rows_dev, stream));
+    if (nc && l == m->layers - 1) {
+      // ---- last layer, read-out rows only: everything after the K/V projection is row-wise, so only the nc rows
+      // the caller reads are computed (as queries against ALL keys).  RNG coordinates travel in t.rowidx, so the
+      // dropout masks are the ones the full path would draw. ----
+      TailWs& t = w.t;
+      TRY(mmt_rows_gather(hin32, b->out_rows, nc, d, t.res32, b->row_index, t.rowidx, stream));
+      TRY(mmt_attn_fwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, b->batch,
+                            b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+      e = {};
+      e.bias = P.bo; e.res = t.res32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
+      e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
+      TRY(mmt_gemm_nt_bf16(t.ctx, d, P.wo, d, t.z1, d, nc, d, d, MMT_EPI_BIAS_DROP_RES, &e, nullptr, stream));
+      TRY(mmt_ln_fwd(t.z1, P.ln1_g, P.ln1_b, m->ln_eps, t.a32, t.a16, t.mean1, t.rstd1, nc, d, nullptr, stream));
+      e = {};
+      e.bias = P.b1; e.out2 = t.g; e.ldout2 = I;
+      TRY(mmt_gemm_nt_bf16(t.a16, d, P.w1, d, t.hpre, I, nc, I, d, MMT_EPI_BIAS_GELU, &e, nullptr, stream));
+      e = {};
+      e.bias = P.b2; e.res = t.a32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
+      e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
+      TRY(mmt_gemm_nt_bf16(t.g, I, P.w2, I, t.z2, d, nc, d, I, MMT_EPI_BIAS_DROP_RES, &e, nullptr, stream));
+      TRY(mmt_ln_fwd_scatter(t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, b->out_rows, nullptr, t.mean2, t.rstd2, nc, d,
+                             stream));
+      break;
+    }
     TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
                      site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
     e = {};
@@ -156,11 +208,58 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     j = {};
     j.partials = partials; j.nblocks = nblocks; j.nvec = nvec; j.nout = nout; j.d = dd; j.out[0] = o0; j.out[1] = o1;
   };
+  const int nc = tail_rows(b, w);
   float* dcur = dlast;  // gradient wrt the current layer's output
   for (int l = m->layers - 1; l >= 0; --l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
+    if (nc && l == m->layers - 1) {
+      // ---- last layer on the nc read-out rows only (mirror of the forward tail) ----
+      TailWs& t = w.t;
+      const int cblocks = (nc + rpb - 1) / rpb;
+      TRY(mmt_rows_gather(dlast, b->out_rows, nc, d, t.dcur, nullptr, nullptr, stream));
+      TRY(mmt_ln_bwd(t.dcur, t.z2, t.mean2, t.rstd2, P.ln2_g, t.dz, t.dy2, w.ln_partials[2 * l + 2], nc, d, 1, nullptr,
+                     t.rowidx, site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
+      add_job(w.ln_partials[2 * l + 2], cblocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
+      MmtEpilogue e = {};
+      e.aux = t.hpre; e.ldaux = I;
+      TRY(mmt_gemm_nt_bf16(t.dy2, d, P.w2_t, d, t.dhpre, I, nc, I, d, MMT_EPI_DGELU, &e, nullptr, stream));
+      e = {};
+      e.res = t.dz; e.ldres = d;
+      TRY(mmt_gemm_nt_bf16(t.dhpre, I, P.w1_t, I, t.dA, d, nc, d, I, MMT_EPI_ADD_F32, &e, nullptr, stream));
+      TRY(mmt_ln_bwd(t.dA, t.z1, t.mean1, t.rstd1, P.ln1_g, t.dz, t.dy, w.ln_partials[2 * l + 1], nc, d, 1, nullptr,
+                     t.rowidx, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+      add_job(w.ln_partials[2 * l + 1], cblocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
+      e = {};
+      TRY(mmt_gemm_nt_bf16(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, nullptr, stream));
+      // dQ exists for the read-out rows only; the residual gradient (t.dz) likewise: zero-fill, then scatter
+      if (hipMemsetAsync(w.dqkv, 0, (size_t)b->rows_alloc * 3 * d * 2, (hipStream_t)stream) != hipSuccess) return MMT_ERR_ARG;
+      TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
+                            w.dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
+                            b->seed_dev, stream));
+      if (hipMemsetAsync(w.dz, 0, (size_t)b->rows_alloc * d * 4, (hipStream_t)stream) != hipSuccess) return MMT_ERR_ARG;
+      TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, w.dz, stream));
+      e = {};
+      e.res = w.dz; e.ldres = d;
+      float* dnext = w.dA;
+      TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+      {
+        MmtWgradGroup g = {};
+        g.count = 4; g.rows = rows; g.n_rows_dev = nr;
+        g.item[0].A = w.dqkv;  g.item[0].lda = 3 * d; g.item[0].B = hin16; g.item[0].ldb = d; g.item[0].N = 3 * d; g.item[0].K2 = d;
+        g.item[0].out = P.g_wqkv; g.item[0].bias_out = P.g_bqkv;
+        g.item[1].A = t.dhpre; g.item[1].lda = I;     g.item[1].B = t.a16; g.item[1].ldb = d; g.item[1].N = I;     g.item[1].K2 = d;
+        g.item[1].out = P.g_w1;   g.item[1].bias_out = P.g_b1; g.item[1].reserved = nc;
+        g.item[2].A = t.dy2;   g.item[2].lda = d;     g.item[2].B = t.g;   g.item[2].ldb = I; g.item[2].N = d;     g.item[2].K2 = I;
+        g.item[2].out = P.g_w2;   g.item[2].bias_out = P.g_b2; g.item[2].reserved = nc;
+        g.item[3].A = t.dy;    g.item[3].lda = d;     g.item[3].B = t.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
+        g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo; g.item[3].reserved = nc;
+        TRY(mmt_wgrad_grouped(&g, stream));
+      }
+      dcur = dnext;
+      continue;
+    }
     // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
     TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   const int tiles_k = it.K2 / 128;
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
-  const int nrows = g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows;
+  // item.reserved > 0: this item contracts over exactly that many rows (compact last-layer buffers)
+  const int nrows = it.reserved > 0 ? it.reserved : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
   const int units = (nrows + 63) / 64;     // 64-row units of the contraction
   const int steps = (units + 1) / 2;       // each step: group 0 takes unit 2s, group 1 unit 2s+1
 

@@ -19,12 +19,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ h32,
     bf16_t* __restrict__ h16, float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
     const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
-    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
+    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev, const int32_t* __restrict__ dst_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int nch = d >> 8;
   const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int64_t hrow = dst_rows ? dst_rows[row] : row;  // where the fp32 output row goes (scatter to token rows)
     f32x4 x[MAXC];
     float s = 0.f;
 #pragma unroll
@@ -67,9 +68,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
             for (int k = 0; k < 4; ++k) y[k] = kp[k] ? y[k] * drop_scale : 0.f;
           }
         }
-        if (h32) *(f32x4*)(h32 + (int64_t)row * d + col) = y;
+        if (h32) *(f32x4*)(h32 + hrow * d + col) = y;
         u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-        *(u32x2*)(h16 + (int64_t)row * d + col) = o;
+        if (h16) *(u32x2*)(h16 + (int64_t)row * d + col) = o;
       }
   }
 }
@@ -280,7 +281,48 @@ extern "C" int mmt_ln_fwd(const float* z, const float* gamma, const float* beta,
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
                      nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f, nullptr);
+                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+// h = LN(z) for a compact set of rows; the fp32 result row i is written to h32[dst_rows[i]] (h16 stays compact, nullable)
+extern "C" int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, float eps, float* h32,
+                                  const int32_t* dst_rows, void* h16, float* mean, float* rstd, int rows, int d,
+                                  void* stream) {
+  if (!z || !gamma || !beta || !h32 || !dst_rows || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
+                     rstd, rows, d, nullptr, nullptr, 0u, 0u, 1.0f, nullptr, dst_rows);
+  return (int)hipGetLastError();
+}
+
+// dst[i] = src[rows[i]] (gather) / dst[rows[i]] = src[i] (scatter), fp32 rows of d floats; idx_out[i] = idx_in ?
+// idx_in[rows[i]] : rows[i] (gather only, nullable) carries the RNG row coordinates along.
+__global__ __launch_bounds__(256) void row_move_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       const int32_t* __restrict__ rows, int n, int d, int scatter,
+                                                       const int32_t* __restrict__ idx_in, int32_t* __restrict__ idx_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const int64_t r = rows[i];
+    const float* s = scatter ? src + (int64_t)i * d : src + r * d;
+    float* t = scatter ? dst + r * d : dst + (int64_t)i * d;
+    for (int c = lane * 4; c < d; c += 256) *(f32x4*)(t + c) = *(const f32x4*)(s + c);
+    if (!scatter && idx_out && lane == 0) idx_out[i] = idx_in ? idx_in[r] : (int32_t)r;
+  }
+}
+
+extern "C" int mmt_rows_gather(const float* src, const int32_t* rows, int n, int d, float* dst, const int32_t* idx_in,
+                               int32_t* idx_out, void* stream) {
+  if (!src || !rows || !dst || n <= 0 || d <= 0 || (d & 3)) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(row_move_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, dst, rows, n, d, 0, idx_in,
+                     idx_out);
+  return (int)hipGetLastError();
+}
+extern "C" int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, void* stream) {
+  if (!src || !rows || !dst || n <= 0 || d <= 0 || (d & 3)) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(row_move_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, dst, rows, n, d, 1, nullptr,
+                     nullptr);
   return (int)hipGetLastError();
 }
 
@@ -296,7 +338,7 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, features,
                      type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev);
+                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev, nullptr);
   return (int)hipGetLastError();
 }
 

@@ -255,6 +255,8 @@ class CENet(nn.Module):
     self.vid_bert_params = vid_bert_params
     self.normalize_experts = normalize_experts
     self.pack_tokens = pack_tokens
+    # the read-out only uses the AGG rows (model.py:583-587): let the last layer compute just those (exact)
+    self.tail_rows_only = True
     unsupported = []
     if vid_cont != 'bert': unsupported.append('vid_cont=%r' % vid_cont)
     if vid_inp != 'both': unsupported.append('vid_inp=%r' % vid_inp)
@@ -435,7 +437,8 @@ class CENet(nn.Module):
     feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
     batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
                         plan.rows, bsz, plan.seq, cu_seqlens=plan.cu, row_index=plan.row_index,
-                        n_rows_dev=plan.n_rows if self.pack_tokens else None)
+                        n_rows_dev=plan.n_rows if self.pack_tokens else None,
+                        out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
     last = self.vid_bert.run_engine(batch, feats)
     vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
     return vid.view(bsz, len(mods), self.same_dim)
