@@ -72,6 +72,13 @@ int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
                      int M, int N, int K, int epilogue, const MmtEpilogue* epi,
                      const int32_t* n_rows_dev, void* stream);
 
+/* Split-K form for skinny problems (M up to a few hundred rows, long K): K-slices run as independent blocks writing fp32
+ * partial slabs into `ws`, a second kernel sums them in a fixed order and applies the epilogue
+ * (MMT_EPI_BF16 / F32 / BIAS_F32 / ADD_F32 / BIAS_DROP_RES).  Same results as mmt_gemm_nt_bf16 up to fp32 summation order. */
+int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K);
+int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       int epilogue, const MmtEpilogue* epi, float* ws, void* stream);
+
 /* Several independent C_i[M_i,N_i] = A_i . B_i^T (+ bias_i) in ONE launch (epilogue MMT_EPI_BIAS_F32 / MMT_EPI_F32):
  * the per-expert ReduceDim.fc projections of model/model.py:426-437 (seven GEMMs with different K). */
 #define MMT_GEMM_GROUP_MAX 16
@@ -105,6 +112,9 @@ typedef struct MmtWgradItem {
   int64_t lda, ldb, ldo;
   int32_t N, K2, N_out, K2_out, tile_begin;
   int32_t reserved; /* > 0: this item contracts over exactly `reserved` rows (overrides rows / n_rows_dev)     */
+  float* slab;      /* splits > 1: partial results [splits][N_out, ldo] (summed by the caller, e.g.            */
+  float* bias_slab; /*   mmt_col_reduce_multi) and partial bias gradients [splits][N_out]                       */
+  int32_t splits, reserved2;
 } MmtWgradItem;
 typedef struct MmtWgradGroup {
   MmtWgradItem item[MMT_WGRAD_MAX];
@@ -134,14 +144,15 @@ int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32
 /* Compact-row variant: LN over `rows` compact rows; fp32 row i goes to h32[dst_rows[i]] (h16 compact, nullable). */
 int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, float eps, float* h32,
                        const int32_t* dst_rows, void* h16, float* mean, float* rstd, int rows, int d, void* stream);
-/* dst[i] = src[rows[i]] (+ idx_out[i] = idx_in ? idx_in[rows[i]] : rows[i]) / dst[rows[i]] = src[i]; fp32 rows of d. */
+/* dst[i] = src[rows[i]] (+ idx_out[i] = idx_in ? idx_in[rows[i]] : rows[i]) / dst[rows[i]] (+)= src[i]; fp32 rows of d
+ * (rows must be distinct for the accumulating scatter). */
 int mmt_rows_gather(const float* src, const int32_t* rows, int n, int d, float* dst, const int32_t* idx_in,
                     int32_t* idx_out, void* stream);
-int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, void* stream);
+int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, int accumulate, void* stream);
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
  * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */
-int mmt_ln_bwd_rows_per_block(void);
+int mmt_ln_bwd_rows_per_block(int rows);
 int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd, const float* gamma,
                float* dz, void* dy, float* partials, int rows, int d, int drop_mode,
                const int32_t* n_rows_dev, const int32_t* row_index, uint32_t drop_key, uint32_t thr16,

@@ -32,7 +32,8 @@ class MmtGemmItem(ctypes.Structure):
 class MmtWgradItem(ctypes.Structure):
   _fields_ = [('A', c_vp), ('B', c_vp), ('out', c_vp), ('bias_out', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldo', c_i64),
               ('N', ctypes.c_int32), ('K2', ctypes.c_int32), ('N_out', ctypes.c_int32), ('K2_out', ctypes.c_int32),
-              ('tile_begin', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+              ('tile_begin', ctypes.c_int32), ('reserved', ctypes.c_int32), ('slab', c_vp), ('bias_slab', c_vp),
+              ('splits', ctypes.c_int32), ('reserved2', ctypes.c_int32)]
 
 
 class MmtWgradGroup(ctypes.Structure):
@@ -102,13 +103,16 @@ SIGNATURES = {
     'mmt_gemm_nt_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
     'mmt_gemm_tn_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_gemm_nt_splitk_workspace_floats': (c_i64, [c_int, c_int, c_int]),
+    'mmt_gemm_nt_splitk': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
+                                   ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
     'mmt_gemm_nt_grouped': (c_int, [ctypes.POINTER(MmtGemmItem), c_int, c_int, c_vp]),
     'mmt_wgrad_grouped': (c_int, [ctypes.POINTER(MmtWgradGroup), c_vp]),
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                  c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
-    'mmt_ln_bwd_rows_per_block': (c_int, []),
+    'mmt_ln_bwd_rows_per_block': (c_int, [c_int]),
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                            c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -127,7 +131,7 @@ SIGNATURES = {
                                   c_f32, c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_ln_fwd_scatter': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mmt_rows_gather': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    'mmt_rows_scatter': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'mmt_rows_scatter': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_attn_dropout_mask': (c_int, [c_vp, c_int, c_int, c_int, c_u32, c_u32, c_vp, c_vp]),
     'mmt_reduce_slabs_2d': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_colsum_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -235,6 +235,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
   const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / dctx / lse / delta
   const int q_local = a.qsel ? qrow - off : qi;
+  if (a.qsel && blockIdx.x == 0) {
+    // query-subset mode: dQ of the non-selected rows is zero -- this block (sample b, head h) clears its 128 columns
+    // of every row of the sample; the selected rows are overwritten at the end (after the K-loop's barriers)
+    for (int e = tid; e < Sb * 16; e += 256) {
+      u32x4 z = {0, 0, 0, 0};
+      *(u32x4*)(a.dqkv + (int64_t)(off + (e >> 4)) * a.ld + h * 128 + (e & 15) * 8) = z;
+    }
+  }
   bf16x8_t qf[4], dof[4];
   float dl = 0.f;
 #pragma unroll

@@ -15,11 +15,16 @@ struct LayerWs {
   char *qkv, *ctx, *a16, *hpre, *g, *h16;
   float *lse, *z1, *mean1, *rstd1, *a32, *z2, *mean2, *rstd2, *h32;
 };
+// In the compact last layer only the QKV weight gradient still contracts over every token row: its tiles are split
+// TAIL_WSPLIT ways over the rows so that they do not outlast the (short) other items of the grouped launch.
+constexpr int TAIL_WSPLIT = 4;
 // Compact buffers of the last layer when only `out_rows` are needed (rows_c = B * n_out_per_sample).
 struct TailWs {
   char *ctx, *a16, *hpre, *g, *dy2, *dy, *dhpre, *dctx;
   float *lse, *res32, *z1, *mean1, *rstd1, *a32, *z2, *mean2, *rstd2, *dcur, *dz, *dA, *delta;
   int32_t* rowidx;
+  float* slabs;  // split-K partials of the skinny long-K GEMMs
+  float *wslab, *bslab;  // split partials of the last layer's QKV weight / bias gradient
   int cap;  // rows the buffers can hold
 };
 struct Ws {
@@ -52,8 +57,10 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
   w->dy = take(R * d * 2); w->dy2 = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
   w->delta = (float*)take(R * H * 4);
-  const size_t rpb = (size_t)mmt_ln_bwd_rows_per_block();
-  for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(((R + rpb - 1) / rpb) * 3 * d * 4);
+  size_t ln_nb = ((size_t)R + 15) / 16;  // blocks of mmt_ln_bwd: rows/16, or rows/4 when rows <= 2048
+  const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
+  if (ln_nb < small_nb) ln_nb = small_nb;
+  for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(ln_nb * 3 * d * 4);
   const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
   {  // tail buffers: B*M read-out rows are at most a quarter of the token rows for T >= 3 (else: full path)
     const size_t C = ((size_t)R / 4 + 255) & ~(size_t)255;
@@ -66,6 +73,8 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     t.z2 = (float*)take(C * d * 4); t.mean2 = (float*)take(C * 4); t.rstd2 = (float*)take(C * 4);
     t.dcur = (float*)take(C * d * 4); t.dz = (float*)take(C * d * 4); t.dA = (float*)take(C * d * 4);
     t.delta = (float*)take(C * H * 4); t.rowidx = (int32_t*)take(C * 4);
+    t.wslab = (float*)take((size_t)TAIL_WSPLIT * 3 * d * d * 4); t.bslab = (float*)take((size_t)TAIL_WSPLIT * 3 * d * 4);
+    t.slabs = (float*)take((size_t)mmt_gemm_nt_splitk_workspace_floats((int)C, (int)d, (int)I) * 4);
   }
   for (int i = 0; i < 2; ++i) w->table_scratch[i] = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
   w->bytes = off;
@@ -148,7 +157,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       e = {};
       e.bias = P.bo; e.res = t.res32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
       e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-      TRY(mmt_gemm_nt_bf16(t.ctx, d, P.wo, d, t.z1, d, nc, d, d, MMT_EPI_BIAS_DROP_RES, &e, nullptr, stream));
+      TRY(mmt_gemm_nt_splitk(t.ctx, d, P.wo, d, t.z1, d, nc, d, d, MMT_EPI_BIAS_DROP_RES, &e, t.slabs, stream));
       TRY(mmt_ln_fwd(t.z1, P.ln1_g, P.ln1_b, m->ln_eps, t.a32, t.a16, t.mean1, t.rstd1, nc, d, nullptr, stream));
       e = {};
       e.bias = P.b1; e.out2 = t.g; e.ldout2 = I;
@@ -156,7 +165,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       e = {};
       e.bias = P.b2; e.res = t.a32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
       e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-      TRY(mmt_gemm_nt_bf16(t.g, I, P.w2, I, t.z2, d, nc, d, I, MMT_EPI_BIAS_DROP_RES, &e, nullptr, stream));
+      TRY(mmt_gemm_nt_splitk(t.g, I, P.w2, I, t.z2, d, nc, d, I, MMT_EPI_BIAS_DROP_RES, &e, t.slabs, stream));
       TRY(mmt_ln_fwd_scatter(t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, b->out_rows, nullptr, t.mean2, t.rstd2, nc, d,
                              stream));
       break;
@@ -196,12 +205,12 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
   const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
   const float sh = scale_of(th), sa = scale_of(ta);
   const float qk_scale = 0.08838834764831845f;
-  const int rpb = mmt_ln_bwd_rows_per_block();
+  const int rpb = mmt_ln_bwd_rows_per_block(rows);
   const int ln_blocks = (rows + rpb - 1) / rpb;
   const int32_t* nr = b->n_rows_dev;
 
   // LayerNorm gamma/beta and embedding-table partial sums stay in per-site buffers; ONE batched reduction at the end
-  MmtColReduceJob jobs[2 * 64 + 3];
+  MmtColReduceJob jobs[2 * 64 + 5];
   int njobs = 0;
   auto add_job = [&](const float* partials, int nblocks, int nvec, int nout, int dd, float* o0, float* o1) {
     MmtColReduceJob& j = jobs[njobs++];
@@ -217,7 +226,8 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     if (nc && l == m->layers - 1) {
       // ---- last layer on the nc read-out rows only (mirror of the forward tail) ----
       TailWs& t = w.t;
-      const int cblocks = (nc + rpb - 1) / rpb;
+      const int crpb = mmt_ln_bwd_rows_per_block(nc);
+      const int cblocks = (nc + crpb - 1) / crpb;
       TRY(mmt_rows_gather(dlast, b->out_rows, nc, d, t.dcur, nullptr, nullptr, stream));
       TRY(mmt_ln_bwd(t.dcur, t.z2, t.mean2, t.rstd2, P.ln2_g, t.dz, t.dy2, w.ln_partials[2 * l + 2], nc, d, 1, nullptr,
                      t.rowidx, site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
@@ -227,28 +237,29 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
       TRY(mmt_gemm_nt_bf16(t.dy2, d, P.w2_t, d, t.dhpre, I, nc, I, d, MMT_EPI_DGELU, &e, nullptr, stream));
       e = {};
       e.res = t.dz; e.ldres = d;
-      TRY(mmt_gemm_nt_bf16(t.dhpre, I, P.w1_t, I, t.dA, d, nc, d, I, MMT_EPI_ADD_F32, &e, nullptr, stream));
+      TRY(mmt_gemm_nt_splitk(t.dhpre, I, P.w1_t, I, t.dA, d, nc, d, I, MMT_EPI_ADD_F32, &e, t.slabs, stream));
       TRY(mmt_ln_bwd(t.dA, t.z1, t.mean1, t.rstd1, P.ln1_g, t.dz, t.dy, w.ln_partials[2 * l + 1], nc, d, 1, nullptr,
                      t.rowidx, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
       add_job(w.ln_partials[2 * l + 1], cblocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
       e = {};
-      TRY(mmt_gemm_nt_bf16(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, nullptr, stream));
-      // dQ exists for the read-out rows only; the residual gradient (t.dz) likewise: zero-fill, then scatter
-      if (hipMemsetAsync(w.dqkv, 0, (size_t)b->rows_alloc * 3 * d * 2, (hipStream_t)stream) != hipSuccess) return MMT_ERR_ARG;
+      TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));
+      // dQ exists for the read-out rows only (the dq kernel zero-fills the rest of the Q section); the residual
+      // gradient t.dz likewise: the input-gradient GEMM runs without residual and t.dz is scatter-added afterwards
       TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
                             w.dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
                             b->seed_dev, stream));
-      if (hipMemsetAsync(w.dz, 0, (size_t)b->rows_alloc * d * 4, (hipStream_t)stream) != hipSuccess) return MMT_ERR_ARG;
-      TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, w.dz, stream));
       e = {};
-      e.res = w.dz; e.ldres = d;
       float* dnext = w.dA;
-      TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+      TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
+      TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, dnext, 1, stream));
       {
         MmtWgradGroup g = {};
         g.count = 4; g.rows = rows; g.n_rows_dev = nr;
         g.item[0].A = w.dqkv;  g.item[0].lda = 3 * d; g.item[0].B = hin16; g.item[0].ldb = d; g.item[0].N = 3 * d; g.item[0].K2 = d;
         g.item[0].out = P.g_wqkv; g.item[0].bias_out = P.g_bqkv;
+        g.item[0].splits = TAIL_WSPLIT; g.item[0].slab = t.wslab; g.item[0].bias_slab = t.bslab;
+        add_job(t.wslab, TAIL_WSPLIT, 1, 1, 3 * d * d, P.g_wqkv, nullptr);
+        add_job(t.bslab, TAIL_WSPLIT, 1, 1, 3 * d, P.g_bqkv, nullptr);
         g.item[1].A = t.dhpre; g.item[1].lda = I;     g.item[1].B = t.a16; g.item[1].ldb = d; g.item[1].N = I;     g.item[1].K2 = d;
         g.item[1].out = P.g_w1;   g.item[1].bias_out = P.g_b1; g.item[1].reserved = nc;
         g.item[2].A = t.dy2;   g.item[2].lda = d;     g.item[2].B = t.g;   g.item[2].ldb = I; g.item[2].N = d;     g.item[2].K2 = I;

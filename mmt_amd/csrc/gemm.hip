@@ -309,13 +309,18 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   const bf16_t* __restrict__ A = (const bf16_t*)it.A;
   const bf16_t* __restrict__ B = (const bf16_t*)it.B;
   const int64_t lda = it.lda, ldb = it.ldb;
-  const int tile = id - it.tile_begin;
+  const int nsplit = it.splits > 1 ? it.splits : 1;
+  const int tile = (id - it.tile_begin) / nsplit, split = (id - it.tile_begin) % nsplit;
   const int tiles_k = it.K2 / 128;
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   // item.reserved > 0: this item contracts over exactly that many rows (compact last-layer buffers)
   const int nrows = it.reserved > 0 ? it.reserved : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
-  const int units = (nrows + 63) / 64;     // 64-row units of the contraction
+  const int units_all = (nrows + 63) / 64;  // 64-row units of the contraction
+  // item.splits > 1: the units are divided among `splits` blocks per tile, each writing its own partial slab
+  const int per_split = (units_all + nsplit - 1) / nsplit;
+  const int u0 = split * per_split;
+  const int units = max(0, min(units_all, u0 + per_split) - u0);
   const int steps = (units + 1) / 2;       // each step: group 0 takes unit 2s, group 1 unit 2s+1
 
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
@@ -340,8 +345,8 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
     const int unit = 2 * step + kg;
     if (unit < units) {
       bf16_t* base = smem + st * TSTAGE + kg * GSTAGE;
-      stage_tn(A, lda, unit * 64, n0, base, wave, lane);
-      stage_tn(B, ldb, unit * 64, k0, base + 64 * 128, wave, lane);
+      stage_tn(A, lda, (u0 + unit) * 64, n0, base, wave, lane);
+      stage_tn(B, ldb, (u0 + unit) * 64, k0, base + 64 * 128, wave, lane);
     }
   };
   if (steps > 0) stage(0, 0);
@@ -353,8 +358,8 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
     const int unit = 2 * s + kg;
     bf16_t* at = smem + cur * TSTAGE + kg * GSTAGE;
     bf16_t* bt = at + 64 * 128;
-    const int live = nrows - unit * 64;       // rows of this unit that exist (<= 0: nothing to do)
-    if (2 * s + 1 >= units || nrows - (2 * s + 1) * 64 < 64) {  // last step: ragged tails (block-uniform condition)
+    const int live = unit < units ? nrows - (u0 + unit) * 64 : 0;  // rows of this unit that exist (<= 0: nothing to do)
+    if (2 * s + 1 >= units || nrows - (u0 + 2 * s + 1) * 64 < 64) {  // last step: ragged tails (block-uniform condition)
       if (live > 0 && live < 64) {
         for (int e = wave * 64 + lane; e < (64 - live) * 32; e += 256) {
           const int r = live + e / 32, q = e % 32;
@@ -405,7 +410,8 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
     for (int j = 0; j < 4; ++j) acc[i][j] += xch[(i * 4 + j) * 256 + t4];
     accb[i] += xch[(16 + i) * 256 + t4];
   }
-  float* __restrict__ out = it.out;
+  float* __restrict__ out = nsplit > 1 ? it.slab + (int64_t)split * it.N_out * it.ldo : it.out;
+  float* __restrict__ bias_out = nsplit > 1 ? (it.bias_slab ? it.bias_slab + (int64_t)split * it.N_out : nullptr) : it.bias_out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wm * 64 + i * 16 + li;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
           if (k2 + e < it.K2_out) out[(int64_t)n * it.ldo + k2 + e] = acc[i][j][e];
       }
     }
-    if (want_bias && lg == 0) it.bias_out[n] = accb[i][0];
+    if (want_bias && lg == 0) bias_out[n] = accb[i][0];
   }
 }
 
@@ -437,8 +443,9 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
     if (it.N_out <= 0 || it.N_out > it.N) it.N_out = it.N;
     if (it.K2_out <= 0 || it.K2_out > it.K2) it.K2_out = it.K2;
     if (it.ldo <= 0) it.ldo = it.K2_out;
+    if (it.splits > 1 && (!it.slab || (it.bias_out && !it.bias_slab))) return MMT_ERR_ARG;
     it.tile_begin = tiles;
-    tiles += (it.N / 128) * (it.K2 / 128);
+    tiles += (it.N / 128) * (it.K2 / 128) * (it.splits > 1 ? it.splits : 1);
   }
   constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;  // 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
   static bool configured = false;

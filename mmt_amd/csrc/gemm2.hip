@@ -306,6 +306,99 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
                                         (int)gridDim.x);
 }
 
+// Split-K for skinny problems (few output tiles, long K: the last layer's read-out rows): blockIdx.y = K-slice, every
+// slice writes a raw fp32 partial tile into its own slab; splitk_epilogue_kernel sums the slabs in a fixed order and
+// applies the epilogue.  A 16-tile x 48-K-step GEMM is otherwise one 40 us chain of dependent K-steps.
+template <int BM, int BN, int WGM, int WGN, int NS>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ ws,
+    int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk) {
+  const int z = blockIdx.y;
+  const int kb = z * kchunk;
+  const int kl = min(kchunk, K - kb);
+  MmtEpilogue e = {};
+  gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32>(A + kb, lda, B + kb, ldb, ws + (int64_t)z * slab_stride, ldws, M, N, kl, e,
+                                                 nullptr, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int64_t slab_stride, int64_t ldws,
+                                                              int splits, void* __restrict__ Cout, int64_t ldc, int M, int N,
+                                                              MmtEpilogue epi) {
+  const int n4 = N >> 2;
+  unsigned dkey = 0;
+  if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+    f32x4 v = *(const f32x4*)(ws + (int64_t)row * ldws + col);
+    for (int s = 1; s < splits; ++s) v += *(const f32x4*)(ws + (int64_t)s * slab_stride + (int64_t)row * ldws + col);
+    if constexpr (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_BIAS_F32) v += *(const f32x4*)(epi.bias + col);
+    if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+      if (epi.drop_thr16) {
+        const int orow = epi.row_index ? epi.row_index[row] : row;
+        bool k[4];
+        keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
+      }
+    }
+    if constexpr (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32)
+      v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+    if constexpr (EPI == MMT_EPI_BF16) {
+      u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+    } else {
+      *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+    }
+  }
+}
+
+extern "C" int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K) {
+  const int splits = K / BK < 16 ? K / BK : 16;
+  return (int64_t)(splits < 1 ? 1 : splits) * ((M + 127) / 128 * 128) * N;
+}
+
+// epilogue: MMT_EPI_BF16 / F32 / BIAS_F32 / ADD_F32 / BIAS_DROP_RES.  ws: mmt_gemm_nt_splitk_workspace_floats() floats.
+extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                                  int K, int epilogue, const MmtEpilogue* epi, float* ws, void* stream) {
+  if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || K % BK || N % 64) return MMT_ERR_ARG;
+  if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
+    return MMT_ERR_ALIGN;
+  MmtEpilogue e = {};
+  if (epi) e = *epi;
+  constexpr int BM = 128, BN = 64, WGM = 4, WGN = 2, NS = 3;
+  const int ksteps = K / BK;
+  int splits = ksteps < 16 ? ksteps : 16;
+  const int per = (ksteps + splits - 1) / splits;       // K-steps per slice
+  splits = (ksteps + per - 1) / per;
+  const int Mpad = (M + 127) / 128 * 128;
+  const int64_t slab = (int64_t)Mpad * N;
+  constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return (int)rc;
+    configured = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>), dim3((Mpad / BM) * (N / BN), splits), dim3(512), lds, s,
+                     (const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK);
+  const int64_t items = (int64_t)M * (N / 4);
+  const int grid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+#define SK_EPI(E) hipLaunchKernelGGL(splitk_epilogue_kernel<E>, dim3(grid), dim3(256), 0, s, ws, slab, (int64_t)N, splits, C, ldc, M, N, e)
+  switch (epilogue) {
+    case MMT_EPI_BF16: SK_EPI(MMT_EPI_BF16); break;
+    case MMT_EPI_F32: SK_EPI(MMT_EPI_F32); break;
+    case MMT_EPI_BIAS_F32: if (!e.bias) return MMT_ERR_ARG; SK_EPI(MMT_EPI_BIAS_F32); break;
+    case MMT_EPI_ADD_F32: if (!e.res) return MMT_ERR_ARG; SK_EPI(MMT_EPI_ADD_F32); break;
+    case MMT_EPI_BIAS_DROP_RES: if (!e.bias || !e.res) return MMT_ERR_ARG; SK_EPI(MMT_EPI_BIAS_DROP_RES); break;
+    default: return MMT_ERR_ARG;
+  }
+#undef SK_EPI
+  return (int)hipGetLastError();
+}
+
 // Several independent small GEMMs (the per-expert ReduceDim projections, model/model.py:426-437) in ONE launch:
 // block -> (problem, tile) through a prefix table; each problem keeps its own XCD-aware tile order.
 struct GemmGroupTable { MmtGemmItem item[MMT_GEMM_GROUP_MAX]; int count; };

@@ -219,14 +219,18 @@ __global__ __launch_bounds__(64 * CR_RG) void col_reduce_kernel(const float* __r
 // The same reduction for up to MMT_COLRED_MAX independent jobs in one launch (blockIdx.y = job): the backward pass
 // leaves every site's partials in its own buffer and sums them all at the end instead of paying one ~6 us
 // launch-latency-bound kernel per LayerNorm.
-struct ColJobs { MmtColReduceJob job[MMT_COLRED_MAX]; };
+struct ColJobs { MmtColReduceJob job[MMT_COLRED_MAX]; int begin[MMT_COLRED_MAX]; int count; };
 __global__ __launch_bounds__(64 * CR_RG) void col_reduce_multi_kernel(ColJobs jobs) {
   __shared__ float red[CR_RG][64];
-  const MmtColReduceJob& jb = jobs.job[blockIdx.y];
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < jobs.count; ++q)
+    if ((int)blockIdx.x >= jobs.begin[q]) p = q;
+  const MmtColReduceJob& jb = jobs.job[p];
+  const int bid = (int)blockIdx.x - jobs.begin[p];
   const int d = jb.d, nvec = jb.nvec, nblocks = jb.nblocks;
   const int chunks = (d + 63) / 64;
-  if ((int)blockIdx.x >= jb.nout * chunks) return;
-  const int j = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63);
+  const int j = bid / chunks, c = (bid % chunks) * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   float* out = jb.out[j];
   const float* __restrict__ partials = jb.partials;
@@ -307,7 +311,11 @@ __global__ __launch_bounds__(256) void row_move_kernel(const float* __restrict__
     const int64_t r = rows[i];
     const float* s = scatter ? src + (int64_t)i * d : src + r * d;
     float* t = scatter ? dst + r * d : dst + (int64_t)i * d;
-    for (int c = lane * 4; c < d; c += 256) *(f32x4*)(t + c) = *(const f32x4*)(s + c);
+    if (scatter == 2) {
+      for (int c = lane * 4; c < d; c += 256) *(f32x4*)(t + c) += *(const f32x4*)(s + c);
+    } else {
+      for (int c = lane * 4; c < d; c += 256) *(f32x4*)(t + c) = *(const f32x4*)(s + c);
+    }
     if (!scatter && idx_out && lane == 0) idx_out[i] = idx_in ? idx_in[r] : (int32_t)r;
   }
 }
@@ -319,10 +327,11 @@ extern "C" int mmt_rows_gather(const float* src, const int32_t* rows, int n, int
                      idx_out);
   return (int)hipGetLastError();
 }
-extern "C" int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, void* stream) {
+extern "C" int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, int accumulate,
+                                void* stream) {
   if (!src || !rows || !dst || n <= 0 || d <= 0 || (d & 3)) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(row_move_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, dst, rows, n, d, 1, nullptr,
-                     nullptr);
+  hipLaunchKernelGGL(row_move_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, dst, rows, n, d,
+                     accumulate ? 2 : 1, nullptr, nullptr);
   return (int)hipGetLastError();
 }
 
@@ -342,7 +351,9 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_ln_bwd_rows_per_block(void) { return 16; }
+// rows per block: 16 for big inputs; 4 (one row per wave) when there are few rows, so that a compact last-layer
+// LayerNorm is not a 14-block launch
+extern "C" int mmt_ln_bwd_rows_per_block(int rows) { return rows <= 2048 ? 4 : 16; }
 
 extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
                           const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
@@ -351,7 +362,7 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
                           void* stream) {
   if (!dout || !z || !mean || !rstd || !gamma || !partials || rows <= 0) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
-  const int rpb = 16, grid = (rows + rpb - 1) / rpb;
+  const int rpb = mmt_ln_bwd_rows_per_block(rows), grid = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(MODE)                                                                            \
   hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), (size_t)4 * 3 * d * sizeof(float), s, dout, z, mean, rstd, gamma, dz, \
@@ -378,16 +389,17 @@ extern "C" int mmt_col_reduce_multi(const MmtColReduceJob* jobs, int n, void* st
   for (int base = 0; base < n; base += MMT_COLRED_MAX) {
     ColJobs tab;
     const int cnt = n - base < MMT_COLRED_MAX ? n - base : MMT_COLRED_MAX;
+    tab.count = cnt;
     int gx = 0;
     for (int i = 0; i < cnt; ++i) {
       const MmtColReduceJob& jb = jobs[base + i];
       if (!jb.partials || jb.nblocks <= 0 || jb.nvec <= 0 || jb.nout <= 0 || jb.nout > 4 || jb.nout > jb.nvec || jb.d <= 0)
         return MMT_ERR_ARG;
       tab.job[i] = jb;
-      const int g = jb.nout * ((jb.d + 63) / 64);
-      gx = g > gx ? g : gx;
+      tab.begin[i] = gx;
+      gx += jb.nout * ((jb.d + 63) / 64);
     }
-    hipLaunchKernelGGL(col_reduce_multi_kernel, dim3(gx, cnt), dim3(64 * CR_RG), 0, (hipStream_t)stream, tab);
+    hipLaunchKernelGGL(col_reduce_multi_kernel, dim3(gx), dim3(64 * CR_RG), 0, (hipStream_t)stream, tab);
   }
   return (int)hipGetLastError();
 }

@@ -79,6 +79,27 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
   return out
 
 
+def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_index=None, drop_key=0, drop_p=0.0,
+                   seed_dev=None):
+  """Split-K variant of gemm_nt for skinny problems (few rows, long K)."""
+  _need_cuda(a, b, out)
+  M = a.shape[0] if m is None else m
+  N, K = b.shape
+  e = MmtEpilogue()
+  e.bias = bias.data_ptr() if bias is not None else None
+  e.res = res.data_ptr() if res is not None else None
+  e.ldres = res.stride(0) if res is not None else 0
+  e.row_index = row_index.data_ptr() if row_index is not None else None
+  thr, scale = dropout_params(drop_p)
+  e.drop_key, e.drop_thr16, e.drop_scale = drop_key, thr, scale
+  e.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None
+  L = _lib.lib()
+  ws = torch.empty(L.mmt_gemm_nt_splitk_workspace_floats(M, N, K), device=a.device, dtype=torch.float32)
+  check(L.mmt_gemm_nt_splitk(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, EPI[epilogue],
+                             ctypes.byref(e), _p(ws), _stream()), 'mmt_gemm_nt_splitk')
+  return out
+
+
 def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32'):
   """items: list of (a [M,K] bf16, b [N,K] bf16, out [M,N] fp32, bias [N] fp32 or None): all in ONE launch."""
   from ._lib import MmtGemmItem
@@ -162,7 +183,7 @@ def ln_bwd(dout, z, mean, rstd, gamma, rows=None, drop_mode=0, drop_key=0, drop_
   R, d = z.shape
   rows = R if rows is None else rows
   L = _lib.lib()
-  rpb = L.mmt_ln_bwd_rows_per_block()
+  rpb = L.mmt_ln_bwd_rows_per_block(rows)
   nblk = (rows + rpb - 1) // rpb
   dz = torch.zeros_like(z)
   dy = torch.zeros(R, d, device=z.device, dtype=torch.bfloat16) if want_dy else None

@@ -379,3 +379,58 @@ def test_attention_dropout_replay_and_varlen():
   ref2.backward(dctx[:91].float())
   dqkv2 = ops.attn_bwd(qkv, bias, ctx2, lse2, dctx, 3, 50, H, scale, cu_seqlens=cu)
   _close('attn.varlen dqkv', dqkv2[:91], x2.grad, 4e-2, 4e-2)
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(224, 512, 3072, 'BIAS_DROP_RES'), (224, 512, 512, 'BF16'), (200, 1024, 6144, 'ADD_F32'),
+                                       (77, 256, 192, 'F32')])
+def test_gemm_nt_splitk(M, N, K, epi):
+  """Skinny split-K GEMM (last-layer read-out rows): same results as the fused-epilogue GEMM, incl. the dropout mask."""
+  from mmt_amd import ops
+  R = ops.pad_rows(M)
+  a = _rand((R, K), seed=120, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.05, seed=121, dtype=torch.bfloat16)
+  bias, res = _rand((N,), seed=122), _rand((R, N), seed=123)
+  rowidx = torch.arange(R, device=_dev(), dtype=torch.int32) * 3 + 5
+  f32 = epi != 'BF16'
+  want = torch.zeros(R, N, device=_dev(), dtype=torch.float32 if f32 else torch.bfloat16)
+  got = torch.full((R, N), 9.0, device=_dev(), dtype=want.dtype)
+  kw = dict(bias=bias, res=res, row_index=rowidx, drop_key=55, drop_p=0.1 if epi == 'BIAS_DROP_RES' else 0.0)
+  ops.gemm_nt(a, b, want, epi, m=M, tile=2, **kw)
+  ops.gemm_nt_splitk(a, b, got, epi, m=M, **kw)
+  _close('splitk', got[:M], want[:M], 2e-2 if not f32 else 2e-3, 1e-2 if not f32 else 2e-4)
+  assert bool((got[M:] == 9.0).all())
+
+
+def test_wgrad_grouped_item_splits_and_row_override():
+  """Per-item row override (compact operands) and per-item split-K slabs summed by mmt_col_reduce_multi."""
+  import ctypes
+  from mmt_amd import _lib, ops
+  from mmt_amd._lib import MmtColReduceJob, MmtWgradGroup, check
+  rows, live = 1024, 900
+  a0, b0 = _rand((rows, 256), seed=130, dtype=torch.bfloat16), _rand((rows, 128), 0.1, seed=131, dtype=torch.bfloat16)
+  a1, b1 = _rand((256, 128), seed=132, dtype=torch.bfloat16), _rand((256, 384), 0.1, seed=133, dtype=torch.bfloat16)
+  a0[live:] = float('nan'); b0[live:] = float('nan')
+  a1[200:] = float('nan'); b1[200:] = float('nan')
+  out0, bias0 = torch.zeros(256, 128, device=_dev()), torch.zeros(256, device=_dev())
+  out1, bias1 = torch.zeros(128, 384, device=_dev()), torch.zeros(128, device=_dev())
+  splits = 4
+  slab, bslab = torch.zeros(splits, 256, 128, device=_dev()), torch.zeros(splits, 256, device=_dev())
+  nr = torch.tensor([live], device=_dev(), dtype=torch.int32)
+  g = MmtWgradGroup()
+  g.count, g.rows, g.n_rows_dev = 2, rows, nr.data_ptr()
+  it = g.item[0]
+  it.A, it.B, it.out, it.bias_out = a0.data_ptr(), b0.data_ptr(), out0.data_ptr(), bias0.data_ptr()
+  it.lda, it.ldb, it.N, it.K2, it.splits, it.slab, it.bias_slab = 256, 128, 256, 128, splits, slab.data_ptr(), bslab.data_ptr()
+  it = g.item[1]
+  it.A, it.B, it.out, it.bias_out = a1.data_ptr(), b1.data_ptr(), out1.data_ptr(), bias1.data_ptr()
+  it.lda, it.ldb, it.N, it.K2, it.reserved = 128, 384, 128, 384, 200
+  check(_lib.lib().mmt_wgrad_grouped(ctypes.byref(g), ops._stream()), 'mmt_wgrad_grouped')
+  jobs = (MmtColReduceJob * 2)()
+  for j, (p, o, dd) in enumerate(((slab, out0, 256 * 128), (bslab, bias0, 256))):
+    jobs[j].partials, jobs[j].nblocks, jobs[j].nvec, jobs[j].nout, jobs[j].d = p.data_ptr(), splits, 1, 1, dd
+    jobs[j].out[0] = o.data_ptr()
+  check(_lib.lib().mmt_col_reduce_multi(jobs, 2, ops._stream()), 'mmt_col_reduce_multi')
+  _close('split item', out0, a0[:live].float().t() @ b0[:live].float(), 6e-3, 2e-4)
+  _close('split bias', bias0, a0[:live].float().sum(0), 2e-3, 1e-5)
+  _close('row-override item', out1, a1[:200].float().t() @ b1[:200].float(), 4e-3, 2e-4)
+  _close('row-override bias', bias1, a1[:200].float().sum(0), 1e-3, 1e-5)
