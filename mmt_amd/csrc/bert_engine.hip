@@ -258,8 +258,6 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
         g.item[0].A = w.dqkv;  g.item[0].lda = 3 * d; g.item[0].B = hin16; g.item[0].ldb = d; g.item[0].N = 3 * d; g.item[0].K2 = d;
         g.item[0].out = P.g_wqkv; g.item[0].bias_out = P.g_bqkv;
         g.item[0].splits = TAIL_WSPLIT; g.item[0].slab = t.wslab; g.item[0].bias_slab = t.bslab;
-        add_job(t.wslab, TAIL_WSPLIT, 1, 1, 3 * d * d, P.g_wqkv, nullptr);
-        add_job(t.bslab, TAIL_WSPLIT, 1, 1, 3 * d, P.g_bqkv, nullptr);
         g.item[1].A = t.dhpre; g.item[1].lda = I;     g.item[1].B = t.a16; g.item[1].ldb = d; g.item[1].N = I;     g.item[1].K2 = d;
         g.item[1].out = P.g_w1;   g.item[1].bias_out = P.g_b1; g.item[1].reserved = nc;
         g.item[2].A = t.dy2;   g.item[2].lda = d;     g.item[2].B = t.g;   g.item[2].ldb = I; g.item[2].N = d;     g.item[2].K2 = I;
@@ -267,6 +265,8 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
         g.item[3].A = t.dy;    g.item[3].lda = d;     g.item[3].B = t.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
         g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo; g.item[3].reserved = nc;
         TRY(mmt_wgrad_grouped(&g, stream));
+        TRY(mmt_reduce_slabs(t.wslab, TAIL_WSPLIT, (int64_t)3 * d * d, P.g_wqkv, 0, stream));
+        TRY(mmt_reduce_slabs(t.bslab, TAIL_WSPLIT, (int64_t)3 * d, P.g_bqkv, 0, stream));
       }
       dcur = dnext;
       continue;

@@ -498,6 +498,9 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     if (N >= 1024 && N % 128 == 0) return mmt_gemm2_dispatch(5, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (nr != nullptr && N % 64 == 0) return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   }
+  // few rows (the compact last layer): the 8-wave staggered tile has the shortest per-block latency
+  if (e.reserved == 0 && M < 512 && N >= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
+    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if (N % 128 == 0 && e.reserved == 1) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   return launch_nt<128, 64, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
 }

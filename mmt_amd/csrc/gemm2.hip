@@ -330,8 +330,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / n4), col = (int)(i % n4) * 4;
-    f32x4 v = *(const f32x4*)(ws + (int64_t)row * ldws + col);
-    for (int s = 1; s < splits; ++s) v += *(const f32x4*)(ws + (int64_t)s * slab_stride + (int64_t)row * ldws + col);
+    const float* p0 = ws + (int64_t)row * ldws + col;
+    f32x4 v = *(const f32x4*)p0;
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {  // fixed association (deterministic), four loads in flight
+      const f32x4 a0 = *(const f32x4*)(p0 + (int64_t)s * slab_stride), a1 = *(const f32x4*)(p0 + (int64_t)(s + 1) * slab_stride);
+      const f32x4 a2 = *(const f32x4*)(p0 + (int64_t)(s + 2) * slab_stride), a3 = *(const f32x4*)(p0 + (int64_t)(s + 3) * slab_stride);
+      v += (a0 + a1) + (a2 + a3);
+    }
+    for (; s < splits; ++s) v += *(const f32x4*)(p0 + (int64_t)s * slab_stride);
     if constexpr (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_BIAS_F32) v += *(const f32x4*)(epi.bias + col);
     if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
       if (epi.drop_thr16) {
