@@ -109,7 +109,7 @@ def time_dominant_kernel(rows, iters=40):
   flops = 2.0 * rows * INTER * HIDDEN
   return dict(bound='mfma', achieved=flops / sec / 1e12, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
               frac=flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, traffic=None,
-              kernel='gemm2_kernel<128,128,2,2,BIAS_GELU> rows=%d N=%d K=%d' % (rows, INTER, HIDDEN),
+              kernel='gemm2_kernel<128,128,2x4 waves,NS2,BIAS_GELU> rows=%d N=%d K=%d' % (rows, INTER, HIDDEN),
               avg_launch_us=sec * 1e6)
 
 

@@ -486,16 +486,16 @@ template <int EPI>
 static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   // Measured on MI355X (tools/gemm_lab.py, tools/gemm_instr.py, profiles/r01_gemm_lab.txt):
-  //   * wide outputs (N >= 1024: QKV, FFN up-projection) run best on gemm2's 128x128 4-wave tile at 2 blocks/CU;
-  //   * dGELU (N = 3072, heavier epilogue) and -- when token packing halves the live rows -- the N = 512 GEMMs run best
-  //     on gemm2's 128x64 tile with 8 waves in two staggered groups (LDS-DMA issue of one group under the other's MFMAs);
+  //   * wide outputs (N >= 1024: QKV, FFN up-projection, dGELU) run best on gemm2's 128x128 tile with 8 waves (wave tile
+  //     64x32) at 2 blocks/CU;
+  //   * when token packing halves the live rows, the N = 512 GEMMs run best on gemm2's 128x64 tile with 8 waves in two
+  //     staggered groups (LDS-DMA issue of one group under the other's MFMAs);
   //   * the dense N = 512 GEMMs stay on this file's 128x64 4-wave tile (both saturate the ~27 B/clk/CU LDS ingest).
   // reserved: 1/2 force the gemm.hip tiles, >= 3 a gemm2 tile.
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if (e.reserved == 0 && M >= 512) {
-    if (EPI == MMT_EPI_DGELU && !e.colsum && N >= 1024)
-      return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    if (N >= 1024 && N % 128 == 0) return mmt_gemm2_dispatch(5, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    if (N >= 1024 && N % 128 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum))
+      return mmt_gemm2_dispatch(14, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (nr != nullptr && N % 64 == 0) return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   }
   // few rows (the compact last layer): the 8-wave staggered tile has the shortest per-block latency

@@ -500,6 +500,7 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 11: if (N % 128 == 0) G2(128, 128, 2, 4, 3); break;  // 8 waves on 128x128 (wave 64x32), staggered
     case 12: if (N % 128 == 0) G2(64, 128, 2, 4, 3); break;   // 8 waves on 64x128 (wave 32x32), staggered, 2 blocks/CU
     case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
+    case 14: if (N % 128 == 0) G2(128, 128, 2, 4, 2); break;  // 8 waves on 128x128, in phase, 2 blocks/CU
   }
 #undef G2
   return MMT_ERR_ARG;
