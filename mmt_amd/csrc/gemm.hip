@@ -297,6 +297,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(
 // 8 waves per tile: wave group kg = wave >> 2 contracts the even / odd 64-row units of the token dimension with its
 // own LDS ring (intra-block split-K), so a CU that owns ONE tile still has two independent load/MFMA streams in
 // flight; the two partial tiles are summed through LDS at the end (fixed order => deterministic).
+#ifdef MMT_GEMM2_INSTR
+__device__ long long* g_wgrad_dbg = nullptr;  // lab build only: per-block cycle counters
+extern "C" int mmt_debug_set_wgrad_buffer(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_dbg), &p, sizeof(p));
+}
+#define WTICK(acc) do { const long long tn_ = clock64(); acc += tn_ - tp; tp = tn_; } while (0)
+#else
+#define WTICK(acc) do {} while (0)
+#endif
 __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   bf16_t* smem = (bf16_t*)wg_smem;  // [2 stages][2 groups][A 64x128 | B 64x128]
@@ -349,12 +358,18 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
       stage_tn(B, ldb, (u0 + unit) * 64, k0, base + 64 * 128, wave, lane);
     }
   };
+#ifdef MMT_GEMM2_INSTR
+  long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t0 = clock64(), tp = t0;
+#endif
   if (steps > 0) stage(0, 0);
   for (int s = 0; s < steps; ++s) {
     const int cur = s & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WTICK(t_wait);
     __syncthreads();
+    WTICK(t_bar);
     if (s + 1 < steps) stage(s + 1, cur ^ 1);
+    WTICK(t_issue);
     const int unit = 2 * s + kg;
     bf16_t* at = smem + cur * TSTAGE + kg * GSTAGE;
     bf16_t* bt = at + 64 * 128;
@@ -389,7 +404,17 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
         }
       }
     }
+#ifdef MMT_GEMM2_INSTR
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[3][3][3]));
+#endif
+    WTICK(t_comp);
   }
+#ifdef MMT_GEMM2_INSTR
+  if (g_wgrad_dbg && tid == 0) {
+    long long* d = g_wgrad_dbg + (int64_t)blockIdx.x * 8;
+    d[0] = t_wait; d[1] = t_bar; d[2] = t_issue; d[3] = t_comp; d[4] = clock64() - t0; d[5] = steps; d[6] = p; d[7] = t0;
+  }
+#endif
   // ---- sum the two wave groups through LDS (group 1 -> group 0), then store ----
   __syncthreads();
   f32x4* xch = (f32x4*)wg_smem;  // [20][256] f32x4 = 80 KiB
