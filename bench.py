@@ -113,6 +113,24 @@ def time_dominant_kernel(rows, iters=40):
               avg_launch_us=sec * 1e6)
 
 
+def pmc_traffic(kernel_sub='gemm2_kernel<128, 128, 2, 4, 2, 2>', grid_sub='[grid 1320 '):
+  """HBM traffic of the dominant kernel per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_kernels.csv,
+  separate --pmc runs of this same command): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a
+  wide coalesced read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
+  import csv
+  path = os.path.join(ROOT, 'profiles', 'r01_pmc_kernels.csv')
+  if not os.path.exists(path):
+    return None
+  with open(path) as f:
+    for row in csv.DictReader(f):
+      if kernel_sub in row['kernel'] and grid_sub in row['kernel']:
+        try:
+          return (2.0 * float(row['FETCH_SIZE']) + float(row['WRITE_SIZE'])) * 1024.0
+        except (KeyError, ValueError):
+          return None
+  return None
+
+
 def cpu_baseline(steps=2):
   """The CPU oracle ('port' of the reference path, pinned to it by tests/golden) on this box's host cores:
   fwd+bwd of config B, train mode semantics without dropout RNG (cheaper than the reference), fp32."""
@@ -235,7 +253,9 @@ def main():
     kflops = 2.0 * rows * INTER * HIDDEN
     alone = time_dominant_kernel(rows)
     out['roofline'] = dict(bound='mfma', achieved=kflops / sec / 1e12, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
-                           frac=kflops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, traffic=None,
+                           frac=kflops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                           traffic=pmc_traffic() if not args.dense else None,
+                           traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_kernels.csv)',
                            kernel=alone['kernel'], avg_launch_us=sec * 1e6, launches_timed=used,
                            standalone_us=alone['avg_launch_us'])
     if world == 1 and not args.no_cpu_baseline:
