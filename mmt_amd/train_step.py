@@ -157,8 +157,6 @@ class GraphedTrainStep:
       g = self._gather(e)
     with torch.cuda.graph(gb, pool=pool, stream=self._stream):
       self.loss = self._loss_backward(e, g)
-    with torch.cuda.stream(self._stream):
-      self.sync.sync()
     with torch.cuda.graph(gc, pool=pool, stream=self._stream):
       self._opt()
     self._graphs, self._e = (ga, gb, gc), e
