@@ -281,6 +281,26 @@ int mmt_sims_eval(const float* txt, const float* vid, const float* tw, const flo
 int mmt_retrieval_ranks(const float* sims, const uint8_t* qmask, int NQ, int NV, float* t2v_rank, float* v2t_rank,
                         float* scratch, void* stream);
 
+/* ---- row-sharded similarity + max-margin loss for very large global batches (largesim.hip) --------------------
+ * BASELINE.json configs[4] / SURVEY.md 8e: rank r owns the text rows r0..r0+b of the n x n similarity; same maths as
+ * model.py:789-837 + loss.py:38-65 without the [n,n,M] weight tensor or the 2n^2 index vectors.  The two big GEMMs
+ * (S = T'V'^T, P = G'V', Q = G'^T T') run on mmt_gemm_nt_bf16 / mmt_wgrad_grouped; these are the passes in between
+ * (host orchestration: mmt_amd/large_sim.py).
+ *   mmt_ls_fold_bf16: out16[r, m*d+c] = bf16(w[r,m] x[r,m,c]), rows R..Rpad zero.
+ *   mmt_ls_finish   : S[t,v] /= sum_m tw[t,m] vw[v,m] (0 -> 1e-5), in place.
+ *   mmt_ls_counts   : rowcnt[t], colcnt[c] += (zeroed by the caller), un-normalised hinge sums loss_part[t].
+ *   mmt_ls_grad     : G16[t,v] = bf16((dL/dS)/den) from the global counts; gs[t,m] = sum_v G' S vw[v,m].
+ *   mmt_ls_unfold   : dx[r,m,:] = w[r,m] P[r,m*d:], dw[r,m] = <x[r,m], P[r,m]> - gsub[r,m]. */
+int mmt_ls_fold_bf16(const float* x, const float* w, int R, int Rpad, int M, int d, void* out16, void* stream);
+int mmt_ls_finish(float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, void* stream);
+int mmt_ls_counts(const float* S, int64_t ld, const float* diag, int b, int n, int r0, float margin, int32_t* rowcnt,
+                  int32_t* colcnt, float* loss_part, void* stream);
+int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const int32_t* rowcnt,
+                const int32_t* colcnt_total, int b, int n, int M, int r0, float margin, float inv_norm, void* G16,
+                int64_t ldg, float* gs, void* stream);
+int mmt_ls_unfold(const float* P, int64_t ldp, const float* x, const float* w, const float* gsub, int R, int M, int d,
+                  float* dx, float* dw, void* stream);
+
 /* ---- text heads (texthead.hip), fp32 ------------------------------------------------------------------
  * GatedEmbeddingUnit per expert (model.py:683-702, 736-750) + text MoE weights (model.py:262-283,618),
  * batched over the M experts. */

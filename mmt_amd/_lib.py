@@ -150,6 +150,12 @@ SIGNATURES = {
     'mmt_sims_eval_workspace_floats': (c_i64, [c_int, c_int, c_int, c_int]),
     'mmt_sims_eval': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_retrieval_ranks': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_ls_fold_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_ls_finish': (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'mmt_ls_counts': (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_ls_grad': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64,
+                            c_vp, c_vp]),
+    'mmt_ls_unfold': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_maxmargin': (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_infonce': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_bert_workspace_bytes': (c_i64, [ctypes.POINTER(MmtBertModel), c_int]),

@@ -280,3 +280,48 @@ def test_eval_path_on_device_metrics_match_reference():
         assert abs(got[k] - v) < 1e-9, (k, got[k], v)
   both = NM.retrieval_metrics(vid.to(DEV), txt.to(DEV), vw.to(DEV), tw.to(DEV), qm)
   assert both['t2v_metrics']['R1'] > 50.0 and set(both) == {'t2v_metrics', 'v2t_metrics'}
+
+
+@pytest.mark.parametrize('world', [1, 2, 4])
+def test_row_sharded_similarity_and_maxmargin(world):
+  """BASELINE configs[4] path at a size the oracle can check: the n x n similarity + max-margin loss sharded by text
+  rows over `world` simulated ranks (phases of mmt_amd.large_sim.RowBlock with the collectives done by hand) against
+  autograd through the oracle on the full matrix.  bf16 GEMM operands: sims atol 2e-3; the loss gradient is
+  piecewise constant in the sims, so gradients are compared by cosine."""
+  from mmt_amd.large_sim import RowBlock, ShardedSimLoss
+  from oracle import mmt_oracle as O
+  rs = np.random.RandomState(7)
+  n, m, d, margin = 512, 3, 128, 0.05
+  vid = torch.nn.functional.normalize(torch.from_numpy(rs.randn(n, m, d).astype(np.float32)), dim=-1)
+  txt = torch.nn.functional.normalize(torch.from_numpy(rs.randn(n, m, d).astype(np.float32)) + 0.5 * vid, dim=-1)
+  tw = torch.softmax(torch.from_numpy(rs.randn(n, m).astype(np.float32)), -1)
+  vw = torch.full((n, m), 1.0 / m)
+  leaves = [x.clone().requires_grad_(True) for x in (vid, txt, tw)]
+  sims_ref = O.cross_view_inner_product(leaves[0], leaves[1][:, :, None, :], vw, leaves[2][:, None, :], 'avg')
+  loss_ref = O.max_margin_ranking_loss(sims_ref, margin, True)
+  loss_ref.backward()
+  b = n // world
+  blocks = [RowBlock(txt[r * b:(r + 1) * b].to(DEV), tw[r * b:(r + 1) * b].to(DEV), vid.to(DEV), vw.to(DEV), r * b, margin)
+            for r in range(world)]
+  diag = torch.cat([blk.phase_similarity() for blk in blocks])                     # all-gather
+  S = torch.cat([blk.S[:b] for blk in blocks]).cpu()
+  assert (S - sims_ref.detach()).abs().max() < 2e-3
+  parts = [blk.phase_counts(diag) for blk in blocks]
+  colcnt = sum(p[0] for p in parts)                                                 # all-reduce
+  loss = sum(p[1] for p in parts)
+  assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item()) + 1e-6
+  outs = [blk.phase_backward(colcnt) for blk in blocks]
+  q = sum(o[2] for o in outs)                                                       # reduce-scatter
+  dvid = torch.cat([blocks[r].phase_video_grad(q[r * b:(r + 1) * b], vid[r * b:(r + 1) * b].to(DEV), vw[r * b:(r + 1) * b].to(DEV))
+                    for r in range(world)]).cpu()
+  dtxt = torch.cat([o[0] for o in outs]).cpu()
+  dtw = torch.cat([o[1] for o in outs]).cpu()
+  for got, ref, nm in ((dvid, leaves[0].grad, 'dvid'), (dtxt, leaves[1].grad, 'dtxt'), (dtw, leaves[2].grad, 'dtw')):
+    assert _cos(got.numpy(), ref.numpy()) > 0.995, (nm, _cos(got.numpy(), ref.numpy()))
+    assert abs(got.norm().item() / ref.norm().item() - 1.0) < 0.03, nm
+  if world == 1:  # the nn.Module wrapper (no process group => one row block) gives the same loss and gradients
+    lv = [x.clone().to(DEV).requires_grad_(True) for x in (vid, txt, tw)]
+    l2 = ShardedSimLoss(margin, True)(lv[0], lv[1][:, :, None, :], vw.to(DEV), lv[2][:, None, :])
+    l2.backward()
+    assert abs(l2.item() - loss.item()) < 1e-6
+    assert (lv[0].grad.cpu() - dvid).abs().max() < 1e-6 and (lv[2].grad.cpu() - dtw).abs().max() < 1e-6
