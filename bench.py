@@ -185,7 +185,7 @@ def main():
 
   # NBATCH different synthetic minibatches resident in HBM; each step copies one (device-to-device) into
   # the static input buffers of the captured graphs.
-  NBATCH = 4
+  NBATCH = 16
   batches = []
   for i in range(NBATCH):
     mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
@@ -195,12 +195,13 @@ def main():
   model.txt_bert.text = static['text']
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
   runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager)
-  first_loss = float(runner.loss.item())
-
   it = 0
+  first_loss = None
   for _ in range(args.warmup):
     runner.load(batches[it % NBATCH]); it += 1
-    runner.step()
+    l = runner.step()
+    if first_loss is None:
+      first_loss = float(l.item())  # loss of the first replayed step (after the runner's own eager warm-up steps)
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
