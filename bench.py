@@ -40,8 +40,9 @@ class SyntheticTextTower(torch.nn.Module):
     self.config = type('C', (), {'hidden_size': 768})()
     self.embeddings = torch.nn.Module()
     self.text = None
+    self.ignores_token_inputs = True  # CENet then skips building ids / masks / position ids for it
 
-  def forward(self, input_ids, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None):
+  def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None):
     return (self.text[:, None, :],)
 
 

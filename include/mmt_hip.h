@@ -371,13 +371,15 @@ typedef struct MmtBertBatch {
   int32_t rows, rows_alloc, batch, seq;
   /* Optional: the only rows of sequence_output the caller will read (CENet: the AGG token of every expert,
    * model.py:583-587), out_rows[b*n_out_per_sample + i], each sample's in ascending order.  The last layer then runs
-   * everything after the K/V projection on those rows only (exact: all of it is row-wise); the other rows of out_last are
-   * left unwritten and only those rows of `dlast` are read.  NULL = every row. */
+   * everything after the K/V projection on those rows only (exact: all of it is row-wise) and returns them COMPACT:
+   * out_last[i] = sequence_output[out_rows[i]] for i < batch * n_out_per_sample; `dlast` is read the same way.  The
+   * compact mode is taken iff batch * n_out_per_sample <= mmt_bert_tail_capacity(rows_alloc).  NULL = every row. */
   const int32_t* out_rows;
   int32_t n_out_per_sample, reserved;
 } MmtBertBatch;
 
 int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc);
+int mmt_bert_tail_capacity(int rows_alloc);
 /* out_last: fp32 [rows_alloc, hidden] last-layer hidden states (sequence_output).  training != 0 enables
  * dropout with p_hidden / p_attn. */
 int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last, int training,

@@ -158,6 +158,7 @@ SIGNATURES = {
     'mmt_ls_unfold': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_maxmargin': (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_infonce': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_bert_tail_capacity': (c_int, [c_int]),
     'mmt_bert_workspace_bytes': (c_i64, [ctypes.POINTER(MmtBertModel), c_int]),
     'mmt_bert_forward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_int, c_vp]),
     'mmt_bert_backward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp, c_int,

@@ -293,6 +293,12 @@ class BertModel(nn.Module):
       self._ws[key] = ws
     return ws
 
+  def compact_output(self, batch, rows_alloc):
+    """True iff the engine returns only the batch.out_rows rows, compacted (see MmtBertBatch.out_rows)."""
+    if batch.out_rows is None or batch.n_out_per_sample <= 0:
+      return False
+    return batch.batch * batch.n_out_per_sample <= _lib.lib().mmt_bert_tail_capacity(rows_alloc)
+
   def _engine_forward(self, batch, features, save):
     rows_alloc = features.shape[0]
     if features.dtype != torch.float32 or not features.is_contiguous() or rows_alloc % ops.ROW_ALIGN:
@@ -316,7 +322,11 @@ class BertModel(nn.Module):
     grad_buf = self._flat.current_grad()
     m, _ = self._struct(grad_buf)
     ws = self._workspace(rows_alloc, True, m)
-    dlast = dout.contiguous().clone()  # the engine uses it as scratch
+    if self.compact_output(batch, rows_alloc):
+      dlast = dout.contiguous()  # compact read-out gradient in the first rows; produced by our own read-out backward,
+                                 # so the engine may use the rest of it (and later all of it) as scratch
+    else:
+      dlast = dout.contiguous().clone()  # the engine uses it as scratch
     dfeat = torch.empty_like(dlast)
     b = self._batch_struct(batch, rows_alloc)
     check(_lib.lib().mmt_bert_backward(ctypes.byref(m), ctypes.byref(b), ws.data_ptr(), dlast.data_ptr(),

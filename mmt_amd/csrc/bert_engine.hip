@@ -63,7 +63,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(ln_nb * 3 * d * 4);
   const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
   {  // tail buffers: B*M read-out rows are at most a quarter of the token rows for T >= 3 (else: full path)
-    const size_t C = ((size_t)R / 4 + 255) & ~(size_t)255;
+    const size_t C = (size_t)mmt_bert_tail_capacity(R);
     TailWs& t = w->t;
     t.cap = (int)C;
     t.ctx = take(C * d * 2); t.a16 = take(C * d * 2); t.hpre = take(C * I * 2); t.g = take(C * I * 2);
@@ -116,6 +116,8 @@ extern "C" int mmt_probe_arm(void** start_events, void** stop_events, int n) {
 }
 extern "C" int mmt_probe_count(void) { return g_probe_i; }
 
+extern "C" int mmt_bert_tail_capacity(int rows_alloc) { return (int)((((size_t)rows_alloc / 4) + 255) & ~(size_t)255); }
+
 extern "C" int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc) {
   if (!m || rows_alloc <= 0 || m->layers > 64) return MMT_ERR_ARG;
   Ws w;
@@ -166,8 +168,9 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       e.bias = P.b2; e.res = t.a32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
       e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
       TRY(mmt_gemm_nt_splitk(t.g, I, P.w2, I, t.z2, d, nc, d, I, MMT_EPI_BIAS_DROP_RES, &e, t.slabs, stream));
-      TRY(mmt_ln_fwd_scatter(t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, b->out_rows, nullptr, t.mean2, t.rstd2, nc, d,
-                             stream));
+      // the nc read-out rows are returned COMPACT: out_last[i] = sequence_output[out_rows[i]], i < nc
+      TRY(mmt_ln_fwd(t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, t.dy /* bf16 copy nobody reads */, t.mean2, t.rstd2, nc, d,
+                     nullptr, stream));
       break;
     }
     TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
@@ -228,8 +231,8 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
       TailWs& t = w.t;
       const int crpb = mmt_ln_bwd_rows_per_block(nc);
       const int cblocks = (nc + crpb - 1) / crpb;
-      TRY(mmt_rows_gather(dlast, b->out_rows, nc, d, t.dcur, nullptr, nullptr, stream));
-      TRY(mmt_ln_bwd(t.dcur, t.z2, t.mean2, t.rstd2, P.ln2_g, t.dz, t.dy2, w.ln_partials[2 * l + 2], nc, d, 1, nullptr,
+      // dlast holds the gradient of the COMPACT read-out rows in its first nc rows (it becomes scratch afterwards)
+      TRY(mmt_ln_bwd(dlast, t.z2, t.mean2, t.rstd2, P.ln2_g, t.dz, t.dy2, w.ln_partials[2 * l + 2], nc, d, 1, nullptr,
                      t.rowidx, site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
       add_job(w.ln_partials[2 * l + 2], cblocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
       MmtEpilogue e = {};

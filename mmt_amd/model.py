@@ -100,7 +100,8 @@ class _ReadoutFn(torch.autograd.Function):
   """vid_embds[b, m] = F.normalize(sequence_output[agg_row[b, m]])  (model.py:583-587, 621-625)."""
 
   @staticmethod
-  def forward(ctx, last, agg_row, bm):
+  def forward(ctx, last, agg_row, bm, compact=False):
+    ctx.compact = compact
     d = last.shape[1]
     out = torch.empty(bm, d, device=last.device, dtype=torch.float32)
     inv = torch.empty(bm, device=last.device, dtype=torch.float32)
@@ -113,10 +114,11 @@ class _ReadoutFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dout):
     out, inv, agg_row = ctx.saved_tensors
-    dlast = torch.zeros(ctx.shape, device=out.device, dtype=torch.float32)
+    # compact engine output: only the first B*M rows exist, no zero fill of the other token rows is needed
+    dlast = (torch.empty if ctx.compact else torch.zeros)(ctx.shape, device=out.device, dtype=torch.float32)
     check(_lib.lib().mmt_readout_bwd(ops._p(out), ops._p(inv), ops._p(dout.contiguous()), ops._p(agg_row),
                                      out.shape[0], out.shape[1], ops._p(dlast), ops._stream()), 'mmt_readout_bwd')
-    return dlast, None, None
+    return dlast, None, None, None
 
 
 class _SimsFn(torch.autograd.Function):
@@ -220,6 +222,7 @@ class _VideoPlan:
     self.pos_ids = torch.zeros(self.rows_alloc, **i32)
     self.mask_bias = torch.zeros(self.rows_alloc, device=device, dtype=torch.float32)
     self.agg_row = torch.zeros(bsz * m, **i32)
+    self.compact_rows = None
     self.features = None
     self.src_rows = bsz * (t + 1)
     self.src_rows_pad = _round_up(self.src_rows, 128)
@@ -257,6 +260,7 @@ class CENet(nn.Module):
     self.pack_tokens = pack_tokens
     # the read-out only uses the AGG rows (model.py:583-587): let the last layer compute just those (exact)
     self.tail_rows_only = True
+    self._vid_weights = {}
     self.overlap_text_heads = False  # measured: no gain on MI355X (1.76 vs 1.74 ms/step), kept as an option
     self._side_streams = {}
     unsupported = []
@@ -442,7 +446,12 @@ class CENet(nn.Module):
                         n_rows_dev=plan.n_rows if self.pack_tokens else None,
                         out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
     last = self.vid_bert.run_engine(batch, feats)
-    vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
+    if self.vid_bert.compact_output(batch, plan.rows_alloc):  # the engine returned just the AGG rows, in agg_row order
+      if plan.compact_rows is None:
+        plan.compact_rows = torch.arange(bsz * len(mods), device=dev, dtype=torch.int32)
+      vid = _ReadoutFn.apply(last, plan.compact_rows, bsz * len(mods), True)
+    else:
+      vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
     return vid.view(bsz, len(mods), self.same_dim)
 
   # ---- text heads (native) -------------------------------------------------------------------------
@@ -527,6 +536,10 @@ class CENet(nn.Module):
   def text_features(self, token_ids, device):
     """model/model.py:349-379: (B, C, W, 2) -> (B*C, text_dim) via the text tower's [CLS]."""
     b, c, w, f = token_ids.size()
+    if getattr(self.txt_bert, 'ignores_token_inputs', False):  # a precomputed-feature stand-in: skip the id/mask prep
+      out = self.txt_bert(None)
+      return out[0][:, 0] if self.post_agg == 'cls' else (torch.max(out[0][:, 1:], 1)[0] if self.post_agg == 'mxp'
+                                                          else torch.mean(out[0][:, 1:], 1))
     tok = token_ids.view(b * c, w, f).to(device)
     input_ids = tok[:, :, 0].long()
     attention_mask = tok[:, :, 1].long()
@@ -583,7 +596,10 @@ class CENet(nn.Module):
       cur.wait_stream(side)
       for t in (text_embds, text_weights):
         t.record_stream(cur)
-    vid_weights = torch.full((b, m), 1.0 / m, device=dev)                       # ones, L1-normalised model.py:594,607
+    vw_key = (b, m, dev)
+    vid_weights = self._vid_weights.get(vw_key)                                   # ones, L1-normalised model.py:594,607
+    if vid_weights is None:
+      vid_weights = self._vid_weights[vw_key] = torch.full((b, m), 1.0 / m, device=dev)
     merge = 'avg' if self.training else self.test_caption_mode                  # model.py:627-631
     self.merge_caption_similarities = merge
     if out == 'conf':

@@ -111,6 +111,9 @@ class GraphedTrainStep:
     return out
 
   def _loss_backward(self, e, g):
+    fast = self._fast_loss_backward(e, g)
+    if fast is not None:
+      return fast
     leaves = {k: v.detach().requires_grad_(e[k].requires_grad) for k, v in g.items()}
     sims = cross_view_similarity(leaves['vid_embds'], leaves['text_embds'], leaves['vid_weights'],
                                  leaves['text_weights'], 'avg')
@@ -121,6 +124,52 @@ class GraphedTrainStep:
     sl = slice(self.rank * b, (self.rank + 1) * b)
     torch.autograd.backward([e[k] for k in need], [gr[sl] for gr in grads])
     return loss.detach()
+
+  def _fast_loss_backward(self, e, g):
+    """Our own similarity + loss kernels called directly (no autograd bookkeeping for this tiny sub-graph: saves the
+    ones_like / multiply / slice launches): global sims -> loss + dL/dsims in one kernel -> similarity backward ->
+    the local rows' gradients pushed into graph A's autograd graph.  None = not applicable (foreign loss module,
+    several captions per video): the generic autograd path is used."""
+    import ctypes
+
+    from . import _lib, ops
+    from .loss import InfoNceLoss, MaxMarginRankingLoss
+    from ._lib import check
+    if not isinstance(self.loss_fn, (MaxMarginRankingLoss, InfoNceLoss)) or g['text_embds'].shape[2] != 1:
+      return None
+    if g['vid_weights'].requires_grad or e['vid_weights'].requires_grad:
+      return None
+    L = _lib.lib()
+    vid = g['vid_embds'].detach().contiguous().float()
+    n, m, d = vid.shape
+    txt = g['text_embds'].detach().reshape(n, m, d).contiguous().float()  # C == 1: (n, M, 1, d) -> (n, M, d) is a view
+    tw = g['text_weights'].detach().reshape(n, m).contiguous().float()
+    vw = g['vid_weights'].detach().reshape(n, m).contiguous().float()
+    dev = vid.device
+    sims = torch.empty(n, n, device=dev, dtype=torch.float32)
+    dots = torch.empty(n, n, m, device=dev, dtype=torch.float32)
+    check(L.mmt_sims_fwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), n, n, m, d, ops._p(sims), ops._p(dots),
+                         ops._stream()), 'mmt_sims_fwd')
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad = torch.empty(n, n, device=dev, dtype=torch.float32)
+    scratch = torch.empty(3 * n, device=dev, dtype=torch.float32)
+    if isinstance(self.loss_fn, MaxMarginRankingLoss):
+      check(L.mmt_maxmargin(ops._p(sims), n, float(self.loss_fn.margin), int(self.loss_fn.fix_norm), ops._p(scratch),
+                            ops._p(loss), ops._p(grad), ops._stream()), 'mmt_maxmargin')
+    else:
+      check(L.mmt_infonce(ops._p(sims), n, ops._p(scratch), ops._p(loss), ops._p(grad), ops._stream()), 'mmt_infonce')
+    dtxt, dvid, dtw, dvw = (torch.empty_like(x) for x in (txt, vid, tw, vw))
+    check(L.mmt_sims_bwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), ops._p(dots), ops._p(grad), n, n, m, d,
+                         ops._p(dtxt), ops._p(dvid), ops._p(dtw), ops._p(dvw), ops._stream()), 'mmt_sims_bwd')
+    b = e['vid_embds'].shape[0]
+    sl = slice(self.rank * b, (self.rank + 1) * b)
+    outs, grads = [], []
+    for k, gfull in (('vid_embds', dvid), ('text_embds', dtxt.view(n, m, 1, d)), ('text_weights', dtw.view(n, 1, m))):
+      if e[k].requires_grad:
+        outs.append(e[k])
+        grads.append(gfull[sl])
+    torch.autograd.backward(outs, grads)
+    return loss
 
   def _zero(self):
     self.opt_flat.zero_grad()
