@@ -165,6 +165,8 @@ def main():
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--dense', action='store_true', help='keep padded tokens (no variable-length packing)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--grad-sync', choices=['auto', 'staged', 'single'], default='auto',
+                  help='auto: staged backward with per-stage all-reduce when N > 1; staged/single force either')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
   args = ap.parse_args()
 
@@ -195,7 +197,8 @@ def main():
   static = FlatMinibatch(batches[0], dev)
   model.txt_bert.text = static['text']
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
-  runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager)
+  runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
+                            overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync])
   it = 0
   first_loss = None
   for _ in range(args.warmup):
@@ -244,7 +247,7 @@ def main():
         'config': {'workload': 'configs[1]: MSRVTT jsfusion shape, 7 experts x 30 tokens, d512, L4, H4, I3072, '
                                'batch 32/GPU, dropout 0.1, train mode, Adam; text tower replaced by synthetic '
                                '(B,768) vectors', 'global_batch': world * BATCH, 'seq_len': seq,
-                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager,
+                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'grad_sync': 'staged' if runner.staged else 'single',
                    'live_rows_rank0': live, 'dense_rows': BATCH * seq},
         'encoder_dense_tflops': pairs_per_s / BATCH * flops / 1e12 / world,
         'encoder_dense_mfma_frac': pairs_per_s / BATCH * flops / 1e12 / world / BF16_DENSE_PEAK_TFLOPS,

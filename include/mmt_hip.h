@@ -389,6 +389,12 @@ int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, flo
  * accumulated) through the g_* pointers. */
 int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast, float* dfeatures,
                       int training, void* stream);
+/* The same backward, layers l_hi .. l_lo only (descending; the embedding stage runs with layer 0), so that a
+ * data-parallel caller can start the all-reduce of a finished layer's gradients while the layers below still run
+ * (the reference's DataParallel reduces after the whole backward, trainer/trainer.py:185-199).  Calls must cover
+ * layers-1 .. 0 in descending order with the same dlast / dfeatures / ws. */
+int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast, float* dfeatures,
+                            int training, int l_hi, int l_lo, void* stream);
 
 /* Measurement hook (bench.py): arm n pairs of caller-created hipEvent_t; each mmt_bert_forward then
  * records one pair around layer 0's FFN up-projection GEMM launch (the dominant kernel) on its stream.

@@ -163,6 +163,8 @@ SIGNATURES = {
     'mmt_bert_forward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_int, c_vp]),
     'mmt_bert_backward': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp, c_int,
                                   c_vp]),
+    'mmt_bert_backward_range': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp,
+                                        c_int, c_int, c_int, c_vp]),
     'mmt_sgemm_batched': (c_int, [ctypes.POINTER(MmtSgemm), c_vp]),
     'mmt_text_heads_workspace_floats': (c_i64, [c_int, c_int, c_int]),
     'mmt_text_heads_fwd': (c_int, [ctypes.POINTER(MmtTextHeads), c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,

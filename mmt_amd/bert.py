@@ -318,6 +318,16 @@ class BertModel(nn.Module):
     return out
 
   def _engine_backward(self, batch, dout, training):
+    run = self.backward_ranges(batch, dout, training)
+    run(self.config.num_hidden_layers - 1, 0)
+    grad_buf = self._flat.current_grad()
+    grads = [self._flat.view(p, grad_buf) if p.requires_grad else None for p in self.trainable_engine_params()]
+    return run.dfeat, grads
+
+  def backward_ranges(self, batch, dout, training):
+    """-> run(l_hi, l_lo): the engine backward of layers l_hi .. l_lo (descending; embeddings with layer 0), to be
+    called range by range from the top layer down (mmt_bert_backward_range); run.dfeat holds the gradient wrt the
+    engine's input features after the range that ends at layer 0.  Parameter gradients land in the flat buffer."""
     rows_alloc = batch.features.shape[0]
     grad_buf = self._flat.current_grad()
     m, _ = self._struct(grad_buf)
@@ -329,10 +339,15 @@ class BertModel(nn.Module):
       dlast = dout.contiguous().clone()  # the engine uses it as scratch
     dfeat = torch.empty_like(dlast)
     b = self._batch_struct(batch, rows_alloc)
-    check(_lib.lib().mmt_bert_backward(ctypes.byref(m), ctypes.byref(b), ws.data_ptr(), dlast.data_ptr(),
-                                       dfeat.data_ptr(), int(training), ops._stream()), 'mmt_bert_backward')
-    grads = [self._flat.view(p, grad_buf) if p.requires_grad else None for p in self.trainable_engine_params()]
-    return dfeat, grads
+    L = _lib.lib()
+
+    def run(l_hi, l_lo):
+      check(L.mmt_bert_backward_range(ctypes.byref(m), ctypes.byref(b), ws.data_ptr(), dlast.data_ptr(),
+                                      dfeat.data_ptr(), int(training), int(l_hi), int(l_lo), ops._stream()),
+            'mmt_bert_backward_range')
+
+    run.dfeat, run.keep = dfeat, (dlast, ws, m, b)
+    return run
 
   def run_engine(self, batch, features):
     """features: fp32 [rows_alloc, hidden] (may require grad) -> sequence_output rows [rows_alloc, hidden]."""

@@ -198,10 +198,13 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
   return 0;
 }
 
-extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
-                                 float* dfeatures, int training, void* stream) {
+// Layers l_hi .. l_lo (descending); the embedding stage runs with layer 0.  A full backward is (layers-1, 0); a caller
+// that wants to start reducing a layer's gradients over ranks while the next layers still run calls it range by range
+// (the buffers that carry the running gradient between calls are determined by the layer index alone).
+extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
+                                       float* dfeatures, int training, int l_hi, int l_lo, void* stream) {
   TRY(check_model(m, b));
-  if (!ws || !dlast || !dfeatures) return MMT_ERR_ARG;
+  if (!ws || !dlast || !dfeatures || l_hi >= m->layers || l_lo < 0 || l_lo > l_hi) return MMT_ERR_ARG;
   Ws w;
   layout(m, b->rows_alloc, (char*)ws, &w);
   const int d = m->hidden, I = m->inter, rows = b->rows;
@@ -221,8 +224,9 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     j.partials = partials; j.nblocks = nblocks; j.nvec = nvec; j.nout = nout; j.d = dd; j.out[0] = o0; j.out[1] = o1;
   };
   const int nc = tail_rows(b, w);
-  float* dcur = dlast;  // gradient wrt the current layer's output
-  for (int l = m->layers - 1; l >= 0; --l) {
+  // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
+  float* dcur = ((m->layers - 1 - l_hi) & 1) ? w.dA : dlast;
+  for (int l = l_hi; l >= l_lo; --l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
@@ -315,6 +319,7 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     }
     dcur = dnext;
   }
+  if (l_lo > 0) return njobs ? mmt_col_reduce_multi(jobs, njobs, stream) : 0;
   // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---
   TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials[0], rows, d, 2, nr,
                  b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
@@ -327,4 +332,10 @@ extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, v
     add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
   }
   return mmt_col_reduce_multi(jobs, njobs, stream);
+}
+
+extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
+                                 float* dfeatures, int training, void* stream) {
+  if (!m) return MMT_ERR_ARG;
+  return mmt_bert_backward_range(m, b, ws, dlast, dfeatures, training, m->layers - 1, 0, stream);
 }

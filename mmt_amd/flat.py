@@ -90,6 +90,16 @@ class FlatParams:
     buf = self.master if buf is None else buf
     return buf.data_ptr() + 4 * self.offsets[id(p)]
 
+  def span(self, params):
+    """(offset, count) of the contiguous run of the flat layout that holds exactly `params`."""
+    ids = {id(p) for p in params}
+    lo = min(self.offsets[i] for i in ids)
+    hi = max(self.offsets[id(p)] + _round_up(p.numel(), ALIGN) for p in params)
+    inside = [p for p in self.params if lo <= self.offsets[id(p)] < hi]
+    if {id(p) for p in inside} != ids:
+      raise ValueError('parameters are not one contiguous run of the flat layout')
+    return lo, hi - lo
+
   def current_grad(self):
     """The buffer every backward function of the current step writes (chosen by select_grad_buffer)."""
     return self.grads[self._which]

@@ -356,10 +356,29 @@ class CENet(nn.Module):
                             k_pad=_round_up(dim, 128))
     self.vid_bert.attach_flat(self._flat)
     self._plans = {}
+    self._stages = None
 
   def __str__(self):
     n = sum(p.numel() for p in self.parameters() if p.requires_grad)
     return super().__str__() + '\nTrainable parameters: {}'.format(n)
+
+  def grad_regions(self):
+    """Contiguous (offset, count) spans of the flat gradient buffer in the order the backward finishes them:
+    [('text', ...), ('layer<L-1>', ...), ..., ('layer0' incl. embeddings, ...), ('reduce', ...)]."""
+    f, vb = self._flat, self.vid_bert
+    n_layers = vb.config.num_hidden_layers
+    named = vb.engine_named_params()
+    per_layer = [[p for n, p in named if n.startswith('encoder.layer.%d.' % l)] for l in range(n_layers)]
+    emb = [p for n, p in named if n.startswith('embeddings.')]
+    reduce_ = self._reduce_params()
+    out = []
+    if self._native_text_heads:
+      out.append(('text', f.span(self._text_head_params())))
+    for l in range(n_layers - 1, 0, -1):
+      out.append(('layer%d' % l, f.span(per_layer[l])))
+    out.append(('layer0', f.span(emb + per_layer[0])))
+    out.append(('reduce', f.span(reduce_)))
+    return out
 
   def engine_params(self):
     """Parameters living in the flat buffer (video side), in layout order."""
@@ -446,6 +465,8 @@ class CENet(nn.Module):
                         n_rows_dev=plan.n_rows if self.pack_tokens else None,
                         out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
     last = self.vid_bert.run_engine(batch, feats)
+    # handles for callers that drive the backward of this forward stage by stage (train_step.GraphedTrainStep)
+    self._stages = dict(plan=plan, feats=feats, batch=batch, last=last) if last.requires_grad else None
     if self.vid_bert.compact_output(batch, plan.rows_alloc):  # the engine returned just the AGG rows, in agg_row order
       if plan.compact_rows is None:
         plan.compact_rows = torch.arange(bsz * len(mods), device=dev, dtype=torch.int32)

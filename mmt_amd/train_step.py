@@ -11,6 +11,18 @@ keeps the two RCCL collectives OUTSIDE of them (so nothing depends on collective
     eager   : all-reduce(SUM) of the flat gradient buffer + text-head bucket   (skipped at world size 1)
     graph C : optimizer step (fused flat Adam + capturable torch Adam for the rest)
 
+With more than one rank the 68 MB gradient all-reduce would sit exposed between B and C (about a quarter of the step
+on 8 GPUs over xGMI rings).  `overlap_grad_sync` (default: on when world size > 1) therefore cuts graph B at the
+points where a contiguous span of the flat gradient buffer is final -- similarity/loss + text heads, then every
+encoder layer from the top down, then embeddings + the expert projections -- and starts that span's all-reduce on
+RCCL's stream while the next stage's graph runs:
+
+    B0 loss, text heads, read-out | all-reduce(text)   B1 layer L-1 | all-reduce(layer L-1)   ...
+    Bk layer 0 + embeddings + video tokens | all-reduce(layer 0, reduce-dim)   wait   C
+
+The stages call the engine's range backward (mmt_bert_backward_range) directly instead of through autograd, so each
+stage is a plain kernel sequence that captures into its own graph; the collectives stay eager.
+
 Everything data-dependent lives in device memory (live row count of the token packing, dropout seed,
 Adam step counter), so replays are correct for new minibatches copied into the static input buffers.
 """
@@ -66,11 +78,16 @@ def _copy_tree(dst, src):
 
 class GraphedTrainStep:
 
-  def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3):
-    """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers)."""
+  def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
+               overlap_grad_sync=None):
+    """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
+    overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
+    backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    self._want_stages = self.world > 1 if overlap_grad_sync is None else bool(overlap_grad_sync)
+    self.staged = False
     self.static = minibatch
     flat_ids = {id(p) for p in model.engine_params()}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
@@ -85,8 +102,10 @@ class GraphedTrainStep:
     self._stream = torch.cuda.Stream()
     self._stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._stream):
-      for _ in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
+      for i in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
         self._eager_step()
+        if i == 0 and self._want_stages:
+          self.staged = self._stageable([p for p in rest if p.grad is not None])  # e.g. the unused pooler: no grad
     torch.cuda.current_stream().wait_stream(self._stream)
     if use_graphs:
       self._capture()
@@ -111,9 +130,11 @@ class GraphedTrainStep:
     return out
 
   def _loss_backward(self, e, g):
-    fast = self._fast_loss_backward(e, g)
+    fast = self._fast_loss_grads(e, g)
     if fast is not None:
-      return fast
+      loss, outs, grads = fast
+      torch.autograd.backward(outs, grads)
+      return loss
     leaves = {k: v.detach().requires_grad_(e[k].requires_grad) for k, v in g.items()}
     sims = cross_view_similarity(leaves['vid_embds'], leaves['text_embds'], leaves['vid_weights'],
                                  leaves['text_weights'], 'avg')
@@ -125,11 +146,11 @@ class GraphedTrainStep:
     torch.autograd.backward([e[k] for k in need], [gr[sl] for gr in grads])
     return loss.detach()
 
-  def _fast_loss_backward(self, e, g):
+  def _fast_loss_grads(self, e, g):
     """Our own similarity + loss kernels called directly (no autograd bookkeeping for this tiny sub-graph: saves the
     ones_like / multiply / slice launches): global sims -> loss + dL/dsims in one kernel -> similarity backward ->
-    the local rows' gradients pushed into graph A's autograd graph.  None = not applicable (foreign loss module,
-    several captions per video): the generic autograd path is used."""
+    (loss, [local outputs of graph A that need a gradient], [their gradients]).  None = not applicable (foreign loss
+    module, several captions per video): the generic autograd path is used."""
     import ctypes
 
     from . import _lib, ops
@@ -168,8 +189,57 @@ class GraphedTrainStep:
       if e[k].requires_grad:
         outs.append(e[k])
         grads.append(gfull[sl])
-    torch.autograd.backward(outs, grads)
-    return loss
+    return loss, outs, grads
+
+  # ---- staged backward (gradient all-reduce overlapped with the remaining backward) -----------------
+  def _stageable(self, rest):
+    m = self.model
+    st = getattr(m, '_stages', None)
+    if rest or st is None or not getattr(m, '_native_text_heads', False):
+      return False
+    from .loss import InfoNceLoss, MaxMarginRankingLoss
+    if not isinstance(self.loss_fn, (MaxMarginRankingLoss, InfoNceLoss)):
+      return False
+    return all(p.requires_grad for p in m._flat.params)
+
+  def _stage_list(self, e, g):
+    """[(callable, [names of the flat-gradient regions that are final once it has run])], in execution order."""
+    model, vb = self.model, self.model.vid_bert
+    st = {}
+
+    def head():
+      fast = self._fast_loss_grads(e, g)
+      if fast is None:
+        raise RuntimeError('staged backward needs one caption per video and the native losses')
+      self.loss, outs, grads = fast
+      pairs = list(zip(outs, grads))
+      txt = [(o, gr) for o, gr in pairs if o is not e['vid_embds']]
+      if txt:
+        torch.autograd.backward([o for o, _ in txt], [gr for _, gr in txt])  # text heads
+      gvid = next(gr for o, gr in pairs if o is e['vid_embds'])
+      h = model._stages
+      dlast, = torch.autograd.grad([e['vid_embds']], [h['last']], [gvid])  # read-out backward only
+      st['run'] = vb.backward_ranges(h['batch'], dlast, vb.training)
+
+    def bottom():
+      st['run'](0, 0)
+      model._video_tokens_backward(model._stages['plan'], st['run'].dfeat)
+
+    stages = [(head, ['text'])]
+    for l in range(vb.config.num_hidden_layers - 1, 0, -1):
+      stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
+    stages.append((bottom, ['layer0', 'reduce']))
+    return stages
+
+  def _reduce_async(self, names):
+    if self.world == 1:
+      return []
+    gbuf = self.model._flat.current_grad()
+    out = []
+    for n in names:
+      off, cnt = self._regions[n]
+      out.append(dist.all_reduce(gbuf[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    return out
 
   def _zero(self):
     self.opt_flat.zero_grad()
@@ -187,8 +257,17 @@ class GraphedTrainStep:
     self._zero()
     e = self._forward()
     g = self._gather(e)
-    self.loss = self._loss_backward(e, g)
-    self.sync.sync()
+    if self.staged:
+      self._regions = dict(self.model.grad_regions())
+      handles = []
+      for fn, names in self._stage_list(e, g):
+        fn()
+        handles += self._reduce_async(names)
+      for h in handles:
+        h.wait()
+    else:
+      self.loss = self._loss_backward(e, g)
+      self.sync.sync()
     self._opt()
 
   # ---- capture -----------------------------------------------------------------------------------
@@ -204,8 +283,17 @@ class GraphedTrainStep:
                     for k, v in e.items()}
     with torch.cuda.stream(self._stream):
       g = self._gather(e)
-    with torch.cuda.graph(gb, pool=pool, stream=self._stream):
-      self.loss = self._loss_backward(e, g)
+    if self.staged:
+      self._regions = dict(self.model.grad_regions())
+      gb = []
+      for fn, names in self._stage_list(e, g):
+        gs = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gs, pool=pool, stream=self._stream):
+          fn()
+        gb.append((gs, names))
+    else:
+      with torch.cuda.graph(gb, pool=pool, stream=self._stream):
+        self.loss = self._loss_backward(e, g)
     with torch.cuda.graph(gc, pool=pool, stream=self._stream):
       self._opt()
     self._graphs, self._e = (ga, gb, gc), e
@@ -229,7 +317,15 @@ class GraphedTrainStep:
     ga.replay()
     if self.world > 1:
       self._gather(self._e)
-    gb.replay()
-    self.sync.sync()
+    if self.staged:
+      handles = []
+      for gs, names in gb:
+        gs.replay()
+        handles += self._reduce_async(names)
+      for h in handles:
+        h.wait()
+    else:
+      gb.replay()
+      self.sync.sync()
     gc.replay()
     return self.loss

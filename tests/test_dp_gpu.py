@@ -48,7 +48,7 @@ def _slice_batch(mb, text, sl):
   return out
 
 
-def _run(rank, world, dev):
+def _run(rank, world, dev, overlap=None):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
@@ -57,7 +57,9 @@ def _run(rank, world, dev):
   b = BATCH // world
   static = FlatMinibatch(_slice_batch(mb, text, slice(rank * b, (rank + 1) * b)), dev)
   model.txt_bert.text = static['text']
-  runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1)
+  runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
+                            overlap_grad_sync=overlap)
+  assert runner.staged == (world > 1 if overlap is None else overlap)
   runner._eager_step()  # one un-captured step: its (all-reduced) gradient buffer is what we compare
   torch.cuda.synchronize()
   grad_after_warmup = model._flat.current_grad().detach().clone().cpu()
@@ -93,3 +95,14 @@ def test_two_ranks_equal_single_process_global_batch(tmp_path):
   assert max(abs(a - b) for a, b in zip(r0['losses'], losses1)) < 1e-4
   assert r0['losses'][0] > 0 and all(l == l for l in r0['losses'])
   assert (r0['master'] - r1['master']).abs().max() < 1e-6  # replicas stay in lock-step
+
+
+def test_staged_backward_equals_single_graph_backward():
+  """The stage-by-stage backward (graph B cut where gradient spans become final, so that their all-reduce can start
+  early) launches the same kernels as the one-graph backward: identical gradients, losses and weights."""
+  dev = torch.device('cuda', 0)
+  g0, l0, m0 = _run(0, 1, dev, overlap=False)
+  g1, l1, m1 = _run(0, 1, dev, overlap=True)
+  assert l0 == l1
+  assert torch.equal(g0, g1)
+  assert torch.equal(m0, m1)
