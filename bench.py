@@ -175,11 +175,19 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
     raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+  # Test hook (1-GPU boxes): MMT_BENCH_BACKEND=gloo runs every rank on cuda:0 with gloo moving the tensors, to exercise
+  # the N > 1 control flow end to end where no second GPU exists.  The default is one GPU per rank over RCCL.
+  backend = os.environ.get('MMT_BENCH_BACKEND', 'nccl')
+  if backend != 'nccl':
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
 
   torch.manual_seed(0)
   model = build_model(pack=not args.dense).to(dev).train()
@@ -218,7 +226,7 @@ def main():
     dist.barrier()
   elapsed = time.perf_counter() - t0
   if world > 1:
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
   final_loss = float(loss.item())
