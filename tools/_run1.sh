@@ -1,4 +1,5 @@
 cd /root/repo
-timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['first_loss'], d['final_loss'])"
-export MMT_BENCH_BACKEND=gloo
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 100 --warmup 10 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['first_loss'], d['final_loss'])"
+timeout 900 python -m pytest tests/test_dp_gpu.py -x -q 2>&1 | tail -1 | cut -c1-300
+P='import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["final_loss"])'
+timeout 300 python bench.py --steps 200 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+timeout 300 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --dense 2>&1 | tail -1 | python -c "$P"
