@@ -78,6 +78,12 @@ int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K);
 int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        int epilogue, const MmtEpilogue* epi, float* ws, void* stream);
+/* The same with explicit control: splits (<= 0: up to 16), wide != 0: 128x128 tiles (N % 128 == 0), n_rows_dev (nullable):
+ * device count of live rows, no_epilogue != 0: only the partial slabs are produced (slab s at ws + s*round_up(M,128)*N,
+ * leading dimension N) for a consumer that sums them itself. */
+int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                          int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide, const int32_t* n_rows_dev,
+                          int no_epilogue, void* stream);
 
 /* Several independent C_i[M_i,N_i] = A_i . B_i^T (+ bias_i) in ONE launch (epilogue MMT_EPI_BIAS_F32 / MMT_EPI_F32):
  * the per-expert ReduceDim.fc projections of model/model.py:426-437 (seven GEMMs with different K). */

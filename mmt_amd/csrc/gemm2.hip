@@ -312,19 +312,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
 template <int BM, int BN, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ ws,
-    int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk) {
+    int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk, const int32_t* __restrict__ n_rows_dev) {
   const int z = blockIdx.y;
   const int kb = z * kchunk;
   const int kl = min(kchunk, K - kb);
   MmtEpilogue e = {};
   gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32>(A + kb, lda, B + kb, ldb, ws + (int64_t)z * slab_stride, ldws, M, N, kl, e,
-                                                 nullptr, (int)blockIdx.x, (int)gridDim.x);
+                                                 n_rows_dev, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int64_t slab_stride, int64_t ldws,
                                                               int splits, void* __restrict__ Cout, int64_t ldc, int M, int N,
-                                                              MmtEpilogue epi) {
+                                                              MmtEpilogue epi, const int32_t* __restrict__ n_rows_dev) {
+  if (n_rows_dev) M = min(M, *n_rows_dev);
   const int n4 = N >> 2;
   unsigned dkey = 0;
   if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
@@ -365,21 +366,9 @@ extern "C" int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K) {
   return (int64_t)(splits < 1 ? 1 : splits) * ((M + 127) / 128 * 128) * N;
 }
 
-// epilogue: MMT_EPI_BF16 / F32 / BIAS_F32 / ADD_F32 / BIAS_DROP_RES.  ws: mmt_gemm_nt_splitk_workspace_floats() floats.
-extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
-                                  int K, int epilogue, const MmtEpilogue* epi, float* ws, void* stream) {
-  if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || K % BK || N % 64) return MMT_ERR_ARG;
-  if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
-    return MMT_ERR_ALIGN;
-  MmtEpilogue e = {};
-  if (epi) e = *epi;
-  constexpr int BM = 128, BN = 64, WGM = 4, WGN = 2, NS = 3;
-  const int ksteps = K / BK;
-  int splits = ksteps < 16 ? ksteps : 16;
-  const int per = (ksteps + splits - 1) / splits;       // K-steps per slice
-  splits = (ksteps + per - 1) / per;
-  const int Mpad = (M + 127) / 128 * 128;
-  const int64_t slab = (int64_t)Mpad * N;
+template <int BM, int BN, int WGM, int WGN, int NS>
+static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* ws, int64_t slab, int M, int Mpad,
+                         int N, int K, int splits, int per, const int32_t* nr, hipStream_t s) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   static bool configured = false;
   if (!configured) {
@@ -388,12 +377,43 @@ extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
+  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>), dim3((Mpad / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
+                     lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr);
+  return 0;
+}
+
+// epilogue: MMT_EPI_BF16 / F32 / BIAS_F32 / ADD_F32 / BIAS_DROP_RES.  ws: mmt_gemm_nt_splitk_workspace_floats() floats
+// (slab s = ws + s * round_up(M,128) * N, leading dimension N).
+// splits <= 0: as many as there are K-steps, at most 16 (skinny problems).  wide: 128x128 tiles (N % 128 == 0) instead of
+// 128x64.  n_rows_dev (nullable): device count of live rows (token packing).  no_epilogue: leave the partial slabs for a
+// consumer that sums them itself (mmt_ln_fwd / mmt_ln_bwd with a slab source); C and epi are then unused.
+extern "C" int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
+                                     int N, int K, int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide,
+                                     const int32_t* n_rows_dev, int no_epilogue, void* stream) {
+  if (!A || !B || (!C && !no_epilogue) || !ws || M <= 0 || N <= 0 || K <= 0 || K % BK || N % 64 || (wide && N % 128))
+    return MMT_ERR_ARG;
+  if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
+    return MMT_ERR_ALIGN;
+  MmtEpilogue e = {};
+  if (epi) e = *epi;
+  const int ksteps = K / BK;
+  if (splits <= 0) splits = 16;
+  if (splits > ksteps) splits = ksteps;
+  if (splits > 16) splits = 16;
+  const int per = (ksteps + splits - 1) / splits;       // K-steps per slice
+  splits = (ksteps + per - 1) / per;
+  const int Mpad = (M + 127) / 128 * 128;
+  const int64_t slab = (int64_t)Mpad * N;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>), dim3((Mpad / BM) * (N / BN), splits), dim3(512), lds, s,
-                     (const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK);
+  int rc = wide ? launch_splitk<128, 128, 2, 4, 2>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, M, Mpad, N, K, splits,
+                                                   per, n_rows_dev, s)
+                : launch_splitk<128, 64, 4, 2, 3>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, M, Mpad, N, K, splits,
+                                                  per, n_rows_dev, s);
+  if (rc) return rc;
+  if (no_epilogue) return (int)hipGetLastError();
   const int64_t items = (int64_t)M * (N / 4);
   const int grid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
-#define SK_EPI(E) hipLaunchKernelGGL(splitk_epilogue_kernel<E>, dim3(grid), dim3(256), 0, s, ws, slab, (int64_t)N, splits, C, ldc, M, N, e)
+#define SK_EPI(E) hipLaunchKernelGGL(splitk_epilogue_kernel<E>, dim3(grid), dim3(256), 0, s, ws, slab, (int64_t)N, splits, C, ldc, M, N, e, n_rows_dev)
   switch (epilogue) {
     case MMT_EPI_BF16: SK_EPI(MMT_EPI_BF16); break;
     case MMT_EPI_F32: SK_EPI(MMT_EPI_F32); break;
@@ -404,6 +424,11 @@ extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int
   }
 #undef SK_EPI
   return (int)hipGetLastError();
+}
+
+extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                                  int K, int epilogue, const MmtEpilogue* epi, float* ws, void* stream) {
+  return mmt_gemm_nt_splitk_ex(A, lda, B, ldb, C, ldc, M, N, K, epilogue, epi, ws, 0, 0, nullptr, 0, stream);
 }
 
 // Several independent small GEMMs (the per-expert ReduceDim projections, model/model.py:426-437) in ONE launch:

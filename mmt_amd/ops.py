@@ -80,7 +80,7 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
 
 
 def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_index=None, drop_key=0, drop_p=0.0,
-                   seed_dev=None):
+                   seed_dev=None, splits=0, wide=False, n_rows_dev=None, no_epilogue=False, ws=None):
   """Split-K variant of gemm_nt for skinny problems (few rows, long K)."""
   _need_cuda(a, b, out)
   M = a.shape[0] if m is None else m
@@ -94,9 +94,12 @@ def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_i
   e.drop_key, e.drop_thr16, e.drop_scale = drop_key, thr, scale
   e.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None
   L = _lib.lib()
-  ws = torch.empty(L.mmt_gemm_nt_splitk_workspace_floats(M, N, K), device=a.device, dtype=torch.float32)
-  check(L.mmt_gemm_nt_splitk(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, EPI[epilogue],
-                             ctypes.byref(e), _p(ws), _stream()), 'mmt_gemm_nt_splitk')
+  if ws is None:
+    ws = torch.empty(L.mmt_gemm_nt_splitk_workspace_floats(M, N, K), device=a.device, dtype=torch.float32)
+  check(L.mmt_gemm_nt_splitk_ex(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, EPI[epilogue],
+                                ctypes.byref(e), _p(ws), int(splits), int(wide),
+                                _p(n_rows_dev) if n_rows_dev is not None else None, int(no_epilogue), _stream()),
+        'mmt_gemm_nt_splitk_ex')
   return out
 
 
