@@ -1,0 +1,51 @@
+"""Attention kernel lab: forward / backward time as a function of sequence length and batch (HIP-graph replay timing),
+to separate per-block latency from throughput.  python tools/attn_lab.py"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmt_amd import _lib, ops  # noqa: E402
+from mmt_amd.ops import _p, _stream  # noqa: E402
+from tools.gemm_lab import timeit  # noqa: E402
+
+dev = torch.device('cuda:0')
+H, d = 4, 512
+
+
+def case(B, S, drop_p):
+  rows = B * S
+  R = ops.pad_rows(rows)
+  qkv = (torch.randn(R, 3 * d, device=dev) * 0.5).to(torch.bfloat16)
+  mask = torch.zeros(R, device=dev)
+  cu = torch.arange(0, B + 1, device=dev, dtype=torch.int32) * S
+  ctx = torch.zeros(R, d, device=dev, dtype=torch.bfloat16)
+  lse = torch.zeros(R, H, device=dev)
+  dctx = (torch.randn(R, d, device=dev) * 0.1).to(torch.bfloat16)
+  dqkv = torch.zeros_like(qkv)
+  delta = torch.zeros(R, H, device=dev)
+  thr, sc = ops.dropout_params(drop_p)
+  L = _lib.lib()
+  scale = 128 ** -0.5
+
+  def fwd():
+    _lib.check(L.mmt_attn_fwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), B, S, H, d, scale, 7, thr, sc, None, _stream()), 'f')
+
+  def bwd():
+    _lib.check(L.mmt_attn_bwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), B, S, H, d, scale,
+                              7, thr, sc, None, _stream()), 'b')
+
+  torch.cuda.synchronize()  # inputs were produced on the default stream; timeit launches on a side stream
+  tf, tb = timeit([fwd, bwd])
+  fl = 4.0 * B * H * S * S * 128
+  print('B %4d S %4d p %.1f | fwd %6.1f us (%5.1f TF)  bwd(dq+dkv) %6.1f us (%5.1f TF)' %
+        (B, S, drop_p, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6))
+
+
+for S in (32, 64, 128, 218):
+  for B in (32, 128, 512):
+    case(B, S, 0.1)
+case(32, 218, 0.0)
+case(128, 128, 0.0)
