@@ -224,10 +224,12 @@ typedef struct MmtPackItem {
 } MmtPackItem;
 /* bf16 shadows of the fp32 master weights (and W^T copies for the input-gradient GEMMs). */
 int mmt_pack_weights(const MmtPackItem* items, int n, void* stream);
-/* torch.optim.Adam step (train.py:100) over one flat fp32 buffer; step_dev = 1-based step on device. */
+/* torch.optim.Adam step (train.py:100) over one flat fp32 buffer; step_dev = 1-based step on device.
+ * lr_dev (nullable): device float that overrides `lr` -- the learning-rate schedule (StepLR + warm-up,
+ * trainer/trainer.py:150-160, train.py:101-103) then works under HIP-graph replay without re-capturing. */
 int mmt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
-                  const int32_t* step_dev, void* stream);
+                  const int32_t* step_dev, const float* lr_dev, void* stream);
 
 /* ---- video tokens (assemble.hip) -------------------------------------------------------------------
  * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip. */

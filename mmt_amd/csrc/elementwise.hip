@@ -102,7 +102,9 @@ extern "C" int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int co
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    float lr, float beta1, float beta2, float eps, float weight_decay,
-                                                   const int32_t* __restrict__ step_dev) {
+                                                   const int32_t* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;  // learning-rate schedules under graph replay: the rate lives on the device
   const float t = (float)*step_dev;
   const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -122,11 +124,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
                              float lr, float beta1, float beta2, float eps, float weight_decay,
-                             const int32_t* step_dev, void* stream) {
+                             const int32_t* step_dev, const float* lr_dev, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || count <= 0 || (count & 3)) return MMT_ERR_ARG;
   const int64_t n4 = count / 4;
   const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                     exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step_dev);
+                     exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step_dev, lr_dev);
   return (int)hipGetLastError();
 }

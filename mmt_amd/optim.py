@@ -11,10 +11,33 @@ from ._lib import check
 
 
 class FlatAdam:
+  """`param_groups` / `state_dict` are shaped like a torch optimizer's, so `torch.optim.lr_scheduler.LambdaLR/StepLR`-style
+  code that only touches `optimizer.param_groups[i]['lr']` (the reference's StepLR + LinearWarmup,
+  train.py:101-103, trainer/trainer.py:150-160) drives it.  The rate is mirrored into a device scalar that the kernel
+  reads, so a captured optimizer graph follows the schedule: call `sync_lr()` (cheap, no-op when unchanged) before
+  replaying -- `GraphedTrainStep.step` does."""
 
   def __init__(self, flat, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-    self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+    self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
     self.exp_avg = self.exp_avg_sq = self.step_dev = None
+    self.param_groups = [dict(params=list(flat.params), lr=lr, initial_lr=lr, betas=betas, eps=eps,
+                              weight_decay=weight_decay)]
+    self.lr_dev, self._lr_on_dev = None, None
+
+  @property
+  def lr(self):
+    return self.param_groups[0]['lr']
+
+  @lr.setter
+  def lr(self, value):
+    self.param_groups[0]['lr'] = value
+
+  def sync_lr(self):
+    """Push param_groups[0]['lr'] to the device scalar if it changed (stream-ordered fill, outside any graph)."""
+    lr = float(self.lr)
+    if self.lr_dev is not None and lr != self._lr_on_dev and not torch.cuda.is_current_stream_capturing():
+      self.lr_dev.fill_(lr)
+      self._lr_on_dev = lr
 
   def _grad(self):
     f = self.flat
@@ -42,11 +65,15 @@ class FlatAdam:
       self.exp_avg = torch.zeros_like(f.master)
       self.exp_avg_sq = torch.zeros_like(f.master)
       self.step_dev = torch.zeros(1, dtype=torch.int32, device=f.master.device)
+    if self.lr_dev is None or self.lr_dev.device != f.master.device:
+      self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=f.master.device)
+      self._lr_on_dev = float(self.lr)
+    self.sync_lr()
     g = self._grad()
     self.step_dev.add_(1)
     check(_lib.lib().mmt_adam_step(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
-                                   f.count, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                   ops._p(self.step_dev), ops._stream()), 'mmt_adam_step')
+                                   f.count, float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                   ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()), 'mmt_adam_step')
     f._dirty = True  # the bf16 shadows are stale now (the kernel wrote through raw pointers)
 
 

@@ -327,6 +327,7 @@ class GraphedTrainStep:
     if not self.use_graphs:
       self._eager_step()
       return self.loss
+    self.opt_flat.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     ga, gb, gc = self._graphs
     ga.replay()
     if self.world > 1:
