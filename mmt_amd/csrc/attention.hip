@@ -24,47 +24,56 @@
 #define LN2 0.6931471805599453f
 #define NEG_BIG (-1.0e30f)
 
-__device__ __forceinline__ int swz16(int r) { return ((r & 7) << 1) | ((r >> 3) & 1); }
+// XOR swizzle of the 16-B chunks of a tile row.  Head dim 128 (256-B rows, 16 chunks): ((row&7)<<1)|((row>>3)&1);
+// head dim 64 (128-B rows, 8 chunks; two rows share one 256-B bank line): (row>>1)&7.
+template <int DH> __device__ __forceinline__ int swz(int r) {
+  return DH == 128 ? (((r & 7) << 1) | ((r >> 3) & 1)) : ((r >> 1) & 7);
+}
 
-__device__ __forceinline__ void stage64x128(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_last,
-                                            bf16_t* lds_tile, int wave, int lane) {
+// 64 x DH bf16 tile by LDS-DMA: one wave-instruction moves 1 KiB = 64 / (DH/8) rows
+template <int DH>
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_last,
+                                        bf16_t* lds_tile, int wave, int lane) {
+  constexpr int CH = DH / 8, RPI = 64 / CH, NI = 16 / RPI;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rbase = (wave * 4 + i) * 4;
-    const int rr = rbase + (lane >> 4);
-    const int c = (lane & 15) ^ swz16(rr);
+  for (int i = 0; i < NI; ++i) {
+    const int rbase = (wave * NI + i) * RPI;
+    const int rr = rbase + lane / CH;
+    const int c = (lane % CH) ^ swz<DH>(rr);
     const int gr = min(row0 + rr, row_last);
     const bf16_t* src = G + (int64_t)gr * ld + c * 8;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * DH), 16, 0, 0);
   }
 }
 
 // same tile, rows gathered through an index list: row i of the tile = G[sel[min(i0 + i, n - 1)]]
-__device__ __forceinline__ void stage64x128_sel(const bf16_t* __restrict__ G, int64_t ld, const int32_t* __restrict__ sel,
-                                                int i0, int n, bf16_t* lds_tile, int wave, int lane) {
+template <int DH>
+__device__ __forceinline__ void stage64_sel(const bf16_t* __restrict__ G, int64_t ld, const int32_t* __restrict__ sel,
+                                            int i0, int n, bf16_t* lds_tile, int wave, int lane) {
+  constexpr int CH = DH / 8, RPI = 64 / CH, NI = 16 / RPI;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rbase = (wave * 4 + i) * 4;
-    const int rr = rbase + (lane >> 4);
-    const int c = (lane & 15) ^ swz16(rr);
+  for (int i = 0; i < NI; ++i) {
+    const int rbase = (wave * NI + i) * RPI;
+    const int rr = rbase + lane / CH;
+    const int c = (lane % CH) ^ swz<DH>(rr);
     const int gr = sel[min(i0 + rr, n - 1)];
     const bf16_t* src = G + (int64_t)gr * ld + c * 8;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * DH), 16, 0, 0);
   }
 }
 
-__device__ __forceinline__ bf16x8_t frag_b128(const bf16_t* tile, int r, int chunk) {
-  return *(const bf16x8_t*)(tile + r * 128 + ((chunk ^ swz16(r)) << 3));
+template <int DH> __device__ __forceinline__ bf16x8_t frag_b128(const bf16_t* tile, int r, int chunk) {
+  return *(const bf16x8_t*)(tile + r * DH + ((chunk ^ swz<DH>(r)) << 3));
 }
 
 // 8 contraction values (rows kappa(g,.) of k-chunk ks) for column colbase + (lane&15)
-__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tile, int ks, int colbase, int lane) {
+template <int DH> __device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tile, int ks, int colbase, int lane) {
   const int t = lane & 15, g = lane >> 4;
   const int col = colbase + 4 * (t & 3);
   const int r0 = ks * 32 + 4 * g + (t >> 2), r1 = r0 + 16;
   const int ch = col >> 3, w = col & 7;
-  const bf16_t* p0 = tile + r0 * 128 + ((ch ^ swz16(r0)) << 3) + w;
-  const bf16_t* p1 = tile + r1 * 128 + ((ch ^ swz16(r1)) << 3) + w;
+  const bf16_t* p0 = tile + r0 * DH + ((ch ^ swz<DH>(r0)) << 3) + w;
+  const bf16_t* p1 = tile + r1 * DH + ((ch ^ swz<DH>(r1)) << 3) + w;
   bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p0));
   bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p1));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -104,9 +113,10 @@ struct AttnArgs {
 // ------------------------------------------------------------------------------------------------
 // forward: grid (q tiles of 64, H, B), 4 waves x 16 queries
 // ------------------------------------------------------------------------------------------------
+template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 64 * 2];
-  float* bias_s = (float*)(smem + 2 * 2 * 64 * 128);  // [2][64]
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2];
+  float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][64]
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
@@ -116,30 +126,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
   const int nkt = (Sb + 63) >> 6;
-  const bf16_t* Kg = a.qkv + a.d + h * 128;
-  const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
+  const bf16_t* Kg = a.qkv + a.d + h * DH;
+  const bf16_t* Vg = a.qkv + 2 * a.d + h * DH;
 
   const int qi = q0 + wave * 16 + li;
   const int qic = min(qi, nqs - 1);
   const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
   const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / lse
   const int q_local = a.qsel ? qrow - off : qi;
-  bf16x8_t qf[4];
+  bf16x8_t qf[DH / 32];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
+  for (int kk = 0; kk < DH / 32; ++kk)
+    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * DH + kk * 32 + lg * 8);
   const unsigned rowkey = attn_rowkey(eff_key(a.drop_key, a.seed_dev), (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
   const float c1 = a.scale * LOG2E;
 
-  f32x4 o[8];
+  f32x4 o[DH / 16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DH / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG, l_run = 0.f;
 
   auto stage = [&](int kt, int st) {
-    bf16_t* base = smem + st * (2 * 64 * 128);
-    stage64x128(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
-    stage64x128(Vg, a.ld, off + kt * 64, row_last, base + 64 * 128, wave, lane);
+    bf16_t* base = smem + st * (2 * 64 * DH);
+    stage64<DH>(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
+    stage64<DH>(Vg, a.ld, off + kt * 64, row_last, base + 64 * DH, wave, lane);
     if (tid < 64) {
       const int k = kt * 64 + tid;
       bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
@@ -151,15 +161,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-    const bf16_t* Ks = smem + cur * (2 * 64 * 128);
-    const bf16_t* Vs = Ks + 64 * 128;
+    const bf16_t* Ks = smem + cur * (2 * 64 * DH);
+    const bf16_t* Vs = Ks + 64 * DH;
     f32x4 s[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
+      for (int kk = 0; kk < DH / 32; ++kk)
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128<DH>(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
     }
     float mt = NEG_BIG;
 #pragma unroll
@@ -191,19 +201,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] *= alpha;
+    for (int i = 0; i < DH / 16; ++i) o[i] *= alpha;
     const bf16x8_t pb0 = pack8(s[0], s[1]), pb1 = pack8(s[2], s[3]);
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
-      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 0, fd * 16, lane), pb0, o[fd], 0, 0, 0);
-      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 1, fd * 16, lane), pb1, o[fd], 0, 0, 0);
+    for (int fd = 0; fd < DH / 16; ++fd) {
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Vs, 0, fd * 16, lane), pb0, o[fd], 0, 0, 0);
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Vs, 1, fd * 16, lane), pb1, o[fd], 0, 0, 0);
     }
   }
   if (qi < nqs) {
     const float inv = 1.0f / l_run;
-    bf16_t* dst = a.ctx + (int64_t)crow * a.ldc + h * 128 + 4 * lg;
+    bf16_t* dst = a.ctx + (int64_t)crow * a.ldc + h * DH + 4 * lg;
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
+    for (int fd = 0; fd < DH / 16; ++fd) {
       u32x2 v = {pack_bf2(o[fd][0] * inv, o[fd][1] * inv), pack_bf2(o[fd][2] * inv, o[fd][3] * inv)};
       *(u32x2*)(dst + fd * 16) = v;
     }
@@ -215,9 +225,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // backward, part 1: dQ (+ delta).  Same tiling as forward: grid (q tiles, H, B).
 //   dA^T[key][q] = V . dO^T ; dS = P o (keep*dA*sc - delta) ; dQ^T[d][q] += K^T . dS^T
 // ------------------------------------------------------------------------------------------------
+template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 64 * 2];
-  float* bias_s = (float*)(smem + 2 * 2 * 64 * 128);
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2];
+  float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
@@ -227,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
   const int nkt = (Sb + 63) >> 6;
-  const bf16_t* Kg = a.qkv + a.d + h * 128;
-  const bf16_t* Vg = a.qkv + 2 * a.d + h * 128;
+  const bf16_t* Kg = a.qkv + a.d + h * DH;
+  const bf16_t* Vg = a.qkv + 2 * a.d + h * DH;
   const int qi = q0 + wave * 16 + li;
   const bool q_ok = qi < nqs;
   const int qic = min(qi, nqs - 1);
@@ -238,18 +249,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   if (a.qsel && blockIdx.x == 0) {
     // query-subset mode: dQ of the non-selected rows is zero -- this block (sample b, head h) clears its 128 columns
     // of every row of the sample; the selected rows are overwritten at the end (after the K-loop's barriers)
-    for (int e = tid; e < Sb * 16; e += 256) {
+    for (int e = tid; e < Sb * (DH / 8); e += 256) {
       u32x4 z = {0, 0, 0, 0};
-      *(u32x4*)(a.dqkv + (int64_t)(off + (e >> 4)) * a.ld + h * 128 + (e & 15) * 8) = z;
+      *(u32x4*)(a.dqkv + (int64_t)(off + e / (DH / 8)) * a.ld + h * DH + (e % (DH / 8)) * 8) = z;
     }
   }
-  bf16x8_t qf[4], dof[4];
+  bf16x8_t qf[DH / 32], dof[DH / 32];
   float dl = 0.f;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * 128 + kk * 32 + lg * 8);
-    const u16x8 dv = *(const u16x8*)(a.dctx + (int64_t)crow * a.ldc + h * 128 + kk * 32 + lg * 8);
-    const u16x8 ov = *(const u16x8*)(a.ctx + (int64_t)crow * a.ldc + h * 128 + kk * 32 + lg * 8);
+  for (int kk = 0; kk < DH / 32; ++kk) {
+    qf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)qrow * a.ld + h * DH + kk * 32 + lg * 8);
+    const u16x8 dv = *(const u16x8*)(a.dctx + (int64_t)crow * a.ldc + h * DH + kk * 32 + lg * 8);
+    const u16x8 ov = *(const u16x8*)(a.ctx + (int64_t)crow * a.ldc + h * DH + kk * 32 + lg * 8);
     dof[kk] = __builtin_bit_cast(bf16x8_t, dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dl += bf2f(dv[e]) * bf2f(ov[e]);
@@ -261,14 +272,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const unsigned rowkey = attn_rowkey(eff_key(a.drop_key, a.seed_dev), (unsigned)(b * a.H + h), (unsigned)a.S4, (unsigned)q_local);
   const float c1 = a.scale * LOG2E;
 
-  f32x4 o[8];
+  f32x4 o[DH / 16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DH / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int kt, int st) {
-    bf16_t* base = smem + st * (2 * 64 * 128);
-    stage64x128(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
-    stage64x128(Vg, a.ld, off + kt * 64, row_last, base + 64 * 128, wave, lane);
+    bf16_t* base = smem + st * (2 * 64 * DH);
+    stage64<DH>(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
+    stage64<DH>(Vg, a.ld, off + kt * 64, row_last, base + 64 * DH, wave, lane);
     if (tid < 64) {
       const int k = kt * 64 + tid;
       bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
@@ -280,17 +291,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-    const bf16_t* Ks = smem + cur * (2 * 64 * 128);
-    const bf16_t* Vs = Ks + 64 * 128;
+    const bf16_t* Ks = smem + cur * (2 * 64 * DH);
+    const bf16_t* Vs = Ks + 64 * DH;
     f32x4 s[4], da[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
       da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
-        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Vs, f * 16 + li, kk * 4 + lg), dof[kk], da[f], 0, 0, 0);
+      for (int kk = 0; kk < DH / 32; ++kk) {
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128<DH>(Ks, f * 16 + li, kk * 4 + lg), qf[kk], s[f], 0, 0, 0);
+        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128<DH>(Vs, f * 16 + li, kk * 4 + lg), dof[kk], da[f], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -309,15 +320,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     const bf16x8_t sb0 = pack8(s[0], s[1]), sb1 = pack8(s[2], s[3]);
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
-      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 0, fd * 16, lane), sb0, o[fd], 0, 0, 0);
-      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 1, fd * 16, lane), sb1, o[fd], 0, 0, 0);
+    for (int fd = 0; fd < DH / 16; ++fd) {
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Ks, 0, fd * 16, lane), sb0, o[fd], 0, 0, 0);
+      o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Ks, 1, fd * 16, lane), sb1, o[fd], 0, 0, 0);
     }
   }
   if (q_ok) {
-    bf16_t* dst = a.dqkv + (int64_t)qrow * a.ld + h * 128 + 4 * lg;
+    bf16_t* dst = a.dqkv + (int64_t)qrow * a.ld + h * DH + 4 * lg;
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
+    for (int fd = 0; fd < DH / 16; ++fd) {
       u32x2 v = {pack_bf2(o[fd][0] * a.scale, o[fd][1] * a.scale), pack_bf2(o[fd][2] * a.scale, o[fd][3] * a.scale)};
       *(u32x2*)(dst + fd * 16) = v;
     }
@@ -329,9 +340,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 //   S[q][key] = Q . K^T (a = Q frag from LDS, b = K frag in registers) ; dA = dO . V^T
 //   dV^T[d][key] += dO^T . A ; dK^T[d][key] += Q^T . dS     (a = transpose reads of the dO / Q tiles)
 // ------------------------------------------------------------------------------------------------
+template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * 128 + 2 * 3 * 64 * 2];
-  float* aux_s = (float*)(smem + 2 * 2 * 64 * 128);  // [2][3][64]: lse2, delta, rowkey(bits)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 3 * 64 * 2];
+  float* aux_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][3][64]: lse2, delta, rowkey(bits)
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
@@ -341,34 +353,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int row_last = off + Sb - 1;
   const int nqs = a.qsel ? a.nq : Sb;
   const int nqt = (nqs + 63) >> 6;
-  const bf16_t* Qg = a.qkv + h * 128;
-  const bf16_t* dOg = a.dctx + h * 128;
+  const bf16_t* Qg = a.qkv + h * DH;
+  const bf16_t* dOg = a.dctx + h * DH;
   const int key_local = k0 + wave * 16 + li;
   const bool key_ok = key_local < Sb;
   const int krow = off + min(key_local, Sb - 1);
-  bf16x8_t kf[4], vf[4];
+  bf16x8_t kf[DH / 32], vf[DH / 32];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    kf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + a.d + h * 128 + kk * 32 + lg * 8);
-    vf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + 2 * a.d + h * 128 + kk * 32 + lg * 8);
+  for (int kk = 0; kk < DH / 32; ++kk) {
+    kf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + a.d + h * DH + kk * 32 + lg * 8);
+    vf[kk] = *(const bf16x8_t*)(a.qkv + (int64_t)krow * a.ld + 2 * a.d + h * DH + kk * 32 + lg * 8);
   }
   const float bias2 = key_ok ? a.mask_bias[krow] * LOG2E : -INFINITY;
   const float c1 = a.scale * LOG2E;
   const unsigned bh = (unsigned)(b * a.H + h);
   const unsigned dkey = eff_key(a.drop_key, a.seed_dev);
 
-  f32x4 dk[8], dv[8];
+  f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < DH / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   auto stage = [&](int qt, int st) {
-    bf16_t* base = smem + st * (2 * 64 * 128);
+    bf16_t* base = smem + st * (2 * 64 * DH);
     if (a.qsel) {
-      stage64x128_sel(Qg, a.ld, a.qsel + b * a.nq, qt * 64, a.nq, base, wave, lane);
-      stage64x128(dOg, a.ldc, b * a.nq + qt * 64, b * a.nq + a.nq - 1, base + 64 * 128, wave, lane);
+      stage64_sel<DH>(Qg, a.ld, a.qsel + b * a.nq, qt * 64, a.nq, base, wave, lane);
+      stage64<DH>(dOg, a.ldc, b * a.nq + qt * 64, b * a.nq + a.nq - 1, base + 64 * DH, wave, lane);
     } else {
-      stage64x128(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
-      stage64x128(dOg, a.ldc, off + qt * 64, row_last, base + 64 * 128, wave, lane);
+      stage64<DH>(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
+      stage64<DH>(dOg, a.ldc, off + qt * 64, row_last, base + 64 * DH, wave, lane);
     }
     if (tid < 64) {
       const int q = qt * 64 + tid;
@@ -387,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) stage(qt + 1, cur ^ 1);
-    const bf16_t* Qs = smem + cur * (2 * 64 * 128);
-    const bf16_t* dOs = Qs + 64 * 128;
+    const bf16_t* Qs = smem + cur * (2 * 64 * DH);
+    const bf16_t* dOs = Qs + 64 * DH;
     const float* ax = aux_s + cur * 192;
     f32x4 s[4], da[4];
 #pragma unroll
@@ -396,9 +408,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
       da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(Qs, f * 16 + li, kk * 4 + lg), kf[kk], s[f], 0, 0, 0);
-        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128(dOs, f * 16 + li, kk * 4 + lg), vf[kk], da[f], 0, 0, 0);
+      for (int kk = 0; kk < DH / 32; ++kk) {
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128<DH>(Qs, f * 16 + li, kk * 4 + lg), kf[kk], s[f], 0, 0, 0);
+        da[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_b128<DH>(dOs, f * 16 + li, kk * 4 + lg), vf[kk], da[f], 0, 0, 0);
       }
     }
     // lane (key = li, g) holds S[q = 16f + 4g + r][key]
@@ -421,18 +433,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bf16x8_t ab0 = pack8(pa[0], pa[1]), ab1 = pack8(pa[2], pa[3]);
     const bf16x8_t sb0 = pack8(s[0], s[1]), sb1 = pack8(s[2], s[3]);
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
-      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(dOs, 0, fd * 16, lane), ab0, dv[fd], 0, 0, 0);
-      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(dOs, 1, fd * 16, lane), ab1, dv[fd], 0, 0, 0);
-      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 0, fd * 16, lane), sb0, dk[fd], 0, 0, 0);
-      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 1, fd * 16, lane), sb1, dk[fd], 0, 0, 0);
+    for (int fd = 0; fd < DH / 16; ++fd) {
+      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(dOs, 0, fd * 16, lane), ab0, dv[fd], 0, 0, 0);
+      dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(dOs, 1, fd * 16, lane), ab1, dv[fd], 0, 0, 0);
+      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Qs, 0, fd * 16, lane), sb0, dk[fd], 0, 0, 0);
+      dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Qs, 1, fd * 16, lane), sb1, dk[fd], 0, 0, 0);
     }
   }
   if (key_ok) {
-    bf16_t* dstk = a.dqkv + (int64_t)krow * a.ld + a.d + h * 128 + 4 * lg;
-    bf16_t* dstv = a.dqkv + (int64_t)krow * a.ld + 2 * a.d + h * 128 + 4 * lg;
+    bf16_t* dstk = a.dqkv + (int64_t)krow * a.ld + a.d + h * DH + 4 * lg;
+    bf16_t* dstv = a.dqkv + (int64_t)krow * a.ld + 2 * a.d + h * DH + 4 * lg;
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
+    for (int fd = 0; fd < DH / 16; ++fd) {
       u32x2 vk = {pack_bf2(dk[fd][0] * a.scale, dk[fd][1] * a.scale), pack_bf2(dk[fd][2] * a.scale, dk[fd][3] * a.scale)};
       u32x2 vv = {pack_bf2(dv[fd][0], dv[fd][1]), pack_bf2(dv[fd][2], dv[fd][3])};
       *(u32x2*)(dstk + fd * 16) = vk;
@@ -456,7 +468,7 @@ __global__ void attn_mask_export_kernel(uint8_t* out, int B, int H, int S, int S
 // ------------------------------------------------------------------------------------------------
 static int check_args(const void* qkv, int B, int S, int H, int d) {
   if (!qkv || B <= 0 || S <= 0 || H <= 0) return MMT_ERR_ARG;
-  if (d != H * 128) return MMT_ERR_ARG;  // head dim 128 only (every published MMT config)
+  if (d != H * 128 && d != H * 64) return MMT_ERR_ARG;  // head dim 128 (every published video-BERT config) or 64 (BERT-base)
   return 0;
 }
 
@@ -469,7 +481,8 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -485,8 +498,13 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   const dim3 grid((S + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (d == H * 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 
@@ -504,7 +522,8 @@ extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.qsel = qsel; a.nq = nq;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -520,8 +539,13 @@ extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.qsel = qsel; a.nq = nq;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  if (d == H * 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 

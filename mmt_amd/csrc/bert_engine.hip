@@ -83,7 +83,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
 int check_model(const MmtBertModel* m, const MmtBertBatch* b) {
   if (!m || !b || !m->layer) return MMT_ERR_ARG;
   if (m->layers <= 0 || m->layers > 64) return MMT_ERR_ARG;
-  if (m->hidden != m->heads * 128) return MMT_ERR_ARG;      // head dim 128
+  if (m->hidden != m->heads * 128 && m->hidden != m->heads * 64) return MMT_ERR_ARG;  // head dim 128 (video BERT) or 64 (BERT-base)
   if (m->hidden % 256 || m->hidden > 1024 || m->inter % 128) return MMT_ERR_ARG;
   if (b->rows <= 0 || b->rows > b->rows_alloc || b->rows_alloc % MMT_ROW_ALIGN) return MMT_ERR_ARG;
   if (!b->features || !b->type_ids || !b->mask_bias) return MMT_ERR_ARG;
@@ -134,7 +134,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
   const int d = m->hidden, I = m->inter, rows = b->rows;
   const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
   const float sh = scale_of(th), sa = scale_of(ta);
-  const float qk_scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float qk_scale = m->hidden == m->heads * 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(head dim)
 
   TRY(mmt_embed_ln_fwd(b->features, b->type_ids, b->pos_ids, m->type_emb, m->pos_emb, w.z0, m->emb_ln_g,
                        m->emb_ln_b, m->ln_eps, w.h32_in, w.h16_in, w.mean0, w.rstd0, rows, d, b->n_rows_dev,
@@ -210,7 +210,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   const int d = m->hidden, I = m->inter, rows = b->rows;
   const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
   const float sh = scale_of(th), sa = scale_of(ta);
-  const float qk_scale = 0.08838834764831845f;
+  const float qk_scale = m->hidden == m->heads * 128 ? 0.08838834764831845f : 0.125f;
   const int rpb = mmt_ln_bwd_rows_per_block(rows);
   const int ln_blocks = (rows + rpb - 1) / rpb;
   const int32_t* nr = b->n_rows_dev;

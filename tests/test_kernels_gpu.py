@@ -325,10 +325,12 @@ def _attn_ref(qkv, bias, B, S, H, scale, cu=None, mask=None, sc=1.0):
   return out
 
 
-@pytest.mark.parametrize('B,S,H', [(2, 16, 2), (3, 37, 2), (2, 70, 4), (2, 218, 4), (1, 300, 2)])
-def test_attention_fwd_bwd_dense(B, S, H):
+@pytest.mark.parametrize('B,S,H,DH', [(2, 16, 2, 128), (3, 37, 2, 128), (2, 70, 4, 128), (2, 218, 4, 128), (1, 300, 2, 128),
+                                      (3, 30, 12, 64), (2, 37, 4, 64), (2, 150, 8, 64)])
+def test_attention_fwd_bwd_dense(B, S, H, DH):
+  """DH = 128: every published video-BERT config; DH = 64: BERT-base (the text tower, 12 heads x 64)."""
   from mmt_amd import ops
-  d = H * 128
+  d = H * DH
   rows = B * S
   R = ops.pad_rows(rows)
   qkv = _rand((R, 3 * d), 1.0, seed=25, dtype=torch.bfloat16)
@@ -336,7 +338,7 @@ def test_attention_fwd_bwd_dense(B, S, H):
   valid = (torch.rand(R, generator=g) > 0.3)
   valid[::S] = True
   bias = ((~valid).float() * -10000.0).to(_dev())
-  scale = 1.0 / math.sqrt(128.0)
+  scale = 1.0 / math.sqrt(float(DH))
   ctx, lse = ops.attn_fwd(qkv, bias, B, S, H, scale)
   x = qkv[:rows].float().requires_grad_(True)
   ref = _attn_ref(x, bias, B, S, H, scale)
@@ -348,11 +350,12 @@ def test_attention_fwd_bwd_dense(B, S, H):
     _close('attn.d' + nm, dqkv[:rows, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d], 4e-2, 4e-2)
 
 
-def test_attention_dropout_replay_and_varlen():
+@pytest.mark.parametrize('DH', [128, 64])
+def test_attention_dropout_replay_and_varlen(DH):
   from mmt_amd import ops
   B, S, H = 3, 50, 2
-  d = H * 128
-  scale = 1.0 / math.sqrt(128.0)
+  d = H * DH
+  scale = 1.0 / math.sqrt(float(DH))
   rows = B * S
   R = ops.pad_rows(rows)
   qkv = _rand((R, 3 * d), 1.0, seed=28, dtype=torch.bfloat16)
