@@ -155,6 +155,12 @@ int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, fl
 int mmt_rows_gather(const float* src, const int32_t* rows, int n, int d, float* dst, const int32_t* idx_in,
                     int32_t* idx_out, void* stream);
 int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, int accumulate, void* stream);
+/* Word-embedding gradient of the text tower (HF BertEmbeddings.word_embeddings, reached from model/model.py:371-376):
+ * dtable[id] = sum of g[i] over token rows i with ids[i] == id, in row order (deterministic); rows with
+ * id == padding_idx or outside [0, vocab) contribute nothing.  dtable [vocab, d] must be zero on entry.  The forward
+ * lookup is mmt_rows_gather(table, ids, ...). */
+int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int vocab, int padding_idx, float* dtable,
+                       void* stream);
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
  * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */

@@ -200,6 +200,10 @@ class BertModel(nn.Module):
   def trainable_engine_params(self):
     return [p for _, p in self.engine_named_params()]
 
+  def flat_named_params(self):
+    """Everything stored in this module's own flat buffer (subclasses add parameters the engine does not touch)."""
+    return self.engine_named_params()
+
   def register_shadows(self, flat):
     d, i = self.config.hidden_size, self.config.intermediate_size
     for l, L in enumerate(self.encoder.layer):
@@ -217,7 +221,7 @@ class BertModel(nn.Module):
 
   def _ensure_ready(self, device):
     if self._flat is None:
-      self._flat = FlatParams(self.engine_named_params())
+      self._flat = FlatParams(self.flat_named_params())
       self.register_shadows(self._flat)
     if self._owns_flat:
       if self._flat.ensure(device):

@@ -335,6 +335,35 @@ extern "C" int mmt_rows_scatter(const float* src, const int32_t* rows, int n, in
   return (int)hipGetLastError();
 }
 
+// Word-embedding gradient (the text tower's nn.Embedding backward, deterministic): dtable[id] = sum over the token rows
+// i with ids[i] == id of g[i], in row order.  One block per token row; the block of an id's FIRST occurrence does the
+// whole sum for that id (rows <= a few thousand: the id scan is cheap), every other block exits.  `padding_idx` rows get
+// no gradient (nn.Embedding(padding_idx=...)).  dtable must be zero on entry (untouched ids keep a zero gradient).
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ ids,
+                                                             int n, int d, int vocab, int padding_idx,
+                                                             float* __restrict__ dtable) {
+  const int i = blockIdx.x;
+  const int id = ids[i];
+  if (id < 0 || id >= vocab || id == padding_idx) return;
+  int seen = 0;
+  for (int j = threadIdx.x; j < i; j += 256) seen |= (ids[j] == id);
+  if (__syncthreads_or(seen)) return;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    f32x4 acc = *(const f32x4*)(g + (int64_t)i * d + c);
+    for (int j = i + 1; j < n; ++j)
+      if (ids[j] == id) acc += *(const f32x4*)(g + (int64_t)j * d + c);
+    *(f32x4*)(dtable + (int64_t)id * d + c) = acc;
+  }
+}
+
+extern "C" int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int vocab, int padding_idx,
+                                  float* dtable, void* stream) {
+  if (!g || !ids || !dtable || n <= 0 || d <= 0 || (d & 3) || vocab <= 0) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(embedding_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, g, ids, n, d, vocab, padding_idx,
+                     dtable);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
                                 const float* type_emb, const float* pos_emb, float* z_save,
                                 const float* gamma, const float* beta, float eps, float* h32, void* h16,

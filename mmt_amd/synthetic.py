@@ -126,3 +126,19 @@ def checksum(t):
   a = t.detach().double().reshape(-1).numpy()
   w = np.cos(np.arange(a.size, dtype=np.float64) * 0.37) + 1.5
   return float((a * w).sum())
+
+
+def text_token_batch(seed, b, w, vocab):
+  """(input_ids, attention_mask) int64 (b, w) like the reference's token_ids[..., 0] / [..., 1]
+  (base/base_dataset.py:874-896): [CLS]-led captions of 5..w tokens, zero-padded tails, with tokens repeated inside a
+  caption and across captions (the word-embedding gradient has to accumulate them)."""
+  rs = np.random.RandomState(seed)
+  ids = rs.randint(1, vocab, size=(b, w)).astype(np.int64)
+  ids[:, 0] = 101 % vocab
+  ids[:, 3] = ids[:, 1]
+  ids[1:, 2] = ids[0, 2]
+  lens = rs.randint(5, w + 1, size=b)
+  lens[0] = w
+  mask = (np.arange(w)[None, :] < lens[:, None]).astype(np.int64)
+  ids = ids * mask
+  return torch.from_numpy(ids), torch.from_numpy(mask)

@@ -247,6 +247,55 @@ def run_bert_fixture(R):
   print('bert     oracle==reference')
 
 
+TEXT_BERT = dict(vocab_size=1000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                 max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.0,
+                 attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12, pad_token_id=0)
+
+
+def run_text_bert_fixture():
+  """The text tower's oracle restatement pinned against the installed transformers BertModel (the reference pins
+  transformers==3.1.0; the BERT arithmetic is the same), forward and backward, head dim 64."""
+  import transformers
+  cfg = transformers.BertConfig(**TEXT_BERT)
+  torch.manual_seed(0)
+  hf = transformers.BertModel(cfg, add_pooling_layer=True)
+  shapes = {k: tuple(v.shape) for k, v in hf.state_dict().items() if v.dtype.is_floating_point}
+  sd = synthetic.make_state_dict(41, {('txt_bert.' + k): v for k, v in shapes.items()})
+  sd['txt_bert.embeddings.word_embeddings.weight'][0].zero_()
+  hf.load_state_dict({k[len('txt_bert.'):]: v for k, v in sd.items()}, strict=False)
+  b, w = 6, 30
+  ids, mask = synthetic.text_token_batch(41, b, w, TEXT_BERT['vocab_size'])
+  pos = torch.arange(w).unsqueeze(0).expand(b, w)
+  probe = torch.from_numpy(np.random.RandomState(42).randn(b, TEXT_BERT['hidden_size']).astype(np.float32))
+  hf.train()  # dropout probabilities are 0: train mode only exercises the autograd path
+  seq = hf(ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids), position_ids=pos)[0]
+  loss = (seq[:, 0] * probe).sum()
+  loss.backward()
+  grads = {('txt_bert.' + n): p.grad for n, p in hf.named_parameters() if p.grad is not None}
+  vb = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, layer_norm_eps=1e-12,
+            hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+  P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+  o_seq = O.text_bert_model(P, 'txt_bert.', vb, ids, mask, None, pos)
+  assert (o_seq - seq).abs().max() < 2e-5, (o_seq - seq).abs().max()
+  (o_seq[:, 0] * probe).sum().backward()
+  for k in ('txt_bert.embeddings.word_embeddings.weight', 'txt_bert.encoder.layer.0.attention.self.query.weight',
+            'txt_bert.encoder.layer.1.output.dense.weight', 'txt_bert.embeddings.LayerNorm.weight'):
+    ref = grads[k]
+    assert (P[k].grad - ref).norm() <= 2e-4 * ref.norm(), k
+  out = collections.OrderedDict()
+  out['meta'] = json.dumps(dict(cfg=TEXT_BERT, seed=41, shape=[b, w], transformers=transformers.__version__,
+                                param_checksums={k: synthetic.checksum(v) for k, v in sd.items()}))
+  out['sequence_output'] = seq.detach().numpy()
+  out['loss'] = np.float64(loss.item())
+  for k in ('embeddings.word_embeddings.weight', 'embeddings.position_embeddings.weight',
+            'embeddings.LayerNorm.bias', 'encoder.layer.0.attention.self.query.weight',
+            'encoder.layer.0.attention.self.value.bias', 'encoder.layer.1.intermediate.dense.weight',
+            'encoder.layer.1.output.dense.weight', 'encoder.layer.1.output.LayerNorm.weight'):
+    out['grad.' + k] = grads['txt_bert.' + k].numpy()
+  np.savez_compressed(os.path.join(GOLDEN, 'text_bert.npz'), **out)
+  print('text_bert oracle==transformers %s' % transformers.__version__)
+
+
 def run_sim_loss_metric_fixtures(R):
   rs = np.random.RandomState(31)
   out = collections.OrderedDict()
@@ -320,6 +369,8 @@ def main():
   R = load_reference()
   torch.set_num_threads(os.cpu_count())
   only = [a for a in sys.argv[1:] if not a.startswith('-')]
+  if not only or 'text_bert' in only:
+    run_text_bert_fixture()
   if not only:
     run_sim_loss_metric_fixtures(R)
     run_bert_fixture(R)

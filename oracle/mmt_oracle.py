@@ -129,6 +129,22 @@ def bert_model(P, pre, cfg, attention_mask, token_type_ids, position_ids, featur
   return h, pooled  # :306-308
 
 
+def text_bert_model(P, pre, cfg, input_ids, attention_mask, token_type_ids=None, position_ids=None):
+  """The text tower: HuggingFace `BertModel` as the reference instantiates and calls it (model/model.py:152-162,
+  371-376; third-party transformers==3.1.0, requirements.txt:42, modeling_bert.py BertEmbeddings/BertEncoder):
+  word + position + token-type embeddings -> LayerNorm -> dropout -> the same encoder layers as model/bert.py with
+  head dim hidden/heads.  `P` uses HuggingFace key names (`LayerNorm`).  Returns sequence_output (B, W, hidden).
+  Pinned against the installed transformers' BertModel by oracle/gen_golden.py (tests/golden/text_bert.npz)."""
+  Q = {k.replace('.LayerNorm.', '.layer_norm.'): v for k, v in P.items()}
+  b, w = input_ids.shape
+  if position_ids is None:
+    position_ids = torch.arange(w).unsqueeze(0).expand(b, w)
+  if token_type_ids is None:
+    token_type_ids = torch.zeros_like(input_ids)
+  features = Q[pre + 'embeddings.word_embeddings.weight'][input_ids]
+  return bert_model(Q, pre, cfg, attention_mask, token_type_ids, position_ids, features)
+
+
 # ----------------------------------------------------------------------------
 # model/model.py
 # ----------------------------------------------------------------------------

@@ -39,3 +39,37 @@ def subsample(t, limit=4096):
   flat = t.detach().reshape(-1)
   stride = max(1, flat.numel() // limit)
   return flat[::stride][:limit].cpu().float().numpy()
+
+
+def text_bert_shapes(cfg):
+  """state_dict shapes of a HuggingFace BertModel with the given config fields (HF key names)."""
+  d, i = cfg['hidden_size'], cfg['intermediate_size']
+  sh = {'embeddings.word_embeddings.weight': (cfg['vocab_size'], d),
+        'embeddings.position_embeddings.weight': (cfg['max_position_embeddings'], d),
+        'embeddings.token_type_embeddings.weight': (cfg['type_vocab_size'], d),
+        'embeddings.LayerNorm.weight': (d,), 'embeddings.LayerNorm.bias': (d,),
+        'pooler.dense.weight': (d, d), 'pooler.dense.bias': (d,)}
+  for l in range(cfg['num_hidden_layers']):
+    p = 'encoder.layer.%d.' % l
+    for n in ('attention.self.query', 'attention.self.key', 'attention.self.value', 'attention.output.dense'):
+      sh[p + n + '.weight'], sh[p + n + '.bias'] = (d, d), (d,)
+    sh[p + 'intermediate.dense.weight'], sh[p + 'intermediate.dense.bias'] = (i, d), (i,)
+    sh[p + 'output.dense.weight'], sh[p + 'output.dense.bias'] = (d, i), (d,)
+    for n in ('attention.output.LayerNorm', 'output.LayerNorm'):
+      sh[p + n + '.weight'], sh[p + n + '.bias'] = (d,), (d,)
+  return sh
+
+
+def load_text_bert_fixture():
+  """-> (gold, cfg, state_dict with 'txt_bert.' prefix, input_ids, attention_mask, probe)."""
+  gold = load_npz('text_bert')
+  meta = json.loads(str(gold['meta']))
+  cfg = meta['cfg']
+  sd = synthetic.make_state_dict(meta['seed'], {('txt_bert.' + k): v for k, v in text_bert_shapes(cfg).items()})
+  sd['txt_bert.embeddings.word_embeddings.weight'][0].zero_()
+  for k, c in meta['param_checksums'].items():
+    assert abs(synthetic.checksum(sd[k]) - c) <= 1e-6 * max(1.0, abs(c)), 'generator drift: ' + k
+  b, w = meta['shape']
+  ids, mask = synthetic.text_token_batch(meta['seed'], b, w, cfg['vocab_size'])
+  probe = torch.from_numpy(np.random.RandomState(42).randn(b, cfg['hidden_size']).astype(np.float32))
+  return gold, cfg, sd, ids, mask, probe

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "attention" 2>&1 | tail -15 | cut -c1-400
+timeout 900 python -m pytest tests/test_text_bert_gpu.py -x -q 2>&1 | tail -25 | cut -c1-400
