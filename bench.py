@@ -46,14 +46,14 @@ class SyntheticTextTower(torch.nn.Module):
     return (self.text[:, None, :],)
 
 
-def build_model(pack, dropout=0.1):
+def build_model(pack, dropout=0.1, text_tower='synthetic'):
   vb = synthetic.vid_bert_params(hidden=HIDDEN, layers=LAYERS, heads=HEADS, inter=INTER, max_pos=32, dropout=dropout)
   return CENet(l2renorm=False, expert_dims=synthetic.compute_dims(synthetic.MSRVTT_MODALITIES), tokenizer=None,
                keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn',
                txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp',
                vid_bert_params=vb, txt_pro='gbn', same_dim=HIDDEN,
                txt_bert_params={'hidden_dropout_prob': dropout, 'attention_probs_dropout_prob': dropout},
-               txt_bert=SyntheticTextTower(), pack_tokens=pack)
+               txt_bert=SyntheticTextTower() if text_tower == 'synthetic' else 'native', pack_tokens=pack)
 
 
 def encoder_flops_per_step(batch, seq):
@@ -167,6 +167,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--grad-sync', choices=['auto', 'staged', 'single'], default='auto',
                   help='auto: staged backward with per-stage all-reduce when N > 1; staged/single force either')
+  ap.add_argument('--text-tower', choices=['synthetic', 'native'], default='synthetic',
+                  help='synthetic: (B,768) text vectors stand in for the text tower (the headline workload); native: '
+                       'random-init bert-base-cased on the engine, token ids in, fine-tuned with the rest (SURVEY 8f.2)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
   args = ap.parse_args()
 
@@ -190,7 +193,7 @@ def main():
       dist.init_process_group(backend, rank=rank, world_size=world)
 
   torch.manual_seed(0)
-  model = build_model(pack=not args.dense).to(dev).train()
+  model = build_model(pack=not args.dense, text_tower=args.text_tower).to(dev).train()
   mdist.broadcast_parameters(model)
   loss_fn = MaxMarginRankingLoss(margin=0.05, fix_norm=True)
 
@@ -203,7 +206,8 @@ def main():
     mb['text'] = text.view(-1, 768)
     batches.append(FlatMinibatch(mb, dev))  # one contiguous HBM buffer per minibatch: load = ONE D2D copy
   static = FlatMinibatch(batches[0], dev)
-  model.txt_bert.text = static['text']
+  if args.text_tower == 'synthetic':
+    model.txt_bert.text = static['text']
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
   runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                             overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync])
@@ -253,9 +257,11 @@ def main():
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: MSRVTT jsfusion shape, 7 experts x 30 tokens, d512, L4, H4, I3072, '
-                               'batch 32/GPU, dropout 0.1, train mode, Adam; text tower replaced by synthetic '
-                               '(B,768) vectors', 'global_batch': world * BATCH, 'seq_len': seq,
-                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'grad_sync': 'staged' if runner.staged else 'single',
+                               'batch 32/GPU, dropout 0.1, train mode, Adam; ' +
+                               ('text tower replaced by synthetic (B,768) vectors' if args.text_tower == 'synthetic' else
+                                'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
+                   'global_batch': world * BATCH, 'seq_len': seq,
+                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'text_tower': args.text_tower, 'grad_sync': 'staged' if runner.staged else 'single',
                    'live_rows_rank0': live, 'dense_rows': BATCH * seq},
         'encoder_dense_tflops': pairs_per_s / BATCH * flops / 1e12 / world,
         'encoder_dense_mfma_frac': pairs_per_s / BATCH * flops / 1e12 / world / BF16_DENSE_PEAK_TFLOPS,

@@ -219,10 +219,15 @@ class BertModel(nn.Module):
     self._flat, self._owns_flat = flat, False
     self._structs = {}
 
-  def _ensure_ready(self, device):
+  def build_flat(self):
+    """The flat parameter buffer this module owns (created on first use)."""
     if self._flat is None:
       self._flat = FlatParams(self.flat_named_params())
       self.register_shadows(self._flat)
+    return self._flat
+
+  def _ensure_ready(self, device):
+    self.build_flat()
     if self._owns_flat:
       if self._flat.ensure(device):
         self._structs = {}

@@ -297,9 +297,21 @@ class CENet(nn.Module):
       dout = vid_bert_params['hidden_dropout_prob']
       txt_bert_params = {'hidden_dropout_prob': dout, 'attention_probs_dropout_prob': dout}
     if txt_bert is None:
-      from transformers import BertModel as TxtBertModel  # model/model.py:39,161
-      txt_bert = TxtBertModel.from_pretrained('bert-base-cased', **txt_bert_params)
+      # model/model.py:39,152-162: pretrained bert-base-cased (needs the HuggingFace cache or network), moved onto
+      # the native engine; txt_bert='native' builds the same architecture with random weights (offline use: the
+      # weights then come from a trained MMT checkpoint via load_state_dict)
+      from transformers import BertModel as TxtBertModel
+      from .text_bert import TextBertModel
+      txt_bert = TextBertModel.from_hf(TxtBertModel.from_pretrained('bert-base-cased', **txt_bert_params))
+    elif isinstance(txt_bert, str):
+      if txt_bert != 'native':
+        raise ValueError("txt_bert: a module, None (pretrained bert-base-cased) or 'native' (random init)")
+      from .text_bert import TextBertModel, bert_base_cased_config
+      txt_bert = TextBertModel(bert_base_cased_config(**txt_bert_params))
     self.txt_bert = txt_bert
+    self._native_text_tower = hasattr(txt_bert, 'flat_named_params')
+    if self._native_text_tower:
+      txt_bert.cls_only = self.post_agg == 'cls'  # model/model.py:378-379 reads last_layer[:, 0] only
     if state == 'frz':
       for name, param in self.txt_bert.named_parameters():
         parts = name.split('.')
@@ -383,6 +395,14 @@ class CENet(nn.Module):
   def engine_params(self):
     """Parameters living in the flat buffer (video side), in layout order."""
     return self._flat.params
+
+  def flats(self):
+    """Every flat parameter buffer of the model: the video side (+ text heads) and, when it runs on the native
+    engine, the text tower's own (its 108 M parameters are an order of magnitude more than the rest)."""
+    out = [self._flat]
+    if self._native_text_tower:
+      out.append(self.txt_bert.build_flat())
+    return out
 
   # ---- video side --------------------------------------------------------------------------------
   def _reduce_params(self):

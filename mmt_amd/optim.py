@@ -39,9 +39,31 @@ class FlatAdam:
       self.lr_dev.fill_(lr)
       self._lr_on_dev = lr
 
+  def _frozen_spans(self):
+    """(offset, count) runs of the flat layout whose parameters have requires_grad == False.  The engine writes a
+    gradient for every parameter it owns; a frozen one (txt_agg='bertfrz...', model/model.py:164-192) must not move,
+    and with zero gradient from step one Adam's update is exactly zero (weight_decay must be 0)."""
+    f = self.flat
+    key = tuple(p.requires_grad for p in f.params)
+    if getattr(self, '_frozen_key', None) != key:
+      spans = []
+      for p in f.params:
+        if not p.requires_grad:
+          o, n = f.offset(p), p.numel()
+          if spans and spans[-1][0] + spans[-1][1] >= o - 64:
+            spans[-1] = (spans[-1][0], o + n - spans[-1][0])
+          else:
+            spans.append((o, n))
+      if spans and self.weight_decay != 0.0:
+        raise NotImplementedError('frozen parameters with weight_decay != 0')
+      self._frozen_key, self._frozen = key, spans
+    return self._frozen
+
   def _grad(self):
     f = self.flat
     g = f.current_grad()
+    for o, n in self._frozen_spans():
+      g[o:o + n].zero_()
     lo, hi = g.data_ptr(), g.data_ptr() + 4 * f.count
     p0 = next((p for p in f.params if p.requires_grad), None)
     if p0 is not None and p0.grad is not None and not (lo <= p0.grad.data_ptr() < hi):

@@ -91,11 +91,15 @@ class GraphedTrainStep:
     self._want_stages = self.world > 1 if overlap_grad_sync is None else bool(overlap_grad_sync)
     self.staged = False
     self.static = minibatch
-    flat_ids = {id(p) for p in model.engine_params()}
+    flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
+    flat_ids = {id(p) for f in flats for p in f.params}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
-    self.opt_flat = FlatAdam(model._flat, lr=lr)
+    self.opt_flats = [FlatAdam(f, lr=lr) for f in flats]
+    self.opt_flat = self.opt_flats[0]
     self.opt_rest = torch.optim.Adam(rest, lr=lr, capturable=use_graphs) if rest else None
-    self.sync = mdist.GradSync(model._flat, rest, group)
+    self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group) for i, f in enumerate(flats)]
+    self.sync = self.syncs[0]
+    self._extra_flats = flats[1:]
     self.use_graphs = use_graphs
     self.loss = None
     self._graphs = None
@@ -227,31 +231,53 @@ class GraphedTrainStep:
       st['run'](0, 0)
       model._video_tokens_backward(model._stages['plan'], st['run'].dfeat)
 
-    stages = [(head, ['text'])]
+    stages = [(head, ['text'] + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
     for l in range(vb.config.num_hidden_layers - 1, 0, -1):
       stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
     stages.append((bottom, ['layer0', 'reduce']))
     return stages
 
+  def _region_table(self):
+    """name -> (flat, offset, count): the video flat's spans in backward order + every other flat as one span (the
+    native text tower's backward runs with the text heads, in the first stage)."""
+    tab = {n: (self.model._flat, off, cnt) for n, (off, cnt) in self.model.grad_regions()}
+    for i, f in enumerate(self._extra_flats):
+      tab['flat%d' % (i + 1)] = (f, 0, f.count)
+    return tab
+
   def _reduce_async(self, names):
     if self.world == 1:
       return []
-    gbuf = self.model._flat.current_grad()
     out = []
     for n in names:
-      off, cnt = self._regions[n]
-      out.append(dist.all_reduce(gbuf[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+      flat, off, cnt = self._regions[n]
+      out.append(dist.all_reduce(flat.current_grad()[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group,
+                                 async_op=True))
     return out
 
   def _zero(self):
-    self.opt_flat.zero_grad()
+    for o in self.opt_flats:
+      o.zero_grad()
     if self.opt_rest is not None:
       self.opt_rest.zero_grad(set_to_none=True)
 
   def _opt(self):
-    self.opt_flat.step()
+    for o in self.opt_flats:
+      o.step()
     if self.opt_rest is not None:
       self.opt_rest.step()
+
+  def _sync_all(self):
+    for sy in self.syncs:
+      sy.sync()
+
+  def set_lr(self, lr):
+    """One learning rate for every optimizer of the step (the reference has a single param group, train.py:100)."""
+    for o in self.opt_flats:
+      o.lr = lr
+    if self.opt_rest is not None:
+      for g in self.opt_rest.param_groups:
+        g['lr'] = lr
 
   _gbuf = None
 
@@ -260,7 +286,7 @@ class GraphedTrainStep:
     e = self._forward()
     g = self._gather(e)
     if self.staged:
-      self._regions = dict(self.model.grad_regions())
+      self._regions = self._region_table()
       handles = []
       for fn, names in self._stage_list(e, g):
         fn()
@@ -269,7 +295,7 @@ class GraphedTrainStep:
         h.wait()
     else:
       self.loss = self._loss_backward(e, g)
-      self.sync.sync()
+      self._sync_all()
     self._opt()
 
   # ---- capture -----------------------------------------------------------------------------------
@@ -296,7 +322,7 @@ class GraphedTrainStep:
         self.loss = self._loss_backward(e, g)
       pool, gb = ga.pool(), None
     elif self.staged:
-      self._regions = dict(self.model.grad_regions())
+      self._regions = self._region_table()
       gb = []
       for fn, names in self._stage_list(e, g):
         gs = torch.cuda.CUDAGraph()
@@ -327,7 +353,8 @@ class GraphedTrainStep:
     if not self.use_graphs:
       self._eager_step()
       return self.loss
-    self.opt_flat.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
+    for o in self.opt_flats:
+      o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     ga, gb, gc = self._graphs
     ga.replay()
     if self.world > 1:
@@ -343,6 +370,6 @@ class GraphedTrainStep:
         h.wait()
     else:
       gb.replay()
-      self.sync.sync()
+      self._sync_all()
     gc.replay()
     return self.loss

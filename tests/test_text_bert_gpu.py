@@ -84,3 +84,68 @@ def test_text_tower_bert_base_shape_matches_oracle():
     name = k[len('txt_bert.'):].replace('.LayerNorm.', '.layer_norm.')
     got = flat.view(named[name], flat.current_grad()).detach().cpu().numpy()
     assert _relerr(got, P[k].grad.numpy()) < 5e-2, (k, _relerr(got, P[k].grad.numpy()))
+
+
+def test_cenet_with_native_text_tower_matches_oracle():
+  """End to end with the text tower inside the model (txt_inp/txt_agg = 'bertftn': fine-tuned, model/model.py:349-379):
+  token ids -> native text tower -> text heads -> similarity -> loss, gradients into the text tower and the video side,
+  against the oracle (text_bert_model feeding cenet_forward) on the 'tiny' fixture's video inputs."""
+  import copy
+  import json
+  import types
+  from mmt_amd import synthetic
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from mmt_amd.model import CENet
+  from mmt_amd.text_bert import TextBertModel, bert_base_cased_config
+  from oracle import mmt_oracle as O
+  from tests.fixtures import load_cenet_fixture, text_bert_shapes
+  fx = load_cenet_fixture('tiny')
+  f = fx.meta['fixture']
+  tcfg = dict(vocab_size=28996, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1024,
+              max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+              layer_norm_eps=1e-12, pad_token_id=0)
+  txt = TextBertModel(bert_base_cased_config(**tcfg))
+  vb = synthetic.vid_bert_params(dropout=0.0, **f['vb'])
+  model = CENet(l2renorm=False, expert_dims=synthetic.compute_dims(f['modalities']), tokenizer=None,
+                keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn',
+                txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp',
+                vid_bert_params=vb, txt_pro='gbn', same_dim=f['vb']['hidden'],
+                txt_bert_params={'hidden_dropout_prob': 0.0, 'attention_probs_dropout_prob': 0.0}, txt_bert=txt)
+  assert model._native_text_tower and model.txt_bert.cls_only
+  tsd = synthetic.make_state_dict(45, {('txt_bert.' + k): v for k, v in text_bert_shapes(tcfg).items()})
+  tsd['txt_bert.embeddings.word_embeddings.weight'][0].zero_()
+  sd = dict(fx.state_dict)
+  sd.update(tsd)
+  model.load_state_dict(sd)
+  model.to(DEV).train()
+  mb = fx.batch
+  dev_mb = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in mb.items()}
+  out = model(dev_mb['token_ids'], dev_mb['features'], dev_mb['features_t'], dev_mb['features_ind'],
+              dev_mb['features_avgpool'], dev_mb['features_maxpool'], dev_mb['query_masks'], out='conf', device=DEV)
+  sims = out['cross_view_conf_matrix']
+  loss = MaxMarginRankingLoss(0.05, True)(sims)
+  loss.backward()
+  # ---- oracle ----
+  probes = ['txt_bert.embeddings.word_embeddings.weight', 'txt_bert.encoder.layer.0.attention.self.value.weight',
+            'txt_bert.encoder.layer.1.output.dense.weight', 'vid_bert.encoder.layer.0.attention.self.query.weight',
+            'text_GU.%s.fc.weight' % fx.cfg['modalities'][0]]
+  P = {k: (v.clone().requires_grad_(True) if k in probes else v.clone()) for k, v in sd.items()}
+  tok = mb['token_ids']
+  b, c, w, _ = tok.shape
+  ids, mask = tok.view(b * c, w, 2)[:, :, 0].long(), tok.view(b * c, w, 2)[:, :, 1].long()
+  pos = torch.arange(w).unsqueeze(0).expand(b * c, w)
+  text = O.text_bert_model(P, 'txt_bert.', tcfg, ids, mask, None, pos)[:, 0].view(b, c, -1)
+  o = O.cenet_forward(P, fx.cfg, copy.deepcopy(mb), text, training=True)
+  o_sims = o['cross_view_conf_matrix']
+  o_loss = O.max_margin_ranking_loss(o_sims, 0.05, True)
+  o_loss.backward()
+  assert (sims.detach().cpu() - o_sims.detach()).abs().max().item() < 3e-3
+  assert abs(loss.item() - o_loss.item()) < 2e-2 * max(abs(o_loss.item()), 1e-3)
+  named = dict(model.named_parameters())
+  for k in probes:
+    flat = model.txt_bert._flat if k.startswith('txt_bert.') else model._flat
+    key = named[k.replace('.LayerNorm.', '.layer_norm.')]
+    got = flat.view(key, flat.current_grad()).detach().cpu().numpy()
+    ref = P[k].grad.numpy()
+    cos = float((got.ravel().astype(np.float64) @ ref.ravel().astype(np.float64)) / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+    assert cos > 0.995 and abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1.0) < 0.05, (k, cos)  # same bar as the video side
