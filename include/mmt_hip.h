@@ -155,12 +155,25 @@ int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, fl
 int mmt_rows_gather(const float* src, const int32_t* rows, int n, int d, float* dst, const int32_t* idx_in,
                     int32_t* idx_out, void* stream);
 int mmt_rows_scatter(const float* src, const int32_t* rows, int n, int d, float* dst, int accumulate, void* stream);
+/* Embedding-table gradient written directly (dtable[v] = sum of g[r] over token rows r < min(rows, *n_rows_dev) with
+ * ids[r] == v, row order; rows of unused ids are zeroed): for large tables with few ids in use (BERT-base's 512-row
+ * position table).  The small video-BERT tables use mmt_table_grad_partials + mmt_col_reduce. */
+int mmt_table_grad_direct(const float* g, const int32_t* ids, int rows, int d, int vocab, const int32_t* n_rows_dev,
+                          float* dtable, void* stream);
 /* Word-embedding gradient of the text tower (HF BertEmbeddings.word_embeddings, reached from model/model.py:371-376):
  * dtable[id] = sum of g[i] over token rows i with ids[i] == id, in row order (deterministic); rows with
- * id == padding_idx or outside [0, vocab) contribute nothing.  dtable [vocab, d] must be zero on entry.  The forward
+ * id == padding_idx or outside [0, vocab) contribute nothing; n_rows_dev (nullable) bounds n on the device.  dtable
+ * [vocab, d] must be zero on entry.  The forward
  * lookup is mmt_rows_gather(table, ids, ...). */
-int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int vocab, int padding_idx, float* dtable,
-                       void* stream);
+int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int vocab, int padding_idx,
+                       const int32_t* n_rows_dev, float* dtable, void* stream);
+/* Text-side token packing (drops the padded tokens of model/model.py:353-369; valid when only the [CLS] row of the
+ * last layer is read, :378-379).  int64 [B, W] inputs (token_type_ids nullable = 0, position_ids nullable = 0..W-1);
+ * int32 outputs: counts [B], cu_seqlens [B+1], n_rows_dev [1], ids/types/pos/row_index [>= B*W] (first *n_rows_dev
+ * entries written; row_index = dense coordinate b*W + t), cls_rows [B] = first kept row of each sample. */
+int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
+                  const int64_t* attention_mask, int B, int W, int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev,
+                  int32_t* ids, int32_t* types, int32_t* pos, int32_t* row_index, int32_t* cls_rows, void* stream);
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
  * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */

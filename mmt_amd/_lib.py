@@ -134,7 +134,9 @@ SIGNATURES = {
     'mmt_ln_fwd_scatter': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mmt_rows_gather': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_rows_scatter': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
-    'mmt_embedding_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_embedding_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_text_plan': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_table_grad_direct': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_attn_dropout_mask': (c_int, [c_vp, c_int, c_int, c_int, c_u32, c_u32, c_vp, c_vp]),
     'mmt_reduce_slabs_2d': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_colsum_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -189,6 +189,75 @@ static int make_table(const MmtExpertIO* experts, int M, ExpertTable& tab) {
   return 0;
 }
 
+// ---- text-side token plan ------------------------------------------------------------------------------------------
+// The reference pads every caption to max_text_words and runs the text tower on all of them (model/model.py:353-376).
+// Only the [CLS] row of the last layer is read (post_agg 'cls', :378-379) and padded tokens are masked as keys in every
+// layer, so -- exactly as on the video side -- dropping them changes nothing: keep the tokens with attention_mask != 0,
+// in order, sample after sample.  row_index keeps the dense coordinate b*W + t (dropout RNG), cls_rows[b] = first kept
+// row of sample b (the caller guarantees attention_mask[:, 0] == 1).
+__global__ __launch_bounds__(256) void text_count_kernel(const int64_t* __restrict__ mask, int W, int32_t* __restrict__ counts) {
+  __shared__ int red[4];
+  const int b = blockIdx.x;
+  int c = 0;
+  for (int t = threadIdx.x; t < W; t += 256) c += mask[(int64_t)b * W + t] != 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void text_pack_kernel(const int64_t* __restrict__ ids_in, const int64_t* __restrict__ types_in,
+                                                        const int64_t* __restrict__ pos_in, const int64_t* __restrict__ mask,
+                                                        int W, const int32_t* __restrict__ cu, int32_t* __restrict__ ids,
+                                                        int32_t* __restrict__ types, int32_t* __restrict__ pos,
+                                                        int32_t* __restrict__ row_index, int32_t* __restrict__ cls_rows) {
+  __shared__ int wave_cnt[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = cu[b];
+  int carry = 0;
+  for (int t0 = 0; t0 < W; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const int64_t src = (int64_t)b * W + t;
+    const bool keep = t < W && mask[src] != 0;
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < wave) woff += wave_cnt[i]; total += wave_cnt[i]; }
+    if (keep) {
+      const int r = base + carry + woff + before;
+      ids[r] = (int32_t)ids_in[src];
+      types[r] = types_in ? (int32_t)types_in[src] : 0;
+      pos[r] = pos_in ? (int32_t)pos_in[src] : t;
+      row_index[r] = (int32_t)src;
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cls_rows[b] = base;
+}
+
+// input_ids / token_type_ids (nullable: 0) / position_ids (nullable: 0..W-1) / attention_mask: contiguous int64 [B, W].
+// Outputs (int32): counts [B], cu_seqlens [B+1], n_rows_dev [1], ids / types / pos / row_index [>= B*W] (only the first
+// *n_rows_dev entries are written), cls_rows [B].
+extern "C" int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
+                             const int64_t* attention_mask, int B, int W, int32_t* counts, int32_t* cu_seqlens,
+                             int32_t* n_rows_dev, int32_t* ids, int32_t* types, int32_t* pos, int32_t* row_index,
+                             int32_t* cls_rows, void* stream) {
+  if (!input_ids || !attention_mask || !counts || !cu_seqlens || !n_rows_dev || !ids || !types || !pos || !row_index ||
+      !cls_rows || B <= 0 || W <= 0)
+    return MMT_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(text_count_kernel, dim3(B), dim3(256), 0, s, attention_mask, W, counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(64), 0, s, counts, B, cu_seqlens, n_rows_dev);
+  hipLaunchKernelGGL(text_pack_kernel, dim3(B), dim3(256), 0, s, input_ids, token_type_ids, position_ids, attention_mask, W,
+                     cu_seqlens, ids, types, pos, row_index, cls_rows);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos,
                               int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot,
                               int32_t* row_index, int32_t* type_ids, int32_t* pos_ids, float* mask_bias,

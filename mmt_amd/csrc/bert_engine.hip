@@ -61,7 +61,8 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
   if (ln_nb < small_nb) ln_nb = small_nb;
   for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(ln_nb * 3 * d * 4);
-  const int vmax = m->type_vocab > m->max_pos ? m->type_vocab : m->max_pos;
+  const int pos_v = m->max_pos > 64 ? 0 : m->max_pos;  // larger position tables take mmt_table_grad_direct (no scratch)
+  const int vmax = m->type_vocab > pos_v ? m->type_vocab : pos_v;
   {  // tail buffers: B*M read-out rows are at most a quarter of the token rows for T >= 3 (else: full path)
     const size_t C = (size_t)mmt_bert_tail_capacity(R);
     TailWs& t = w->t;
@@ -123,6 +124,18 @@ extern "C" int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_allo
   Ws w;
   layout(m, rows_alloc, nullptr, &w);
   return (int64_t)w.bytes;
+}
+
+// N = hidden GEMMs with a long K on SHORT batches (the text tower: ~1000 token rows x 768): too few output tiles for
+// 256 CUs and a 36..48-step dependent K loop per tile -> split K over 2..4 blocks per tile (partials in the tail's slab
+// workspace, which is idle outside the tail layer) and reduce in the epilogue kernel.  Measured 30 -> 17 us (K = 3072),
+// 24 -> 15.5 us (K = 2304) at 960 rows; not worth it at K = 768.  The video side (thousands of rows) never takes it.
+static int gemm_hidden(const Ws& w, int rows, int d, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                       int64_t ldc, int K, int epi, const MmtEpilogue* e, const int32_t* nr, void* stream) {
+  const int tiles = ((rows + 127) / 128) * (d / 64), ksteps = K / 64;
+  if (tiles < 160 && ksteps >= 32 && rows <= 4 * w.t.cap)
+    return mmt_gemm_nt_splitk_ex(A, lda, B, ldb, C, ldc, rows, d, K, epi, e, w.t.slabs, ksteps >= 48 ? 4 : 2, 0, nr, 0, stream);
+  return mmt_gemm_nt_bf16(A, lda, B, ldb, C, ldc, rows, d, K, epi, e, nr, stream);
 }
 
 extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last,
@@ -189,7 +202,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
     e = {};
     e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-    TRY(mmt_gemm_nt_bf16(L.g, I, P.w2, I, L.z2, d, rows, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
+    TRY(gemm_hidden(w, rows, d, L.g, I, P.w2, I, L.z2, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
     float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
     TRY(mmt_ln_fwd(L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16, L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
     hin32 = hout32;
@@ -257,7 +270,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
                             b->seed_dev, stream));
       e = {};
       float* dnext = w.dA;
-      TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
+      TRY(gemm_hidden(w, rows, d, w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
       TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, dnext, 1, stream));
       {
         MmtWgradGroup g = {};
@@ -288,7 +301,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     // --- BertIntermediate: dense(d->I) ---
     e = {};
     e.res = w.dz; e.ldres = d;
-    TRY(mmt_gemm_nt_bf16(w.dhpre, I, P.w1_t, I, w.dA, d, rows, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
+    TRY(gemm_hidden(w, rows, d, w.dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
     TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
@@ -302,7 +315,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.
-    TRY(mmt_gemm_nt_bf16(w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, rows, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+    TRY(gemm_hidden(w, rows, d, w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- all four weight gradients + bias gradients of the layer: ONE grouped launch (256 tiles at d=512, I=3072) ---
     {
       MmtWgradGroup g = {};
@@ -328,8 +341,12 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   TRY(mmt_table_grad_partials(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch[0], stream));
   add_job(w.table_scratch[0], chunks, 1, 1, m->type_vocab * d, m->g_type_emb, nullptr);
   if (b->pos_ids) {
-    TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], stream));
-    add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
+    if (m->max_pos > 64) {  // BERT-base position table (512 rows, a few dozen in use): no vocab-sized partial sums
+      TRY(mmt_table_grad_direct(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, m->g_pos_emb, stream));
+    } else {
+      TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], stream));
+      add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
+    }
   }
   return mmt_col_reduce_multi(jobs, njobs, stream);
 }

@@ -335,14 +335,40 @@ extern "C" int mmt_rows_scatter(const float* src, const int32_t* rows, int n, in
   return (int)hipGetLastError();
 }
 
+// Table gradient for LARGE vocabularies with few distinct ids in use (BERT-base position table: 512 rows, 30 used):
+// one block per table row v sums the token rows with ids[r] == v in row order and writes (zero if none) -- no partial
+// buffers proportional to vocab * d.  d <= 1024.
+__global__ __launch_bounds__(256) void table_grad_direct_kernel(const float* __restrict__ g, const int32_t* __restrict__ ids,
+                                                                int rows, int d, const int32_t* __restrict__ n_rows_dev,
+                                                                float* __restrict__ out) {
+  const int v = blockIdx.x, c = threadIdx.x * 4;
+  const int n = n_rows_dev ? min(rows, *n_rows_dev) : rows;
+  if (c >= d) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < n; ++r)
+    if (ids[r] == v) acc += *(const f32x4*)(g + (int64_t)r * d + c);  // block-uniform branch
+  *(f32x4*)(out + (int64_t)v * d + c) = acc;
+}
+
+extern "C" int mmt_table_grad_direct(const float* g, const int32_t* ids, int rows, int d, int vocab,
+                                     const int32_t* n_rows_dev, float* dtable, void* stream) {
+  if (!g || !ids || !dtable || rows <= 0 || vocab <= 0 || d <= 0 || (d & 3) || d > 1024) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(table_grad_direct_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, g, ids, rows, d, n_rows_dev,
+                     dtable);
+  return (int)hipGetLastError();
+}
+
 // Word-embedding gradient (the text tower's nn.Embedding backward, deterministic): dtable[id] = sum over the token rows
 // i with ids[i] == id of g[i], in row order.  One block per token row; the block of an id's FIRST occurrence does the
 // whole sum for that id (rows <= a few thousand: the id scan is cheap), every other block exits.  `padding_idx` rows get
 // no gradient (nn.Embedding(padding_idx=...)).  dtable must be zero on entry (untouched ids keep a zero gradient).
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ ids,
                                                              int n, int d, int vocab, int padding_idx,
+                                                             const int32_t* __restrict__ n_rows_dev,
                                                              float* __restrict__ dtable) {
   const int i = blockIdx.x;
+  if (n_rows_dev) n = min(n, *n_rows_dev);
+  if (i >= n) return;
   const int id = ids[i];
   if (id < 0 || id >= vocab || id == padding_idx) return;
   int seen = 0;
@@ -357,10 +383,10 @@ __global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __rest
 }
 
 extern "C" int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int vocab, int padding_idx,
-                                  float* dtable, void* stream) {
+                                  const int32_t* n_rows_dev, float* dtable, void* stream) {
   if (!g || !ids || !dtable || n <= 0 || d <= 0 || (d & 3) || vocab <= 0) return MMT_ERR_ARG;
   hipLaunchKernelGGL(embedding_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, g, ids, n, d, vocab, padding_idx,
-                     dtable);
+                     n_rows_dev, dtable);
   return (int)hipGetLastError();
 }
 

@@ -41,12 +41,12 @@ class _WordEmbeddingFn(torch.autograd.Function):
   """features[r] = table[ids[r]] on the padded row grid; backward = deterministic scatter-add into the flat gradient."""
 
   @staticmethod
-  def forward(ctx, model, ids_i32, rows, table):
+  def forward(ctx, model, ids_i32, rows, table, n_rows_dev=None):
     R, d = ids_i32.shape[0], table.shape[1]
     out = torch.zeros(R, d, device=table.device, dtype=torch.float32)
     check(_lib.lib().mmt_rows_gather(ops._p(table), ops._p(ids_i32), rows, d, ops._p(out), None, None, ops._stream()),
           'mmt_rows_gather')
-    ctx.model, ctx.rows = model, rows
+    ctx.model, ctx.rows, ctx.n_rows_dev = model, rows, n_rows_dev
     ctx.save_for_backward(ids_i32)
     return out
 
@@ -56,15 +56,16 @@ class _WordEmbeddingFn(torch.autograd.Function):
     model = ctx.model
     table = model.embeddings.word_embeddings.weight
     if not table.requires_grad:
-      return None, None, None, None
+      return None, None, None, None, None
     flat = model._flat
     gview = flat.view(table, flat.current_grad())
     gview.zero_()
     pad = model.embeddings.word_embeddings.padding_idx
     check(_lib.lib().mmt_embedding_grad(ops._p(g.contiguous()), ops._p(ids_i32), ctx.rows, table.shape[1], table.shape[0],
-                                        -1 if pad is None else int(pad), ops._p(gview), ops._stream()),
-          'mmt_embedding_grad')
-    return None, None, None, gview
+                                        -1 if pad is None else int(pad),
+                                        ops._p(ctx.n_rows_dev) if ctx.n_rows_dev is not None else None, ops._p(gview),
+                                        ops._stream()), 'mmt_embedding_grad')
+    return None, None, None, gview, None
 
 
 class TextBertModel(BertModel):
@@ -85,6 +86,7 @@ class TextBertModel(BertModel):
       emb.weight.data[cfg.pad_token_id].zero_()
     self.embeddings.word_embeddings = emb
     self.cls_only = False
+    self.pack_tokens = True      # with cls_only: drop the padded tokens (exact, see mmt_text_plan)
     self.compute_pooler = False  # model/model.py:376 reads output[0] only
     self._plans = {}
     self._register_load_state_dict_pre_hook(self._hf_names_in)
@@ -125,7 +127,13 @@ class TextBertModel(BertModel):
                                 pos=torch.zeros(R, dtype=torch.int32, device=dev),
                                 mask_bias=torch.zeros(R, dtype=torch.float32, device=dev),
                                 cls_rows=torch.arange(bsz, dtype=torch.int32, device=dev) * seq,
-                                compact=torch.arange(bsz, dtype=torch.int32, device=dev))
+                                # packed variant (mmt_text_plan): one int32 block [ids | types | pos | row_index] + scalars
+                                packed=torch.zeros(4, R, dtype=torch.int32, device=dev),
+                                counts=torch.zeros(bsz, dtype=torch.int32, device=dev),
+                                cu=torch.zeros(bsz + 1, dtype=torch.int32, device=dev),
+                                n_rows=torch.zeros(1, dtype=torch.int32, device=dev),
+                                packed_cls=torch.zeros(bsz, dtype=torch.int32, device=dev),
+                                zero_bias=torch.zeros(R, dtype=torch.float32, device=dev))
       self._plans[key] = p
     return p
 
@@ -144,30 +152,43 @@ class TextBertModel(BertModel):
     self._ensure_ready(dev)
     p = self._plan(bsz, seq, dev)
     rows = p.rows
-    p.ids[:rows].copy_(input_ids.reshape(-1))
-    if token_type_ids is None:
-      p.types.zero_()
-    else:
-      p.types[:rows].copy_(token_type_ids.reshape(-1))
-    if position_ids is None:
-      p.pos[:rows].copy_(torch.arange(seq, device=dev, dtype=torch.int32).repeat(bsz))
-    else:
-      p.pos[:rows].copy_(position_ids.expand(bsz, seq).reshape(-1))
-    if attention_mask is None:
-      p.mask_bias.zero_()
-    else:
-      torch.mul(1.0 - attention_mask.reshape(-1).to(torch.float32), -10000.0, out=p.mask_bias[:rows])
     table = self.embeddings.word_embeddings.weight
-    feats = _WordEmbeddingFn.apply(self, p.ids, rows, table)
-    batch = EngineBatch(None, p.types, p.pos, p.mask_bias, rows, bsz, seq,
-                        out_rows=p.cls_rows if self.cls_only else None, n_out_per_sample=1 if self.cls_only else 0)
+    if self.cls_only and self.pack_tokens and attention_mask is not None:
+      # variable-length path: the engine sees only the real tokens (cu_seqlens), the [CLS] rows are read out
+      def i64(x):
+        return None if x is None else x.expand(bsz, seq).to(torch.int64).contiguous()
+      ids64, typ64, pos64, msk64 = i64(input_ids), i64(token_type_ids), i64(position_ids), i64(attention_mask)
+      p.packed.zero_()
+      check(_lib.lib().mmt_text_plan(ops._p(ids64), ops._p(typ64) if typ64 is not None else None,
+                                     ops._p(pos64) if pos64 is not None else None, ops._p(msk64), bsz, seq,
+                                     ops._p(p.counts), ops._p(p.cu), ops._p(p.n_rows), ops._p(p.packed[0]),
+                                     ops._p(p.packed[1]), ops._p(p.packed[2]), ops._p(p.packed[3]), ops._p(p.packed_cls),
+                                     ops._stream()), 'mmt_text_plan')
+      feats = _WordEmbeddingFn.apply(self, p.packed[0], rows, table, p.n_rows)
+      batch = EngineBatch(None, p.packed[1], p.packed[2], p.zero_bias, rows, bsz, seq, cu_seqlens=p.cu,
+                          row_index=p.packed[3], n_rows_dev=p.n_rows, out_rows=p.packed_cls, n_out_per_sample=1)
+    else:
+      p.ids[:rows].copy_(input_ids.reshape(-1))
+      if token_type_ids is None:
+        p.types.zero_()
+      else:
+        p.types[:rows].copy_(token_type_ids.reshape(-1))
+      if position_ids is None:
+        p.pos[:rows].copy_(torch.arange(seq, device=dev, dtype=torch.int32).repeat(bsz))
+      else:
+        p.pos[:rows].copy_(position_ids.expand(bsz, seq).reshape(-1))
+      if attention_mask is None:
+        p.mask_bias.zero_()
+      else:
+        torch.mul(1.0 - attention_mask.reshape(-1).to(torch.float32), -10000.0, out=p.mask_bias[:rows])
+      feats = _WordEmbeddingFn.apply(self, p.ids, rows, table)
+      batch = EngineBatch(None, p.types, p.pos, p.mask_bias, rows, bsz, seq,
+                          out_rows=p.cls_rows if self.cls_only else None, n_out_per_sample=1 if self.cls_only else 0)
     last = self.run_engine(batch, feats)
     d = self.config.hidden_size
     if self.cls_only:
-      if self.compact_output(batch, p.R):
-        seq_out = last[:bsz].view(bsz, 1, d)
-      else:
-        seq_out = last[:rows].view(bsz, seq, d)[:, :1]
+      cls = last[:bsz] if self.compact_output(batch, p.R) else last.index_select(0, batch.out_rows.long())
+      seq_out = cls.view(bsz, 1, d)
     else:
       seq_out = last[:rows].view(bsz, seq, d)
     return (seq_out, self.pooler(seq_out) if self.compute_pooler and not self.cls_only else None)

@@ -25,11 +25,11 @@ def _relerr(a, b):
   return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.mark.parametrize('cls_only', [False, True])
-def test_text_tower_matches_transformers_golden(cls_only):
+@pytest.mark.parametrize('cls_only,pack', [(False, False), (True, False), (True, True)])
+def test_text_tower_matches_transformers_golden(cls_only, pack):
   gold, cfg, sd, ids, mask, probe = load_text_bert_fixture()
   model = _native(cfg, sd).train()  # dropout probabilities are 0 in this fixture
-  model.cls_only = cls_only
+  model.cls_only, model.pack_tokens = cls_only, pack
   pos = torch.arange(ids.shape[1]).unsqueeze(0).expand_as(ids)
   seq = model(ids.to(DEV), attention_mask=mask.to(DEV), token_type_ids=torch.zeros_like(ids).to(DEV),
               position_ids=pos.to(DEV), head_mask=None)[0]
@@ -149,3 +149,23 @@ def test_cenet_with_native_text_tower_matches_oracle():
     ref = P[k].grad.numpy()
     cos = float((got.ravel().astype(np.float64) @ ref.ravel().astype(np.float64)) / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
     assert cos > 0.995 and abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1.0) < 0.05, (k, cos)  # same bar as the video side
+
+
+def test_text_token_packing_is_exact_including_dropout():
+  """Dropping the padded tokens (mmt_text_plan) changes nothing: same [CLS] outputs and gradients as the padded run, with
+  dropout ON (the RNG is indexed by the dense coordinate b*W + t)."""
+  gold, cfg, sd, ids, mask, probe = load_text_bert_fixture()
+  cfg = dict(cfg, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+  outs = []
+  for pack in (False, True):
+    model = _native(cfg, sd).train()
+    model.cls_only, model.pack_tokens = True, pack
+    model._ensure_ready(DEV)
+    model._seed_dev.fill_(1234)
+    seq = model(ids.to(DEV), attention_mask=mask.to(DEV), token_type_ids=None, position_ids=None)[0]
+    (seq[:, 0] * probe.to(DEV)).sum().backward()
+    flat = model._flat
+    outs.append((seq.detach().cpu(), flat.current_grad().detach().cpu().clone()))
+  assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-3
+  g0, g1 = outs[0][1], outs[1][1]
+  assert (g0 - g1).norm().item() < 2e-3 * g0.norm().item()
