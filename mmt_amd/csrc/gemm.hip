@@ -517,7 +517,11 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
   //     staggered groups (LDS-DMA issue of one group under the other's MFMAs);
   //   * the dense N = 512 GEMMs stay on this file's 128x64 4-wave tile (both saturate the ~27 B/clk/CU LDS ingest).
   // reserved: 1/2 force the gemm.hip tiles, >= 3 a gemm2 tile.
+  //   * short batches (M <= 1024: the text tower's ~560..960 token rows): too few 128x128 tiles for 256 CUs; the
+  //     128x64 8-wave tile wins everywhere (tools/gemm_lab.py --text: 10.3 vs 13.2 us FFN-up at 560 live rows).
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (e.reserved == 0 && M <= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
+    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if (e.reserved == 0 && M >= 512) {
     if (N >= 1024 && N % 128 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum))
       return mmt_gemm2_dispatch(14, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

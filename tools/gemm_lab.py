@@ -83,6 +83,7 @@ def main():
   ap.add_argument('--tiles', default='1,2,3,4,5,6')
   ap.add_argument('--ablate', action='store_true', help='(needs a lab build with debug flags)')
   ap.add_argument('--nocheck', action='store_true')
+  ap.add_argument('--text', action='store_true', help='the text tower shapes (d = 768) instead of the video ones (d = 512)')
   args = ap.parse_args()
   tiles = [int(t) for t in args.tiles.split(',')]
   for tile in tiles:
@@ -112,9 +113,12 @@ def main():
   for rows in [int(r) for r in args.rows.split(',')]:
     R = ops.pad_rows(rows)
     print('rows', rows)
-    for (N, K, epi) in [(3072, 512, 'BIAS_GELU'), (3072, 512, 'DGELU'), (3072, 512, 'BIAS_BF16'), (1536, 512, 'BIAS_BF16'),
-                        (512, 512, 'BIAS_DROP_RES'), (512, 3072, 'BIAS_DROP_RES'), (512, 3072, 'ADD_F32'),
-                        (512, 1536, 'ADD_F32'), (512, 512, 'BF16')]:
+    video = [(3072, 512, 'BIAS_GELU'), (3072, 512, 'DGELU'), (3072, 512, 'BIAS_BF16'), (1536, 512, 'BIAS_BF16'),
+             (512, 512, 'BIAS_DROP_RES'), (512, 3072, 'BIAS_DROP_RES'), (512, 3072, 'ADD_F32'), (512, 1536, 'ADD_F32'),
+             (512, 512, 'BF16')]
+    text = [(3072, 768, 'BIAS_GELU'), (3072, 768, 'DGELU'), (2304, 768, 'BIAS_BF16'), (768, 768, 'BIAS_DROP_RES'),
+            (768, 768, 'BF16')]
+    for (N, K, epi) in (text if args.text else video):
       a, b = rnd(R, K), rnd(N, K, scale=0.05)
       bias, res = rnd(N, dtype=torch.float32), rnd(R, N, dtype=torch.float32)
       f32 = epi in ('BIAS_DROP_RES', 'ADD_F32')
