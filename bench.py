@@ -80,11 +80,13 @@ class KernelProbe:
     self._lib = _lib.lib()
     self._lib.mmt_probe_arm(self._a, self._b, n)
 
-  def finish(self):
+  def finish(self, stride=1, offset=0):
+    """stride/offset: with the native text tower every step runs TWO encoder forwards (text first, then video): the
+    video tower's launches are the odd ones."""
     used = self._lib.mmt_probe_count()
     self._lib.mmt_probe_arm(None, None, 0)
-    ms = [self.start[i].elapsed_time(self.stop[i]) for i in range(used)]
-    return sum(ms) / max(1, len(ms)) * 1e-3, used
+    ms = [self.start[i].elapsed_time(self.stop[i]) for i in range(offset, used, stride)]
+    return sum(ms) / max(1, len(ms)) * 1e-3, len(ms)
 
 
 def time_dominant_kernel(rows, iters=40):
@@ -238,7 +240,8 @@ def main():
   # dominant-kernel duration: HIP events around its launch (engine probe) in eager steps of the same
   # workload right after the timed region (events cannot be read back from inside a graph replay)
   probe_steps = 8
-  probe = KernelProbe(probe_steps) if rank == 0 else None
+  towers = 2 if args.text_tower == 'native' else 1
+  probe = KernelProbe(probe_steps * towers) if rank == 0 else None
   live_rows = []
   plan0 = model._plans[next(iter(model._plans))]
   for _ in range(probe_steps):
@@ -268,7 +271,7 @@ def main():
         'first_loss': first_loss, 'final_loss': final_loss,
     }
     rows = live if not args.dense else BATCH * seq
-    sec, used = probe.finish()
+    sec, used = probe.finish(stride=towers, offset=towers - 1)
     kflops = 2.0 * rows * INTER * HIDDEN
     alone = time_dominant_kernel(rows)
     out['roofline'] = dict(bound='mfma', achieved=kflops / sec / 1e12, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
