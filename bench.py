@@ -172,6 +172,8 @@ def main():
   ap.add_argument('--text-tower', choices=['synthetic', 'native'], default='synthetic',
                   help='synthetic: (B,768) text vectors stand in for the text tower (the headline workload); native: '
                        'random-init bert-base-cased on the engine, token ids in, fine-tuned with the rest (SURVEY 8f.2)')
+  ap.add_argument('--force-collectives', action='store_true',
+                  help='N=1 only: run the all-gather / all-reduce plumbing on a 1-rank RCCL group (measures its overhead)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
   args = ap.parse_args()
 
@@ -187,6 +189,10 @@ def main():
     local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
+  if world == 1 and args.force_collectives:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend == 'nccl':
@@ -212,7 +218,8 @@ def main():
     model.txt_bert.text = static['text']
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
   runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
-                            overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync])
+                            overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
+                            force_collectives=args.force_collectives)
   it = 0
   first_loss = None
   for _ in range(args.warmup):
@@ -283,7 +290,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
-  if world > 1:
+  if dist.is_initialized():
     dist.destroy_process_group()
 
 

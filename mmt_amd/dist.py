@@ -53,8 +53,8 @@ class GradSync:
     self.flat, self.other, self.group = flat, [p for p in other_params if p.requires_grad], group
     self._bucket = None
 
-  def sync(self):
-    if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+  def sync(self, force=False):
+    if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not force):
       return
     handles = []
     if self.flat is not None:

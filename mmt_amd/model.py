@@ -340,10 +340,15 @@ class CENet(nn.Module):
       self.moe_txt_dropout = nn.Dropout(txt_bert_params['hidden_dropout_prob'])
 
     # --- flat storage of everything the engine touches ---
-    named = self.vid_bert.engine_named_params('vid_bert.')
+    # Layout order = reverse of the order in which the backward finishes the gradients:
+    #   [expert projections | embeddings | layer 0 | ... | layer L-1 | text heads]
+    # so the spans that a data-parallel step reduces early (text heads + top layer) and last (layer 0 + embeddings +
+    # projections) are each ONE contiguous run (grad_regions()).
+    named = []
     for mod in self.modalities:
       named += [('video_dim_reduce.%s.fc.weight' % mod, self.video_dim_reduce[mod].fc.weight),
                 ('video_dim_reduce.%s.fc.bias' % mod, self.video_dim_reduce[mod].fc.bias)]
+    named += self.vid_bert.engine_named_params('vid_bert.')
     self._native_text_heads = txt_pro in ('gbn', 'gem')
     if self._native_text_heads:
       named += [('text_GU.%s.fc.weight' % mod, self.text_GU[mod].fc.weight) for mod in self.modalities]  # contiguous
@@ -376,20 +381,20 @@ class CENet(nn.Module):
 
   def grad_regions(self):
     """Contiguous (offset, count) spans of the flat gradient buffer in the order the backward finishes them:
-    [('text', ...), ('layer<L-1>', ...), ..., ('layer0' incl. embeddings, ...), ('reduce', ...)]."""
+    [('top', text heads + last layer), ('layer<L-2>', ...), ..., ('layer1', ...),
+     ('bottom', expert projections + embeddings + layer 0)]  (one layer: 'top' = text heads only)."""
     f, vb = self._flat, self.vid_bert
     n_layers = vb.config.num_hidden_layers
     named = vb.engine_named_params()
     per_layer = [[p for n, p in named if n.startswith('encoder.layer.%d.' % l)] for l in range(n_layers)]
     emb = [p for n, p in named if n.startswith('embeddings.')]
-    reduce_ = self._reduce_params()
-    out = []
-    if self._native_text_heads:
-      out.append(('text', f.span(self._text_head_params())))
-    for l in range(n_layers - 1, 0, -1):
+    top = list(self._text_head_params()) if self._native_text_heads else []
+    if n_layers >= 2:
+      top = per_layer[n_layers - 1] + top
+    out = [('top', f.span(top))] if top else []
+    for l in range(n_layers - 2, 0, -1):
       out.append(('layer%d' % l, f.span(per_layer[l])))
-    out.append(('layer0', f.span(emb + per_layer[0])))
-    out.append(('reduce', f.span(reduce_)))
+    out.append(('bottom', f.span(self._reduce_params() + emb + per_layer[0])))
     return out
 
   def engine_params(self):

@@ -81,14 +81,18 @@ def _copy_tree(dst, src):
 class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
-               overlap_grad_sync=None):
+               overlap_grad_sync=None, force_collectives=False):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-    self._want_stages = self.world > 1 if overlap_grad_sync is None else bool(overlap_grad_sync)
+    # measurement hook: issue the collectives even at world size 1 (a 1-rank RCCL group) to see what their stream
+    # plumbing costs on a single GPU (bench.py --force-collectives)
+    self._force_coll = bool(force_collectives) and dist.is_initialized()
+    self._multi = self.world > 1 or self._force_coll
+    self._want_stages = self._multi if overlap_grad_sync is None else bool(overlap_grad_sync)
     self.staged = False
     self.static = minibatch
     flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
@@ -119,23 +123,49 @@ class GraphedTrainStep:
   # ---- pieces ------------------------------------------------------------------------------------
   def _forward(self):
     mb = self.static
-    return self.model(mb['token_ids'], mb['features'], mb['features_t'], mb['features_ind'], mb['features_avgpool'],
-                      mb['features_maxpool'], mb['query_masks'], out='embds')
+    e = self.model(mb['token_ids'], mb['features'], mb['features_t'], mb['features_ind'], mb['features_avgpool'],
+                   mb['features_maxpool'], mb['query_masks'], out='embds')
+    self._pack_local(e)
+    return e
+
+  _send = _recv = _gkeys = None
+
+  def _pack_local(self, e):
+    """The local embeddings / weights laid out in ONE send buffer (runs inside graph A): one all-gather per step
+    instead of four -- every collective costs ~25 us of stream plumbing here, more than these transfers."""
+    if not self._multi:
+      return
+    if self._send is None:
+      self._gkeys = [(k, tuple(e[k].shape), e[k].numel()) for k in sorted(e)]
+      total = sum(n for _, _, n in self._gkeys)
+      dev = e[self._gkeys[0][0]].device
+      self._send = torch.empty(total, device=dev, dtype=torch.float32)
+      self._recv = torch.empty(self.world * total, device=dev, dtype=torch.float32)
+    off = 0
+    for k, _, n in self._gkeys:
+      self._send[off:off + n].copy_(e[k].detach().reshape(-1))
+      off += n
 
   def _gather(self, e):
-    """-> dict of LEAF tensors holding the global batch (requires_grad where the local one does)."""
-    out = {}
-    for k, v in e.items():
-      if self.world == 1:
-        g = v.detach()
-      else:
-        g = self._gbuf[k] if self._gbuf is not None else torch.empty((self.world * v.shape[0],) + v.shape[1:],
-                                                                      device=v.device, dtype=v.dtype)
-        dist.all_gather_into_tensor(g, v.detach().contiguous(), group=self.group)
-      out[k] = g
+    """-> dict of the global batch as [world, numel] strided views of the receive buffer (see _globalize)."""
+    if not self._multi:
+      return {k: v.detach() for k, v in e.items()}
+    dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+    recv, out, off = self._recv.view(self.world, -1), {}, 0
+    for k, _, n in self._gkeys:
+      out[k] = recv[:, off:off + n]
+      off += n
     return out
 
+  def _globalize(self, e, g):
+    """[world, numel] views -> contiguous global-batch tensors shaped like the local ones (copies: inside graph B)."""
+    if not self._multi:
+      return g
+    shapes = {k: shape for k, shape, _ in self._gkeys}
+    return {k: v.reshape((self.world * shapes[k][0],) + shapes[k][1:]) for k, v in g.items()}
+
   def _loss_backward(self, e, g):
+    g = self._globalize(e, g)
     fast = self._fast_loss_grads(e, g)
     if fast is not None:
       loss, outs, grads = fast
@@ -214,7 +244,7 @@ class GraphedTrainStep:
     st = {}
 
     def head():
-      fast = self._fast_loss_grads(e, g)
+      fast = self._fast_loss_grads(e, self._globalize(e, g))
       if fast is None:
         raise RuntimeError('staged backward needs one caption per video and the native losses')
       self.loss, outs, grads = fast
@@ -231,10 +261,18 @@ class GraphedTrainStep:
       st['run'](0, 0)
       model._video_tokens_backward(model._stages['plan'], st['run'].dfeat)
 
-    stages = [(head, ['text'] + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
-    for l in range(vb.config.num_hidden_layers - 1, 0, -1):
+    n_layers = vb.config.num_hidden_layers
+
+    def top():
+      head()
+      if n_layers >= 2:
+        st['run'](n_layers - 1, n_layers - 1)
+
+    names = dict(self.model.grad_regions())
+    stages = [(top, (['top'] if 'top' in names else []) + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
+    for l in range(n_layers - 2, 0, -1):
       stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
-    stages.append((bottom, ['layer0', 'reduce']))
+    stages.append((bottom, ['bottom']))
     return stages
 
   def _region_table(self):
@@ -246,7 +284,7 @@ class GraphedTrainStep:
     return tab
 
   def _reduce_async(self, names):
-    if self.world == 1:
+    if not self._multi:
       return []
     out = []
     for n in names:
@@ -269,7 +307,7 @@ class GraphedTrainStep:
 
   def _sync_all(self):
     for sy in self.syncs:
-      sy.sync()
+      sy.sync(force=self._force_coll)
 
   def set_lr(self, lr):
     """One learning rate for every optimizer of the step (the reference has a single param group, train.py:100)."""
@@ -279,7 +317,6 @@ class GraphedTrainStep:
       for g in self.opt_rest.param_groups:
         g['lr'] = lr
 
-  _gbuf = None
 
   def _eager_step(self):
     self._zero()
@@ -304,16 +341,13 @@ class GraphedTrainStep:
     self._zero()
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     e = g = pool = None
-    if self.world > 1 or self.staged:
+    if self._multi or self.staged:
       with torch.cuda.graph(ga, stream=self._stream):
         e = self._forward()
       pool = ga.pool()
-      if self.world > 1:
-        self._gbuf = {k: torch.empty((self.world * v.shape[0],) + v.shape[1:], device=v.device, dtype=v.dtype)
-                      for k, v in e.items()}
       with torch.cuda.stream(self._stream):
         g = self._gather(e)
-    if self.world == 1 and not self.staged:
+    if not self._multi and not self.staged:
       # nothing happens between forward and backward on one rank: one graph for both (one launch gap less per step)
       ga = torch.cuda.CUDAGraph()
       with torch.cuda.graph(ga, stream=self._stream):
@@ -357,7 +391,7 @@ class GraphedTrainStep:
       o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     ga, gb, gc = self._graphs
     ga.replay()
-    if self.world > 1:
+    if self._multi:
       self._gather(self._e)
     if gb is None:
       pass  # forward + backward were captured as one graph
