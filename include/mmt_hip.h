@@ -84,6 +84,15 @@ int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, v
 int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                           int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide, const int32_t* n_rows_dev,
                           int no_epilogue, void* stream);
+/* NN operand form: C[M,N] = A[M,K] . B[K,N] with B row-major [K, N] -- a weight W[out, in] as stored, used for the
+ * input gradient dX = dY . W (autograd of every nn.Linear of model/bert.py:146-150,186,218,234) without a transposed
+ * copy: the tile is staged as it lies and the MFMA fragments come from ds_read_b64_tr_b16.  Epilogues: MMT_EPI_BF16,
+ * MMT_EPI_F32, MMT_EPI_ADD_F32, MMT_EPI_DGELU (no colsum).  Same alignment rules as mmt_gemm_nt_bf16; N % 64 == 0. */
+int mmt_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                     int epilogue, const MmtEpilogue* epi, const int32_t* n_rows_dev, void* stream);
+int mmt_gemm_nn_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                          int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide, const int32_t* n_rows_dev,
+                          int no_epilogue, void* stream);
 
 /* Several independent C_i[M_i,N_i] = A_i . B_i^T (+ bias_i) in ONE launch (epilogue MMT_EPI_BIAS_F32 / MMT_EPI_F32):
  * the per-expert ReduceDim.fc projections of model/model.py:426-437 (seven GEMMs with different K). */

@@ -106,6 +106,10 @@ SIGNATURES = {
     'mmt_gemm_nt_splitk_workspace_floats': (c_i64, [c_int, c_int, c_int]),
     'mmt_gemm_nt_splitk': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                    ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
+    'mmt_gemm_nn_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
+                                 ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
+    'mmt_gemm_nn_splitk_ex': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
+                                      ctypes.POINTER(MmtEpilogue), c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_gemm_nt_splitk_ex': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                       ctypes.POINTER(MmtEpilogue), c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_gemm_nt_grouped': (c_int, [ctypes.POINTER(MmtGemmItem), c_int, c_int, c_vp]),

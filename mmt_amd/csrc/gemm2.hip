@@ -58,12 +58,48 @@ __device__ __forceinline__ void stage2(const bf16_t* __restrict__ G, int64_t ld,
   }
 }
 
+// ---- "NN" operand form: B given as [K, N] row-major (a weight matrix W[out, in] used for the input gradient
+// dX = dY . W: the contraction index is W's ROW).  The tile is staged as it lies in memory, [BK rows][BN columns], and
+// the MFMA fragments (8 contraction values per output column) come from the hardware transpose read
+// ds_read_b64_tr_b16 -- no W^T copy in HBM, no transposing pack kernel.
+template <int BN> __device__ __forceinline__ int swz_kn(int r) {
+  return BN == 128 ? (((r & 7) << 1) | ((r >> 3) & 1)) : ((r >> 1) & 7);  // 16 / 8 chunks of 16 B per tile row
+}
+template <int BN, int NW>
+__device__ __forceinline__ void stage2_kn(const bf16_t* __restrict__ G, int64_t ld, int k0, int n0, bf16_t* lds_tile,
+                                          int wave, int lane) {
+  constexpr int CHN = BN / 8, RPI = 64 / CHN, PER = CHN / NW;  // chunks per row, rows per wave-instruction
+  static_assert(CHN % NW == 0, "stage2_kn geometry");
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int rbase = (wave * PER + i) * RPI;
+    const int r = rbase + lane / CHN;
+    const int c = (lane % CHN) ^ swz_kn<BN>(r);
+    const bf16_t* src = G + (int64_t)(k0 + r) * ld + n0 + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + rbase * BN), 16, 0, 0);
+  }
+}
+// fragment of mfma_f32_32x32x16: lane (column colbase + (lane & 31), half lh = lane >> 5) gets the contraction rows
+// kk*16 + lh*8 + 0..7 in natural order (two 4-row transpose reads), matching the A fragment's k order.
+template <int BN>
+__device__ __forceinline__ bf16x8_t frag_kn(const bf16_t* tile, int kk, int colbase, int lane) {
+  const int t = lane & 15;
+  const int col = colbase + ((lane >> 4) & 1) * 16 + 4 * (t & 3);
+  const int r0 = kk * 16 + (lane >> 5) * 8 + (t >> 2), r1 = r0 + 4;
+  const int ch = col >> 3, w = col & 7;
+  const bf16_t* p0 = tile + r0 * BN + ((ch ^ swz_kn<BN>(r0)) << 3) + w;
+  const bf16_t* p1 = tile + r1 * BN + ((ch ^ swz_kn<BN>(r1)) << 3) + w;
+  bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p0));
+  bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)LDS_PTR(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
 __device__ __forceinline__ void gemm2_body(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, const MmtEpilogue& epi,
@@ -123,7 +159,8 @@ __device__ __forceinline__ void gemm2_body(
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < KT) {
       stage2<BM, NW>(A, lda, m0, amax, s0 * BK, smem + s0 * STAGE, wave, lane);
-      stage2<BN, NW>(B, ldb, n0, bmax, s0 * BK, smem + s0 * STAGE + BM * BK, wave, lane);
+      if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, s0 * BK, n0, smem + s0 * STAGE + BM * BK, wave, lane);
+      else stage2<BN, NW>(B, ldb, n0, bmax, s0 * BK, smem + s0 * STAGE + BM * BK, wave, lane);
     }
   // per-lane LDS offsets of this wave's fragments (row r, 16-byte chunk c lives at chunk c ^ ((r>>1)&7))
   int aoff[MI], boff[NJ], asw[MI], bsw[NJ];
@@ -158,7 +195,8 @@ __device__ __forceinline__ void gemm2_body(
     const bool do_issue = kt + NS - 1 < KT;
     if (do_issue && !late_issue) {
       stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
-      stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
+      if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, (kt + NS - 1) * BK, n0, smem + nxt * STAGE + BM * BK, wave, lane);
+      else stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
     TICK(t_issue);
     const bf16_t* st = smem + cur * STAGE;
@@ -167,7 +205,10 @@ __device__ __forceinline__ void gemm2_body(
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[0][i] = *(const bf16x8_t*)(st + aoff[i] + ((lh ^ asw[i]) << 3));
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bfr[0][j] = *(const bf16x8_t*)(st + boff[j] + ((lh ^ bsw[j]) << 3));
+    for (int j = 0; j < NJ; ++j) {
+      if constexpr (BKN) bfr[0][j] = frag_kn<BN>(st + BM * BK, 0, wn * WTN + j * 32, lane);
+      else bfr[0][j] = *(const bf16x8_t*)(st + boff[j] + ((lh ^ bsw[j]) << 3));
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) {
@@ -175,7 +216,10 @@ __device__ __forceinline__ void gemm2_body(
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[(kk + 1) & 1][i] = *(const bf16x8_t*)(st + aoff[i] + ((c ^ asw[i]) << 3));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bfr[(kk + 1) & 1][j] = *(const bf16x8_t*)(st + boff[j] + ((c ^ bsw[j]) << 3));
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (BKN) bfr[(kk + 1) & 1][j] = frag_kn<BN>(st + BM * BK, kk + 1, wn * WTN + j * 32, lane);
+          else bfr[(kk + 1) & 1][j] = *(const bf16x8_t*)(st + boff[j] + ((c ^ bsw[j]) << 3));
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -185,7 +229,8 @@ __device__ __forceinline__ void gemm2_body(
     }
     if (do_issue && late_issue) {
       stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
-      stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
+      if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, (kt + NS - 1) * BK, n0, smem + nxt * STAGE + BM * BK, wave, lane);
+      else stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
 #ifdef MMT_GEMM2_INSTR
@@ -297,19 +342,19 @@ __device__ __forceinline__ void gemm2_body(
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
     const int32_t* __restrict__ n_rows_dev) {
-  gemm2_body<BM, BN, WGM, WGN, NS, EPI>(A, lda, B, ldb, Cout, ldc, M, N, K, epi, n_rows_dev, (int)blockIdx.x,
-                                        (int)gridDim.x);
+  gemm2_body<BM, BN, WGM, WGN, NS, EPI, BKN>(A, lda, B, ldb, Cout, ldc, M, N, K, epi, n_rows_dev, (int)blockIdx.x,
+                                             (int)gridDim.x);
 }
 
 // Split-K for skinny problems (few output tiles, long K: the last layer's read-out rows): blockIdx.y = K-slice, every
 // slice writes a raw fp32 partial tile into its own slab; splitk_epilogue_kernel sums the slabs in a fixed order and
 // applies the epilogue.  A 16-tile x 48-K-step GEMM is otherwise one 40 us chain of dependent K-steps.
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool BKN = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ ws,
     int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk, const int32_t* __restrict__ n_rows_dev) {
@@ -317,8 +362,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
   const int kb = z * kchunk;
   const int kl = min(kchunk, K - kb);
   MmtEpilogue e = {};
-  gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32>(A + kb, lda, B + kb, ldb, ws + (int64_t)z * slab_stride, ldws, M, N, kl, e,
-                                                 n_rows_dev, (int)blockIdx.x, (int)gridDim.x);
+  gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32, BKN>(A + kb, lda, BKN ? B + (int64_t)kb * ldb : B + kb, ldb,
+                                                      ws + (int64_t)z * slab_stride, ldws, M, N, kl, e, n_rows_dev,
+                                                      (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int EPI>
@@ -366,18 +412,18 @@ extern "C" int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K) {
   return (int64_t)(splits < 1 ? 1 : splits) * ((M + 127) / 128 * 128) * N;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool BKN = false>
 static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* ws, int64_t slab, int M, int Mpad,
                          int N, int K, int splits, int per, const int32_t* nr, hipStream_t s) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   static bool configured = false;
   if (!configured) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>,
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
-  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS>), dim3((Mpad / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
+  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3((Mpad / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
                      lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr);
   return 0;
 }
@@ -387,9 +433,9 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
 // splits <= 0: as many as there are K-steps, at most 16 (skinny problems).  wide: 128x128 tiles (N % 128 == 0) instead of
 // 128x64.  n_rows_dev (nullable): device count of live rows (token packing).  no_epilogue: leave the partial slabs for a
 // consumer that sums them itself (mmt_ln_fwd / mmt_ln_bwd with a slab source); C and epi are then unused.
-extern "C" int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
-                                     int N, int K, int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide,
-                                     const int32_t* n_rows_dev, int no_epilogue, void* stream) {
+static int splitk_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide, const int32_t* n_rows_dev,
+                       int no_epilogue, bool b_kn, void* stream) {
   if (!A || !B || (!C && !no_epilogue) || !ws || M <= 0 || N <= 0 || K <= 0 || K % BK || N % 64 || (wide && N % 128))
     return MMT_ERR_ARG;
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
@@ -405,10 +451,14 @@ extern "C" int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, 
   const int Mpad = (M + 127) / 128 * 128;
   const int64_t slab = (int64_t)Mpad * N;
   hipStream_t s = (hipStream_t)stream;
-  int rc = wide ? launch_splitk<128, 128, 2, 4, 2>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, M, Mpad, N, K, splits,
-                                                   per, n_rows_dev, s)
-                : launch_splitk<128, 64, 4, 2, 3>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, ws, slab, M, Mpad, N, K, splits,
-                                                  per, n_rows_dev, s);
+  const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)B;
+  int rc;
+  if (b_kn)
+    rc = wide ? launch_splitk<128, 128, 2, 4, 2, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
+              : launch_splitk<128, 64, 4, 2, 3, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
+  else
+    rc = wide ? launch_splitk<128, 128, 2, 4, 2>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
+              : launch_splitk<128, 64, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
   if (rc) return rc;
   if (no_epilogue) return (int)hipGetLastError();
   const int64_t items = (int64_t)M * (N / 4);
@@ -424,6 +474,18 @@ extern "C" int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, 
   }
 #undef SK_EPI
   return (int)hipGetLastError();
+}
+
+extern "C" int mmt_gemm_nt_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
+                                     int N, int K, int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide,
+                                     const int32_t* n_rows_dev, int no_epilogue, void* stream) {
+  return splitk_impl(A, lda, B, ldb, C, ldc, M, N, K, epilogue, epi, ws, splits, wide, n_rows_dev, no_epilogue, false, stream);
+}
+// the same with B given as [K, N] row-major (see mmt_gemm_nn_bf16)
+extern "C" int mmt_gemm_nn_splitk_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
+                                     int N, int K, int epilogue, const MmtEpilogue* epi, float* ws, int splits, int wide,
+                                     const int32_t* n_rows_dev, int no_epilogue, void* stream) {
+  return splitk_impl(A, lda, B, ldb, C, ldc, M, N, K, epilogue, epi, ws, splits, wide, n_rows_dev, no_epilogue, true, stream);
 }
 
 extern "C" int mmt_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
@@ -486,7 +548,7 @@ extern "C" int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
 static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
@@ -499,13 +561,13 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static bool configured = false;
   if (!configured) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, NS, EPI>,
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
   const int grid = ((M + BM - 1) / BM) * (N / BN);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
@@ -543,6 +605,40 @@ int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const
     case MMT_EPI_ADD_F32: return pick2<MMT_EPI_ADD_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     case MMT_EPI_F32: return pick2<MMT_EPI_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     case MMT_EPI_BIAS_F32: return pick2<MMT_EPI_BIAS_F32>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
+  return MMT_ERR_ARG;
+}
+
+// ---- NN form: C[M,N] = A[M,K] . B[K,N]  (B row-major [K, N]: a weight matrix W[out = K, in = N] as stored) ----------
+// The input-gradient GEMMs of every nn.Linear on the path (dX = dY . W; reference autograd of model/bert.py:146-150,
+// 186, 218, 234) without a transposed weight copy.  Epilogues: BF16, F32, ADD_F32, DGELU.  Tiles as the NT form:
+// 128x128 / 8 waves for wide outputs, 128x64 / 8 staggered waves otherwise and for short batches.
+template <int EPI>
+static int pick_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  const int forced = e.reserved & 0xff;
+  const bool wide = forced ? forced == 14 : (M > 1024 && N >= 1024 && N % 128 == 0);
+  if (wide) return launch2<128, 128, 2, 4, 2, EPI, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  return launch2<128, 64, 4, 2, 3, EPI, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+}
+
+extern "C" int mmt_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                                int K, int epilogue, const MmtEpilogue* epi, const int32_t* n_rows_dev, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || K % BK || N % 64) return MMT_ERR_ARG;
+  if ((lda % 8) || (ldb % 8) || (ldc % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15))
+    return MMT_ERR_ALIGN;
+  MmtEpilogue e = {};
+  if (epi) e = *epi;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case MMT_EPI_BF16: return pick_nn<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_F32: return pick_nn<MMT_EPI_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_ADD_F32:
+      if (!e.res) return MMT_ERR_ARG;
+      return pick_nn<MMT_EPI_ADD_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_DGELU:
+      if (!e.aux || e.colsum) return MMT_ERR_ARG;
+      return pick_nn<MMT_EPI_DGELU>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
   }
   return MMT_ERR_ARG;
 }

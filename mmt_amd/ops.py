@@ -63,6 +63,23 @@ def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, 
   return out
 
 
+def gemm_nn(a, w, out, epilogue='BF16', m=None, res=None, aux=None, n_rows_dev=None, tile=0):
+  """out[M,N] = a[M,K] @ w[K,N] (w row-major [K, N]: a weight [out, in] as stored -> input gradient), fused epilogue
+  BF16 / F32 / ADD_F32 / DGELU."""
+  _need_cuda(a, w, out)
+  M = a.shape[0] if m is None else m
+  K, N = w.shape
+  e = MmtEpilogue()
+  e.res = res.data_ptr() if res is not None else None
+  e.ldres = res.stride(0) if res is not None else 0
+  e.aux = aux.data_ptr() if aux is not None else None
+  e.ldaux = aux.stride(0) if aux is not None else 0
+  e.reserved = tile
+  check(_lib.lib().mmt_gemm_nn_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                                    EPI[epilogue], ctypes.byref(e), _p(n_rows_dev), _stream()), 'mmt_gemm_nn_bf16')
+  return out
+
+
 def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=None):
   """out[N,K2] (+)= a[rows,N]^T @ b[rows,K2]  (fp32 result; split over rows, deterministic reduce)."""
   _need_cuda(a, b)
@@ -80,11 +97,11 @@ def gemm_tn(a, b, rows=None, splits=4, out=None, accumulate=False, n_rows_dev=No
 
 
 def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_index=None, drop_key=0, drop_p=0.0,
-                   seed_dev=None, splits=0, wide=False, n_rows_dev=None, no_epilogue=False, ws=None):
-  """Split-K variant of gemm_nt for skinny problems (few rows, long K)."""
+                   seed_dev=None, splits=0, wide=False, n_rows_dev=None, no_epilogue=False, ws=None, b_kn=False):
+  """Split-K variant of gemm_nt for skinny problems (few rows, long K).  b_kn: b is [K, N] row-major (gemm_nn)."""
   _need_cuda(a, b, out)
   M = a.shape[0] if m is None else m
-  N, K = b.shape
+  N, K = (b.shape[1], b.shape[0]) if b_kn else b.shape
   e = MmtEpilogue()
   e.bias = bias.data_ptr() if bias is not None else None
   e.res = res.data_ptr() if res is not None else None
@@ -96,7 +113,8 @@ def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_i
   L = _lib.lib()
   if ws is None:
     ws = torch.empty(L.mmt_gemm_nt_splitk_workspace_floats(M, N, K), device=a.device, dtype=torch.float32)
-  check(L.mmt_gemm_nt_splitk_ex(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, EPI[epilogue],
+  fn = L.mmt_gemm_nn_splitk_ex if b_kn else L.mmt_gemm_nt_splitk_ex
+  check(fn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, EPI[epilogue],
                                 ctypes.byref(e), _p(ws), int(splits), int(wide),
                                 _p(n_rows_dev) if n_rows_dev is not None else None, int(no_epilogue), _stream()),
         'mmt_gemm_nt_splitk_ex')

@@ -437,3 +437,37 @@ def test_wgrad_grouped_item_splits_and_row_override():
   _close('split bias', bias0, a0[:live].float().sum(0), 2e-3, 1e-5)
   _close('row-override item', out1, a1[:200].float().t() @ b1[:200].float(), 4e-3, 2e-4)
   _close('row-override bias', bias1, a1[:200].float().sum(0), 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize('M,N,K,tile', [(300, 512, 1536, 0), (777, 3072, 512, 14), (777, 3072, 512, 13), (1500, 1536, 768, 0),
+                                        (130, 768, 2304, 0), (1100, 512, 3072, 0)])
+def test_gemm_nn_input_gradient_form(M, N, K, tile):
+  """C = A . W with W row-major [K, N] (a weight as stored, no transposed copy): every epilogue the backward uses."""
+  from mmt_amd import ops
+  R = ops.pad_rows(M)
+  a = _rand((R, K), seed=140, dtype=torch.bfloat16)
+  w = _rand((K, N), 0.05, seed=141, dtype=torch.bfloat16)
+  ref = a[:M].float() @ w.float()
+  out16 = torch.zeros(R, N, device=_dev(), dtype=torch.bfloat16)
+  ops.gemm_nn(a, w, out16, 'BF16', m=M, tile=tile)
+  _close('nn.bf16', out16[:M].float(), ref, 2e-2, 2e-2)
+  out32 = torch.zeros(R, N, device=_dev())
+  ops.gemm_nn(a, w, out32, 'F32', m=M, tile=tile)
+  _close('nn.f32', out32[:M], ref, 2e-3, 2e-3)
+  res = _rand((R, N), seed=142)
+  ops.gemm_nn(a, w, out32, 'ADD_F32', m=M, res=res, tile=tile)
+  _close('nn.add', out32[:M], ref + res[:M], 2e-3, 2e-3)
+  aux = _rand((R, N), seed=143, dtype=torch.bfloat16)
+  ops.gemm_nn(a, w, out16, 'DGELU', m=M, aux=aux, tile=tile)
+  x = aux[:M].float().requires_grad_(True)
+  (x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))).sum().backward()
+  _close('nn.dgelu', out16[:M].float(), ref * x.grad, 3e-2, 3e-2)
+  # live-row count on the device (token packing): rows past it are left untouched
+  nr = torch.tensor([M // 2], device=_dev(), dtype=torch.int32)
+  out32.fill_(7.0)
+  ops.gemm_nn(a, w, out32, 'F32', m=M, n_rows_dev=nr, tile=tile)
+  _close('nn.live', out32[:M // 2], ref[:M // 2], 2e-3, 2e-3)
+  assert (out32[(M // 2 + 127) // 128 * 128:M] == 7.0).all()
+  # split-K variant
+  ops.gemm_nt_splitk(a, w, out32, 'ADD_F32', m=M, res=res, splits=3, b_kn=True)
+  _close('nn.splitk', out32[:M], ref + res[:M], 2e-3, 2e-3)
