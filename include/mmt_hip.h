@@ -292,10 +292,12 @@ int mmt_readout_fwd(const float* last_hidden, const int32_t* agg_row, int BM, in
 int mmt_readout_bwd(const float* vid_embds, const float* inv_norm, const float* dvid_embds,
                     const int32_t* agg_row, int BM, int d, float* dlast_hidden, void* stream);
 /* sharded_cross_view_inner_product, model.py:789-837: txt [NT,M,d], vid [NV,M,d], tw [NT,M], vw [NV,M]
- * -> sims [NT,NV] (rows = text); dots [NT,NV,M] is saved for backward. */
+ * -> sims [NT,NV] (rows = text); dots = NT*NV*M floats saved for the backward (its layout is private to the pair of
+ * calls; mmt_sims_bwd OVERWRITES it).  From 64 rows/columns on (the global batch of a data-parallel step) the per-expert
+ * dot products and both embedding gradients run as batched exact-fp32 MFMA GEMMs. */
 int mmt_sims_fwd(const float* txt, const float* vid, const float* tw, const float* vw, int NT, int NV, int M,
                  int d, float* sims, float* dots, void* stream);
-int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, const float* dots,
+int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, float* dots,
                  const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
                  float* dvw, void* stream);
 /* MaxMarginRankingLoss.forward (loss.py:38-65): loss scalar + d loss/d sims; partial = n floats scratch. */

@@ -130,6 +130,105 @@ __global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- similarity for larger batches (the GLOBAL batch of a data-parallel step: n = 32 * ranks) -----------------------
+// The row-per-block kernels above do n*M*d multiply-adds per block on the vector ALU: fine at n = 32 (7 us), 88 us
+// forward and 515 us backward at n = 256.  From LARGE_N on the expert dot products run on the exact-fp32 matrix cores
+// instead (mmt_sgemm_batched, one GEMM per expert): dots laid out [M][NT][NV], and in the backward the coefficient
+// matrices H_m = dsims * w_m (written over the dots) feed two more batched GEMMs for dtxt / dvid.
+#define LARGE_N 64
+// sims[t][v] = sum_m w_m dots_m,  w_m = tw[t][m] vw[v][m] / nrm  (nrm == 0 -> 1e-5, model.py:816)
+__global__ __launch_bounds__(256) void sims_combine_kernel(const float* __restrict__ dots, const float* __restrict__ tw,
+                                                           const float* __restrict__ vw, int NT, int NV, int M,
+                                                           float* __restrict__ sims) {
+  const int t = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= NV) return;
+  const int64_t plane = (int64_t)NT * NV, at = (int64_t)t * NV + v;
+  float nrm = 0.f;
+  for (int m = 0; m < M; ++m) nrm += tw[t * M + m] * vw[v * M + m];
+  if (nrm == 0.f) nrm = 1e-5f;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += tw[t * M + m] * vw[v * M + m] / nrm * dots[m * plane + at];
+  sims[at] = s;
+}
+
+// da_m[t][v] = d loss / d (tw[t][m] vw[v][m])  (see sims_bwd_kernel); MODE 0: block per video v -> dvw[v][m] (reads only);
+// MODE 1: block per text t -> dtw[t][m], then dots_m[t][v] <- H_m = dsims * w_m in place.
+template <int MODE>
+__global__ __launch_bounds__(256) void sims_weights_bwd_kernel(float* __restrict__ dots, const float* __restrict__ dsims,
+                                                               const float* __restrict__ tw, const float* __restrict__ vw,
+                                                               int NT, int NV, int M, float* __restrict__ dw) {
+  __shared__ float red[4][MAXM];
+  const int self = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NO = MODE == 1 ? NV : NT;
+  const int64_t plane = (int64_t)NT * NV;
+  float acc[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+  for (int o = threadIdx.x; o < NO; o += 256) {
+    const int t = MODE == 1 ? self : o, v = MODE == 1 ? o : self;
+    const int64_t at = (int64_t)t * NV + v;
+    const float g = dsims[at];
+    float a[MAXM], dm[MAXM];
+    float nrm = 0.f, gw = 0.f;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m)
+      if (m < M) { a[m] = tw[t * M + m] * vw[v * M + m]; dm[m] = dots[m * plane + at]; nrm += a[m]; }
+    const bool zero = nrm == 0.f;
+    if (zero) nrm = 1e-5f;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m)
+      if (m < M) gw += g * dm[m] * a[m] / nrm;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m)
+      if (m < M) {
+        const float da = zero ? g * dm[m] / nrm : (g * dm[m] - gw) / nrm;
+        acc[m] += da * (MODE == 1 ? vw[v * M + m] : tw[t * M + m]);
+        if (MODE == 1) dots[m * plane + at] = g * a[m] / nrm;  // H_m
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    const float r = wave_sum(acc[m]);
+    if (lane == 0) red[wave][m] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < M) dw[self * M + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                    red[3][threadIdx.x];
+}
+
+static int sims_fwd_large(const float* txt, const float* vid, const float* tw, const float* vw, int NT, int NV, int M, int d,
+                          float* sims, float* dots, void* stream) {
+  MmtSgemm g = {};
+  g.batch = M; g.M = NT; g.N = NV; g.K = d;
+  g.sai = (int64_t)M * d; g.sak = 1; g.sbj = (int64_t)M * d; g.sbk = 1; g.ldc = NV;
+  for (int m = 0; m < M; ++m) { g.A[m] = txt + (int64_t)m * d; g.B[m] = vid + (int64_t)m * d; g.C[m] = dots + (int64_t)m * NT * NV; }
+  int rc = mmt_sgemm_batched(&g, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sims_combine_kernel, dim3((NV + 255) / 256, NT), dim3(256), 0, (hipStream_t)stream, dots, tw, vw, NT, NV,
+                     M, sims);
+  return (int)hipGetLastError();
+}
+
+static int sims_bwd_large(const float* txt, const float* vid, const float* tw, const float* vw, float* dots,
+                          const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
+                          float* dvw, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sims_weights_bwd_kernel<0>, dim3(NV), dim3(256), 0, s, dots, dsims, tw, vw, NT, NV, M, dvw);
+  hipLaunchKernelGGL(sims_weights_bwd_kernel<1>, dim3(NT), dim3(256), 0, s, dots, dsims, tw, vw, NT, NV, M, dtw);
+  const int64_t plane = (int64_t)NT * NV;
+  MmtSgemm g = {};  // dtxt[t][m][:] = sum_v H_m[t][v] vid[v][m][:]
+  g.batch = M; g.M = NT; g.N = d; g.K = NV;
+  g.sai = NV; g.sak = 1; g.sbj = 1; g.sbk = (int64_t)M * d; g.ldc = (int64_t)M * d;
+  for (int m = 0; m < M; ++m) { g.A[m] = dots + m * plane; g.B[m] = vid + (int64_t)m * d; g.C[m] = dtxt + (int64_t)m * d; }
+  int rc = mmt_sgemm_batched(&g, stream);
+  if (rc) return rc;
+  g = {};           // dvid[v][m][:] = sum_t H_m[t][v] txt[t][m][:]
+  g.batch = M; g.M = NV; g.N = d; g.K = NT;
+  g.sai = 1; g.sak = NV; g.sbj = 1; g.sbk = (int64_t)M * d; g.ldc = (int64_t)M * d;
+  for (int m = 0; m < M; ++m) { g.A[m] = dots + m * plane; g.B[m] = txt + (int64_t)m * d; g.C[m] = dvid + (int64_t)m * d; }
+  return mmt_sgemm_batched(&g, stream);
+}
+
 // ---- losses ------------------------------------------------------------------------------------------
 // Block k handles diagonal index k: row k (first hinge direction) and column k (second direction).
 // partial[k] = sum_{c!=k} relu(m - s_kk + s_kc) + sum_{r!=k} relu(m - s_kk + s_rk)   (fix_norm: off-diagonal only)
@@ -232,6 +331,7 @@ extern "C" int mmt_sims_fwd(const float* txt, const float* vid, const float* tw,
                             int d, float* sims, float* dots, void* stream) {
   if (!txt || !vid || !tw || !vw || !sims || !dots || NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024)
     return MMT_ERR_ARG;
+  if (NT >= LARGE_N || NV >= LARGE_N) return sims_fwd_large(txt, vid, tw, vw, NT, NV, M, d, sims, dots, stream);
   const size_t lds = (size_t)M * d * sizeof(float);
   if (lds > 64 * 1024) return MMT_ERR_ARG;
   int gy = (NV + 3) / 4;
@@ -241,11 +341,13 @@ extern "C" int mmt_sims_fwd(const float* txt, const float* vid, const float* tw,
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, const float* dots,
+extern "C" int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, float* dots,
                             const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
                             float* dvw, void* stream) {
   if (!txt || !vid || !tw || !vw || !dots || !dsims || !dtxt || !dvid || !dtw || !dvw) return MMT_ERR_ARG;
   if (NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024) return MMT_ERR_ARG;
+  if (NT >= LARGE_N || NV >= LARGE_N)
+    return sims_bwd_large(txt, vid, tw, vw, dots, dsims, NT, NV, M, d, dtxt, dvid, dtw, dvw, stream);
   hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
                      NV, M, d, 0, dtxt, dtw);
   hipLaunchKernelGGL(sims_bwd_kernel, dim3(NV, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,

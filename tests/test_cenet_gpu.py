@@ -325,3 +325,39 @@ def test_row_sharded_similarity_and_maxmargin(world):
     l2.backward()
     assert abs(l2.item() - loss.item()) < 1e-6
     assert (lv[0].grad.cpu() - dvid).abs().max() < 1e-6 and (lv[2].grad.cpu() - dtw).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize('nv,c', [(96, 1), (256, 1), (70, 2), (33, 3)])
+def test_similarity_large_batch_gemm_path(nv, c):
+  """From 64 rows / columns on (the global batch of a multi-rank step; B*C captions at eval) the similarity runs as
+  batched fp32 MFMA GEMMs: forward and every gradient against the einsum form of model/model.py:789-837 (incl. an
+  all-zero weight row, :816; text row = b*C + cap, :805,822)."""
+  from mmt_amd.model import cross_view_similarity
+  m, d = 7, 512
+  nt = nv * c
+  g = torch.Generator().manual_seed(5)
+  vid = torch.nn.functional.normalize(torch.randn(nv, m, d, generator=g), dim=-1)
+  txt = torch.nn.functional.normalize(torch.randn(nv, m, c, d, generator=g), dim=-1)
+  vw = torch.rand(nv, m, generator=g)
+  tw = torch.softmax(torch.randn(nv, c, m, generator=g), -1)
+  vw[3] = 0.0
+  gout = torch.randn(nt, nv, generator=g)
+
+  def ref(vid, txt, vw, tw):
+    t = txt.permute(0, 2, 1, 3).reshape(nt, m, d)
+    a = tw.reshape(nt, m)[:, :, None] * vw.t()[None]          # [nt, m, nv]
+    nrm = a.sum(1, keepdim=True)
+    nrm = torch.where(nrm == 0, torch.full_like(nrm, 1e-5), nrm)
+    return (a / nrm * torch.einsum('tmd,vmd->tmv', t, vid)).sum(1)
+
+  leaves = [x.clone().double().requires_grad_(True) for x in (vid, txt, vw, tw)]
+  want = ref(*leaves)
+  want.backward(gout.double())
+  dev = [x.clone().to(DEV).requires_grad_(True) for x in (vid, txt, vw, tw)]
+  got = cross_view_similarity(dev[0], dev[1], dev[2], dev[3], 'indep')
+  assert tuple(got.shape) == (nt, nv)
+  assert (got.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5
+  got.backward(gout.to(DEV))
+  for a, b, nm in zip(dev, leaves, ('vid', 'txt', 'vw', 'tw')):
+    err = (a.grad.detach().cpu().double() - b.grad).abs().max().item()
+    assert err < 1e-4 * max(1.0, b.grad.abs().max().item()), (nm, err)
