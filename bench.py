@@ -134,7 +134,7 @@ def pmc_traffic(kernel_sub='gemm2_kernel<128, 128, 2, 4, 2, 2>', grid_sub='[grid
   return None
 
 
-def cpu_baseline(steps=2):
+def cpu_baseline(steps=6):
   """The CPU oracle ('port' of the reference path, pinned to it by tests/golden) on this box's host cores:
   fwd+bwd of config B, train mode semantics without dropout RNG (cheaper than the reference), fp32."""
   import copy
