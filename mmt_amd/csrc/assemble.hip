@@ -23,13 +23,30 @@ __device__ __forceinline__ void decode_slot(int s, int T, int& expert, int& j) {
 
 // grid = B blocks of 256 threads.  Phase 0 (counts) / phase 1 (fill, after cu has been scanned).
 __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M, int T, int S, int pack, int max_pos,
-                                                   int phase, int32_t* __restrict__ counts, const int32_t* __restrict__ cu,
-                                                   int32_t* __restrict__ slot, int32_t* __restrict__ row_index,
+                                                   int phase, int32_t* __restrict__ counts, int32_t* __restrict__ cu,
+                                                   int32_t* __restrict__ n_rows, int32_t* __restrict__ slot, int32_t* __restrict__ row_index,
                                                    int32_t* __restrict__ type_ids, int32_t* __restrict__ pos_ids,
                                                    float* __restrict__ mask_bias, int32_t* __restrict__ agg_row) {
   __shared__ int scan[256];
   __shared__ int carry;
   const int b = blockIdx.x, tid = threadIdx.x;
+  int base = 0;
+  if (phase == 1) {  // exclusive prefix of the per-sample counts (phase 0), computed by the block itself: no scan launch
+    int part = 0;
+    for (int i = tid; i < b; i += 256) part += counts[i];
+    scan[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) scan[tid] += scan[tid + o];
+      __syncthreads();
+    }
+    base = scan[0];
+    __syncthreads();
+    if (tid == 0) {
+      cu[b] = base;
+      if (b == B - 1) { cu[B] = base + counts[b]; *n_rows = base + counts[b]; }
+    }
+  }
   if (tid == 0) carry = 0;
   __syncthreads();
   for (int s0 = 0; s0 < S; s0 += 256) {
@@ -54,7 +71,7 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
     }
     const int before = carry + scan[tid] - live;
     if (phase == 1 && s < S) {
-      const int row = live ? cu[b] + before : -1;
+      const int row = live ? base + before : -1;
       slot[(int64_t)b * S + s] = row;
       if (live) {
         row_index[row] = b * S + s;
@@ -268,11 +285,10 @@ extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, i
     return MMT_ERR_ARG;
   const int S = 1 + M * (T + 1);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, s, tab, B, M, T, S, pack, max_pos, 0, counts, nullptr,
+  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, s, tab, B, M, T, S, pack, max_pos, 0, counts, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(64), 0, s, counts, B, cu_seqlens, n_rows_dev);
   hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, s, tab, B, M, T, S, pack, max_pos, 1, counts, cu_seqlens,
-                     slot, row_index, type_ids, pos_ids, mask_bias, agg_row);
+                     n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row);
   return (int)hipGetLastError();
 }
 

@@ -83,11 +83,16 @@ __global__ __launch_bounds__(256) void sims_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
                                                        const float* __restrict__ tw, const float* __restrict__ vw,
                                                        const float* __restrict__ dots, const float* __restrict__ dsims,
-                                                       int NT, int NV, int M, int d, int side, float* __restrict__ dx,
-                                                       float* __restrict__ dwt) {
+                                                       int NT, int NV, int M, int d, float* __restrict__ dtxt,
+                                                       float* __restrict__ dtw, float* __restrict__ dvid,
+                                                       float* __restrict__ dvw) {
   __shared__ __attribute__((aligned(16))) float racc[4][1024];
   __shared__ float rw[4];
+  const int side = blockIdx.z;  // both sides in ONE launch
   const int self = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (self >= (side == 0 ? NT : NV)) return;
+  float* __restrict__ dx = side == 0 ? dtxt : dvid;
+  float* __restrict__ dwt = side == 0 ? dtw : dvw;
   const int NO = side == 0 ? NV : NT;  // the other side's count
   const float* other = side == 0 ? vid : txt;
   const float* wother = side == 0 ? vw : tw;
@@ -348,10 +353,8 @@ extern "C" int mmt_sims_bwd(const float* txt, const float* vid, const float* tw,
   if (NT <= 0 || NV <= 0 || M <= 0 || M > MAXM || d % 4 || d > 1024) return MMT_ERR_ARG;
   if (NT >= LARGE_N || NV >= LARGE_N)
     return sims_bwd_large(txt, vid, tw, vw, dots, dsims, NT, NV, M, d, dtxt, dvid, dtw, dvw, stream);
-  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
-                     NV, M, d, 0, dtxt, dtw);
-  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NV, M), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots, dsims, NT,
-                     NV, M, d, 1, dvid, dvw);
+  hipLaunchKernelGGL(sims_bwd_kernel, dim3(NT > NV ? NT : NV, M, 2), dim3(256), 0, (hipStream_t)stream, txt, vid, tw, vw, dots,
+                     dsims, NT, NV, M, d, dtxt, dtw, dvid, dvw);
   return (int)hipGetLastError();
 }
 
