@@ -172,6 +172,9 @@ def main():
   ap.add_argument('--text-tower', choices=['synthetic', 'native'], default='synthetic',
                   help='synthetic: (B,768) text vectors stand in for the text tower (the headline workload); native: '
                        'random-init bert-base-cased on the engine, token ids in, fine-tuned with the rest (SURVEY 8f.2)')
+  ap.add_argument('--host-inputs', action='store_true',
+                  help='minibatches live in pinned host memory: every step uploads one over PCIe (the PCIe-inclusive rate; '
+                       'the headline value keeps the inputs resident in HBM)')
   ap.add_argument('--force-collectives', action='store_true',
                   help='N=1 only: run the all-gather / all-reduce plumbing on a 1-rank RCCL group (measures its overhead)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
@@ -212,7 +215,8 @@ def main():
   for i in range(NBATCH):
     mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
     mb['text'] = text.view(-1, 768)
-    batches.append(FlatMinibatch(mb, dev))  # one contiguous HBM buffer per minibatch: load = ONE D2D copy
+    # one contiguous buffer per minibatch (HBM, or pinned host memory with --host-inputs): load = ONE copy
+    batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
   static = FlatMinibatch(batches[0], dev)
   if args.text_tower == 'synthetic':
     model.txt_bert.text = static['text']
@@ -271,7 +275,7 @@ def main():
                                ('text tower replaced by synthetic (B,768) vectors' if args.text_tower == 'synthetic' else
                                 'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
                    'global_batch': world * BATCH, 'seq_len': seq,
-                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'text_tower': args.text_tower, 'grad_sync': 'staged' if runner.staged else 'single',
+                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'inputs': 'pinned host, uploaded every step' if args.host_inputs else 'resident in HBM', 'text_tower': args.text_tower, 'grad_sync': 'staged' if runner.staged else 'single',
                    'live_rows_rank0': live, 'dense_rows': BATCH * seq},
         'encoder_dense_tflops': pairs_per_s / BATCH * flops / 1e12 / world,
         'encoder_dense_mfma_frac': pairs_per_s / BATCH * flops / 1e12 / world / BF16_DENSE_PEAK_TFLOPS,

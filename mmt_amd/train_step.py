@@ -41,7 +41,9 @@ class FlatMinibatch(dict):
   static input buffers of the captured graphs is a single device-to-device (or host-to-device) copy instead of
   ~45 tiny ones (the reference's move_dict_to_device, trainer/trainer.py:36-52, moves tensor by tensor)."""
 
-  def __init__(self, minibatch, device):
+  def __init__(self, minibatch, device, pin_memory=False):
+    """device may be 'cpu' (+ pin_memory=True): a host-side staging buffer whose upload into a device FlatMinibatch of
+    the same layout is one asynchronous H2D copy."""
     super().__init__()
     leaves = []
 
@@ -62,7 +64,8 @@ class FlatMinibatch(dict):
       off = (off + 255) // 256 * 256
       spans.append(off)
       off += v.numel() * v.element_size()
-    self.flat = torch.zeros(max(off, 1), dtype=torch.uint8, device=device)
+    self.flat = torch.zeros(max(off, 1), dtype=torch.uint8, device=device,
+                            pin_memory=bool(pin_memory) and torch.device(device).type == 'cpu')
     for (out, k, v), o in zip(leaves, spans):
       n = v.numel() * v.element_size()
       view = self.flat[o:o + n].view(v.dtype).view(v.shape)

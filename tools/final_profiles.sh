@@ -7,6 +7,9 @@ cd $R
 timeout 900 python bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $O/bench_packed.json
 timeout 600 python bench.py --steps 200 --warmup 20 --dense --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_dense.json
 timeout 600 python bench.py --steps 100 --warmup 10 --text-tower native --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_native_text_tower.json
+timeout 600 python bench.py --steps 200 --warmup 20 --host-inputs --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_host_inputs.json
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/pytest_gpu.txt
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.txt 2>&1
 cd /tmp
 rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o step -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/prof_bench.log 2>&1
 DB=$(find /tmp/prof -name "*.db" | head -1)
