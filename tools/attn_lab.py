@@ -5,8 +5,13 @@ Findings so far (B = 32, S = 218, head dim 128: 17.8 us forward with the shipped
   * a 4-deep prefetch ring (all key tiles requested up front, 128 KiB LDS, 1 block/CU): 27 us -- co-resident blocks
     matter more than prefetch depth;
   * split over keys (16 queries x 4 waves, one key tile per wave, K fragments straight from global, wave-private V tile,
-    log-sum-exp merge): 38 us -- every 16-query group re-stages K/V, and tile staging (LDS-DMA issue + TA), not the
-    dependent chain, is what the kernel spends its time on."""
+    log-sum-exp merge): 38 us -- every 16-query group re-stages K/V;
+  * transpose reads from inline asm (so the compiler's wait-count pass no longer drains the next tile's prefetch with a
+    vmcnt(0) in front of them) + the key-mask bias fetched once in the prologue: 18.7 us -- the exposed DMA latency was
+    not the limiter either.
+  Throughput view (B = 512: 206 us = 3800 CU-cycles per 64x64x128 tile step, MFMA needs 512): each wave runs its
+  MFMAs (512 cycles), the softmax / dropout VALU work (~1200), the LDS-DMA issue (~800) and LDS waits one after the
+  other, with only two waves per SIMD to overlap them; the VALU share is the next thing to cut."""
 import ctypes
 import os
 import sys
