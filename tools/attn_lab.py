@@ -9,6 +9,10 @@ Findings so far (B = 32, S = 218, head dim 128: 17.8 us forward with the shipped
   * transpose reads from inline asm (so the compiler's wait-count pass no longer drains the next tile's prefetch with a
     vmcnt(0) in front of them) + the key-mask bias fetched once in the prologue: 18.7 us -- the exposed DMA latency was
     not the limiter either.
+  * 8 waves per block, the wave pair (w, w+4) sharing 16 queries and splitting every 64-key tile in halves (same staged
+    tile, half the MFMA / softmax work per wave, merge at the end): 19.5 us -- halving the per-wave instruction stream
+    changes nothing, so the limiter is a per-CU resource.  PMC (profiles/r01_pmc_kernels.csv, first pass): 52 % of the
+    wave cycles are parked in s_waitcnt / barriers, LDS bank-conflict cycles are 28 % of the LDS-active cycles.
   Throughput view (B = 512: 206 us = 3800 CU-cycles per 64x64x128 tile step, MFMA needs 512): each wave runs its
   MFMAs (512 cycles), the softmax / dropout VALU work (~1200), the LDS-DMA issue (~800) and LDS waits one after the
   other, with only two waves per SIMD to overlap them; the VALU share is the next thing to cut."""
