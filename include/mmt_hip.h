@@ -438,6 +438,9 @@ int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* 
  * records one pair around layer 0's FFN up-projection GEMM launch (the dominant kernel) on its stream.
  * The arrays must stay alive until the events have been read.  Pass NULL/0 to disarm. */
 int mmt_probe_arm(void** start_events, void** stop_events, int n);
+/* Measurement hook (tools/dispatch_lab.py): `blocks` workgroups of `threads` threads with `lds_bytes` of dynamic LDS, each
+ * spinning for `spin` clock ticks -- the workgroup dispatch rate as a function of the workgroup's shape. */
+int mmt_debug_dispatch_probe(int blocks, int threads, int lds_bytes, int spin, float* sink, void* stream);
 int mmt_probe_count(void);
 
 #ifdef __cplusplus

@@ -132,3 +132,27 @@ extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, 
                      exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step_dev, lr_dev);
   return (int)hipGetLastError();
 }
+
+
+// ---- measurement hook (tools/dispatch_lab.py): how fast does the hardware dispatch workgroups of a given shape? ----
+// Every block touches its dynamic LDS once and spins for `spin` clock ticks.
+__global__ void dispatch_probe_kernel(int spin, float* __restrict__ sink) {
+  extern __shared__ float probe_lds[];
+  probe_lds[threadIdx.x] = (float)blockIdx.x;
+  const long long t0 = clock64();
+  while (clock64() - t0 < spin) {}
+  if (sink && probe_lds[threadIdx.x] < 0.f) sink[0] = 1.f;
+}
+
+extern "C" int mmt_debug_dispatch_probe(int blocks, int threads, int lds_bytes, int spin, float* sink, void* stream) {
+  if (blocks <= 0 || threads <= 0 || threads > 1024 || lds_bytes < threads * 4 || lds_bytes > 160 * 1024) return MMT_ERR_ARG;
+  static int configured = 0;
+  if (lds_bytes > configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)dispatch_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
+    if (rc != hipSuccess) return (int)rc;
+    configured = 160 * 1024;
+  }
+  hipLaunchKernelGGL(dispatch_probe_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, spin, sink);
+  return (int)hipGetLastError();
+}
