@@ -92,6 +92,28 @@ __device__ __forceinline__ bool attn_keep(unsigned rowkey, unsigned k, unsigned 
   return ((k & 1) ? (r >> 16) : (r & 0xffffU)) >= thr16;
 }
 
+// A wave's 16 x DH result block (lane (row li, group lg) holds 4 consecutive columns of DH/16 fragments) written out as
+// whole 16-byte chunks of full rows: transposed through a wave-private LDS corner `ob` (16 * (DH + 8) bf16).  row_ptr(r)
+// gives the global address of row r's first column, or nullptr to skip the row.
+template <int DH, typename RowPtr>
+__device__ __forceinline__ void store_block16(bf16_t* ob, const f32x4* o, float mul, int lane, RowPtr row_ptr) {
+  constexpr int PITCH = DH + 8, CPR = DH / 8;
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int fd = 0; fd < DH / 16; ++fd) {
+    u32x2 v = {pack_bf2(o[fd][0] * mul, o[fd][1] * mul), pack_bf2(o[fd][2] * mul, o[fd][3] * mul)};
+    *(u32x2*)(ob + li * PITCH + fd * 16 + 4 * lg) = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the same wave wrote and reads
+#pragma unroll
+  for (int it = 0; it < 16 * CPR / 64; ++it) {
+    const int idx = it * 64 + lane, r = idx / CPR, c = idx % CPR;
+    bf16_t* dst = row_ptr(r);
+    if (dst) *(u32x4*)(dst + c * 8) = *(const u32x4*)(ob + r * PITCH + c * 8);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // the corner may be reused by the caller
+}
+
 struct AttnArgs {
   const bf16_t* qkv; int64_t ld;       // [rows, 3d]
   const int32_t* cu; int S_dense;      // cu nullable => dense b*S_dense
@@ -209,33 +231,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Vs, 1, fd * 16, lane), pb1, o[fd], 0, 0, 0);
     }
   }
-  // Output through LDS: a lane holds 4 consecutive columns of 8 fragments of ONE query, i.e. 8-byte pieces 32 B apart;
-  // stored directly that is 8 partial-line writes per lane (measured: 3 us of a 18 us launch).  Each wave transposes
-  // its 16 x DH block in its own corner of the (now idle) stage buffers and writes whole 16-byte chunks of full rows.
+  // Output through LDS (store_block16): stored directly, a lane's result is 8 partial-line writes 32 B apart (measured:
+  // 3 us of an 18 us launch).
   __syncthreads();
-  {
-    constexpr int PITCH = DH + 8;  // bf16 elements; +16 B keeps the 8-byte column writes off each other's banks
-    bf16_t* ob = smem + wave * 16 * PITCH;
-    const float inv = 1.0f / l_run;
-#pragma unroll
-    for (int fd = 0; fd < DH / 16; ++fd) {
-      u32x2 v = {pack_bf2(o[fd][0] * inv, o[fd][1] * inv), pack_bf2(o[fd][2] * inv, o[fd][3] * inv)};
-      *(u32x2*)(ob + li * PITCH + fd * 16 + 4 * lg) = v;
-    }
-    if (qi < nqs && lg == 0) a.lse[(int64_t)crow * a.H + h] = (m_run + log2f(l_run)) * LN2;
-    // same wave wrote and reads: no block barrier needed, only the LDS counter
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    constexpr int CPR = DH / 8;          // 16-byte chunks per row
-#pragma unroll
-    for (int it = 0; it < 16 * CPR / 64; ++it) {
-      const int idx = it * 64 + lane, r = idx / CPR, c = idx % CPR;
-      const int qr = q0 + wave * 16 + r;
-      if (qr < nqs) {
-        const int64_t orow = a.qsel ? (int64_t)b * a.nq + qr : (int64_t)off + qr;
-        *(u32x4*)(a.ctx + orow * a.ldc + h * DH + c * 8) = *(const u32x4*)(ob + r * PITCH + c * 8);
-      }
-    }
-  }
+  if (qi < nqs && lg == 0) a.lse[(int64_t)crow * a.H + h] = (m_run + log2f(l_run)) * LN2;
+  store_block16<DH>(smem + wave * 16 * (DH + 8), o, 1.0f / l_run, lane, [&](int r) -> bf16_t* {
+    const int qr = q0 + wave * 16 + r;
+    if (qr >= nqs) return nullptr;
+    return a.ctx + (a.qsel ? (int64_t)b * a.nq + qr : (int64_t)off + qr) * a.ldc + h * DH;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,14 +346,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Ks, 1, fd * 16, lane), sb1, o[fd], 0, 0, 0);
     }
   }
-  if (q_ok) {
-    bf16_t* dst = a.dqkv + (int64_t)qrow * a.ld + h * DH + 4 * lg;
-#pragma unroll
-    for (int fd = 0; fd < DH / 16; ++fd) {
-      u32x2 v = {pack_bf2(o[fd][0] * a.scale, o[fd][1] * a.scale), pack_bf2(o[fd][2] * a.scale, o[fd][3] * a.scale)};
-      *(u32x2*)(dst + fd * 16) = v;
-    }
-  }
+  __syncthreads();  // stage buffers idle: each wave transposes its block in its own corner
+  store_block16<DH>(smem + wave * 16 * (DH + 8), o, a.scale, lane, [&](int r) -> bf16_t* {
+    const int qr = q0 + wave * 16 + r;
+    if (qr >= nqs) return nullptr;
+    const int64_t grow = a.qsel ? (int64_t)a.qsel[b * a.nq + qr] : (int64_t)off + qr;
+    return a.dqkv + grow * a.ld + h * DH;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,17 +460,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(Qs, 1, fd * 16, lane), sb1, dk[fd], 0, 0, 0);
     }
   }
-  if (key_ok) {
-    bf16_t* dstk = a.dqkv + (int64_t)krow * a.ld + a.d + h * DH + 4 * lg;
-    bf16_t* dstv = a.dqkv + (int64_t)krow * a.ld + 2 * a.d + h * DH + 4 * lg;
-#pragma unroll
-    for (int fd = 0; fd < DH / 16; ++fd) {
-      u32x2 vk = {pack_bf2(dk[fd][0] * a.scale, dk[fd][1] * a.scale), pack_bf2(dk[fd][2] * a.scale, dk[fd][3] * a.scale)};
-      u32x2 vv = {pack_bf2(dv[fd][0], dv[fd][1]), pack_bf2(dv[fd][2], dv[fd][3])};
-      *(u32x2*)(dstk + fd * 16) = vk;
-      *(u32x2*)(dstv + fd * 16) = vv;
-    }
-  }
+  __syncthreads();  // stage buffers idle: each wave transposes its blocks in its own corner
+  auto krow_ptr = [&](int r, int section) -> bf16_t* {
+    const int kl = k0 + wave * 16 + r;
+    return kl < Sb ? a.dqkv + (int64_t)(off + kl) * a.ld + section * a.d + h * DH : nullptr;
+  };
+  store_block16<DH>(smem + wave * 16 * (DH + 8), dk, a.scale, lane, [&](int r) { return krow_ptr(r, 1); });
+  store_block16<DH>(smem + wave * 16 * (DH + 8), dv, 1.0f, lane, [&](int r) { return krow_ptr(r, 2); });
 }
 
 // test helper: materialise the attention dropout keep-mask, uint8 [B,H,S,S] (dense layout only)
