@@ -116,7 +116,7 @@ def time_dominant_kernel(rows, iters=40):
               avg_launch_us=sec * 1e6)
 
 
-def pmc_traffic(kernel_sub='gemm2_kernel<128, 128, 2, 4, 2, 2>', grid_sub='[grid 1320 '):
+def pmc_traffic(kernel_sub='gemm2_kernel<128, 128, 2, 4, 2, 2', grid_sub='[grid 1320 '):
   """HBM traffic of the dominant kernel per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_kernels.csv,
   separate --pmc runs of this same command): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a
   wide coalesced read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
