@@ -8,9 +8,11 @@ MI355X equivalent has one exchange step and one reduction:
      (n x n) similarity and the loss (redundantly: n <= a few hundred pairs, microseconds);
      backward of the gather hands each rank the gradient slice of its own rows -- no reduce-scatter is
      needed because every rank holds the complete loss;
-  2. one all-reduce(SUM) over the engine's flat gradient buffer (17.1 M fp32 for config B = one bucket,
-     one collective) plus one small bucket for the text-head parameters.  SUM, not mean: the loss is
-     already a mean over the global batch, exactly as DataParallel's reduce-add.
+  2. all-reduce(SUM) over the engine's flat gradient buffer (17.1 M fp32 for config B) -- as ONE collective after the
+     backward (`GradSync`), or, in `train_step.GraphedTrainStep`'s staged mode, span by span while the rest of the
+     backward still runs (the flat layout is ordered back to front for that, `CENet.grad_regions`).  SUM, not mean: the
+     loss is already a mean over the global batch, exactly as DataParallel's reduce-add.  Parameters outside the flat
+     buffers (a foreign text tower) travel in one extra bucket; a native text tower brings its own flat buffer.
 
 BatchNorm in the text heads uses per-rank statistics, as the reference's replicas do.
 Works with the gloo backend on CPU tensors too (used by the world_size-2 tests).
