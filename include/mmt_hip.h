@@ -438,6 +438,11 @@ int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* 
  * records one pair around layer 0's FFN up-projection GEMM launch (the dominant kernel) on its stream.
  * The arrays must stay alive until the events have been read.  Pass NULL/0 to disarm. */
 int mmt_probe_arm(void** start_events, void** stop_events, int n);
+/* y = dropout(x) (n % 4 == 0, 16-byte aligned) with the counter-based RNG of the engine: nn.Dropout in front of the text
+ * MoE logits (model/model.py:274).  Forward: key = hash(drop_key, *seed_dev), stored to key_save (nullable); backward:
+ * pass the saved key as key_load (the encoder advances the seed in between) and the gradient as x. */
+int mmt_dropout_f32(const float* x, float* y, int64_t n, uint32_t drop_key, uint32_t thr16, float scale,
+                    const uint32_t* seed_dev, uint32_t* key_save, const uint32_t* key_load, void* stream);
 /* Measurement hook (tools/dispatch_lab.py): `blocks` workgroups of `threads` threads with `lds_bytes` of dynamic LDS, each
  * spinning for `spin` clock ticks -- the workgroup dispatch rate as a function of the workgroup's shape. */
 int mmt_debug_dispatch_probe(int blocks, int threads, int lds_bytes, int spin, float* sink, void* stream);

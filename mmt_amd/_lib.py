@@ -145,6 +145,7 @@ SIGNATURES = {
     'mmt_reduce_slabs_2d': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     'mmt_colsum_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_pack_weights': (c_int, [ctypes.POINTER(MmtPackItem), c_int, c_vp]),
+    'mmt_dropout_f32': (c_int, [c_vp, c_vp, c_i64, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_debug_dispatch_probe': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_adam_step': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,

@@ -134,6 +134,37 @@ extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, 
 }
 
 
+// ---- stand-alone dropout (the MoE-logit input of the text heads, model/model.py:274) ------------------------------
+// y = keep ? x * scale : 0 with the engine's counter-based RNG, so that a captured training step contains no framework
+// RNG at all (a philox-based dropout makes every graph replay refill the generator's seed / offset tensors first).
+// The stream key is hash(drop_key, *seed_dev) at FORWARD time; it is written to key_save so that the backward, which
+// runs after the encoder has advanced the seed, re-draws the same mask (key_load).
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+                                                      unsigned drop_key, unsigned thr16, float scale,
+                                                      const unsigned* __restrict__ seed_dev, unsigned* __restrict__ key_save,
+                                                      const unsigned* __restrict__ key_load) {
+  const unsigned key = key_load ? *key_load : eff_key(drop_key, seed_dev);
+  if (key_save && blockIdx.x == 0 && threadIdx.x == 0) *key_save = key;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = ((const f32x4*)x)[i];
+    bool k[4];
+    keep4(key, (unsigned long long)i * 4ull, thr16, k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * scale : 0.f;
+    ((f32x4*)y)[i] = v;
+  }
+}
+
+extern "C" int mmt_dropout_f32(const float* x, float* y, int64_t n, uint32_t drop_key, uint32_t thr16, float scale,
+                               const uint32_t* seed_dev, uint32_t* key_save, const uint32_t* key_load, void* stream) {
+  if (!x || !y || n <= 0 || (n & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return MMT_ERR_ARG;
+  const int64_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n4, drop_key, thr16, scale, seed_dev,
+                     key_save, key_load);
+  return (int)hipGetLastError();
+}
+
 // ---- measurement hook (tools/dispatch_lab.py): how fast does the hardware dispatch workgroups of a given shape? ----
 // Every block touches its dynamic LDS once and spins for `spin` clock ticks.
 __global__ void dispatch_probe_kernel(int spin, float* __restrict__ sink) {

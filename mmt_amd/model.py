@@ -148,6 +148,31 @@ class _SimsFn(torch.autograd.Function):
     return dtxt, dvid, dtw, dvw
 
 
+class _MoeDropoutFn(torch.autograd.Function):
+  """nn.Dropout in front of the text MoE logits (model/model.py:274) on the engine's counter-based RNG: with it a
+  captured training step contains no framework RNG (a philox dropout makes every graph replay refill the generator's
+  seed / offset tensors first: two extra launches per step)."""
+  SITE_KEY = 0x7e57d0a1
+
+  @staticmethod
+  def forward(ctx, x, p, seed_dev):
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    ctx.key = torch.empty(1, dtype=torch.int32, device=x.device)
+    ctx.thr, ctx.scale = ops.dropout_params(p)
+    check(_lib.lib().mmt_dropout_f32(ops._p(x), ops._p(y), x.numel(), _MoeDropoutFn.SITE_KEY, ctx.thr, ctx.scale,
+                                     ops._p(seed_dev), ops._p(ctx.key), None, ops._stream()), 'mmt_dropout_f32')
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous().float()
+    gx = torch.empty_like(g)
+    check(_lib.lib().mmt_dropout_f32(ops._p(g), ops._p(gx), g.numel(), _MoeDropoutFn.SITE_KEY, ctx.thr, ctx.scale, None,
+                                     None, ops._p(ctx.key), ops._stream()), 'mmt_dropout_f32')
+    return gx, None, None
+
+
 class _TextHeadsFn(torch.autograd.Function):
   """text (B*C, K) -> text_embds (B, M, C, d), text_weights (B, C, M): the per-expert GatedEmbeddingUnits
   (model.py:413-417, 683-750) and the text MoE softmax (model.py:262-283, 610-618) in one native pass."""
@@ -628,8 +653,12 @@ class CENet(nn.Module):
         side.wait_stream(cur)
       with torch.cuda.stream(side if side is not None else cur):
         text_moe = None
-        if self.txt_wgh == 'emb' and self.training and self.moe_txt_dropout.p > 0:
-          text_moe = self.moe_txt_dropout(text)  # model.py:274: dropout only in front of the MoE logits
+        if self.txt_wgh == 'emb' and self.training and self.moe_txt_dropout.training and self.moe_txt_dropout.p > 0:
+          # model.py:274: dropout only in front of the MoE logits
+          if text.numel() % 4 == 0 and self.vid_bert._seed_dev is not None:
+            text_moe = _MoeDropoutFn.apply(text, self.moe_txt_dropout.p, self.vid_bert._seed_dev)
+          else:
+            text_moe = self.moe_txt_dropout(text)
         text_embds, text_weights = _TextHeadsFn.apply(self, text, text_moe, c, *self._text_head_params())
     else:
       text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417

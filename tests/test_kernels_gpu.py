@@ -471,3 +471,23 @@ def test_gemm_nn_input_gradient_form(M, N, K, tile):
   # split-K variant
   ops.gemm_nt_splitk(a, w, out32, 'ADD_F32', m=M, res=res, splits=3, b_kn=True)
   _close('nn.splitk', out32[:M], ref + res[:M], 2e-3, 2e-3)
+
+
+def test_standalone_dropout_keep_rate_and_backward_mask():
+  """mmt_dropout_f32 (the text MoE-logit dropout): keep rate p, survivors scaled by 1/(1-p), the backward re-draws the
+  SAME mask from the saved key although the per-step seed has advanced in between, and a new seed gives a new mask."""
+  from mmt_amd import ops
+  from mmt_amd.model import _MoeDropoutFn
+  _, sc = ops.dropout_params(0.1)  # 1 / (1 - p) for the 16-bit threshold actually used
+  x = _rand((64, 768), seed=150).requires_grad_(True)
+  seed = torch.tensor([1234], dtype=torch.int32, device=_dev())
+  y = _MoeDropoutFn.apply(x, 0.1, seed)
+  keep = y != 0
+  assert 0.88 < keep.float().mean().item() < 0.92
+  _close('dropout.scale', y[keep], (x * sc)[keep].detach(), 1e-6, 1e-6)
+  seed.add_(1)  # the encoder advances the seed between forward and backward
+  g = _rand((64, 768), seed=151)
+  y.backward(g)
+  _close('dropout.bwd', x.grad, g * keep * sc, 1e-6, 1e-6)
+  y2 = _MoeDropoutFn.apply(x.detach(), 0.1, seed)
+  assert ((y2 != 0) != keep).float().mean().item() > 0.05
