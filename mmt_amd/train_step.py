@@ -11,7 +11,7 @@ keeps the two RCCL collectives OUTSIDE of them (so nothing depends on collective
     eager   : all-reduce(SUM) of the flat gradient buffer + text-head bucket   (skipped at world size 1)
     graph C : optimizer step (fused flat Adam + capturable torch Adam for the rest)
 
-On one rank A and B are captured as ONE graph (13 us per step less than two).
+On one rank A, B and C are captured as ONE graph (every graph boundary costs ~9 us).
 
 With more than one rank the 68 MB gradient all-reduce would sit exposed between B and C (about a quarter of the step
 on 8 GPUs over xGMI rings).  `overlap_grad_sync` (default: on when world size > 1) therefore cuts graph B at the
@@ -357,7 +357,10 @@ class GraphedTrainStep:
         e = self._forward()
         g = self._gather(e)
         self.loss = self._loss_backward(e, g)
-      pool, gb = ga.pool(), None
+        self._opt()  # ... and the optimizer: the whole step is ONE graph launch
+      self._graphs, self._e = (ga, None, None), e
+      torch.cuda.synchronize()
+      return
     elif self.staged:
       self._regions = self._region_table()
       gb = []
@@ -408,5 +411,6 @@ class GraphedTrainStep:
     else:
       gb.replay()
       self._sync_all()
-    gc.replay()
+    if gc is not None:
+      gc.replay()
     return self.loss
