@@ -1,14 +1,14 @@
 """One data-parallel training step of the hot path, captured as HIP graphs.
 
 Eagerly, a step issues ~600 tiny launches (text heads, autograd glue, optimizer) and is host-bound at
-~7 ms while the kernels need < 2 ms.  `GraphedTrainStep` captures the compute in three HIP graphs and
-keeps the two RCCL collectives OUTSIDE of them (so nothing depends on collective capture support):
+~7 ms while the kernels need < 2 ms.  `GraphedTrainStep` captures the compute in HIP graphs and keeps the RCCL
+collectives OUTSIDE of them (so nothing depends on collective capture support).  The basic multi-rank shape:
 
     graph A : CENet forward (out='embds') on the local batch
-    eager   : all-gather of embeddings / weights over ranks            (skipped at world size 1)
+    eager   : ONE all-gather of the embeddings / weights over ranks (packed into a send buffer inside graph A)
     graph B : global similarity + loss + backward (through the gather, into the local embeddings,
               through graph A's autograd graph into the flat gradient buffer)
-    eager   : all-reduce(SUM) of the flat gradient buffer + text-head bucket   (skipped at world size 1)
+    eager   : all-reduce(SUM) of the flat gradient buffer(s) (+ a bucket for parameters outside them)
     graph C : optimizer step (fused flat Adam + capturable torch Adam for the rest)
 
 On one rank A, B and C are captured as ONE graph (every graph boundary costs ~9 us).
@@ -19,8 +19,9 @@ points where a contiguous span of the flat gradient buffer is final -- similarit
 encoder layer from the top down, then embeddings + the expert projections -- and starts that span's all-reduce on
 RCCL's stream while the next stage's graph runs:
 
-    B0 loss, text heads, read-out | all-reduce(text)   B1 layer L-1 | all-reduce(layer L-1)   ...
-    Bk layer 0 + embeddings + video tokens | all-reduce(layer 0, reduce-dim)   wait   C
+    B0 loss, text heads, read-out, layer L-1 | all-reduce('top')   B1 layer L-2 | all-reduce   ...
+    Bk layer 0 + embeddings + video tokens | all-reduce('bottom')   wait   C
+(the flat layout is ordered back to front so that each of these spans is one contiguous run, CENet.grad_regions)
 
 The stages call the engine's range backward (mmt_bert_backward_range) directly instead of through autograd, so each
 stage is a plain kernel sequence that captures into its own graph; the collectives stay eager.
