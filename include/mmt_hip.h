@@ -259,6 +259,25 @@ int mmt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   const int32_t* step_dev, const float* lr_dev, void* stream);
 
+/* The same optimizer step (train.py:100) that ALSO refreshes the bf16 shadows of the GEMM weights (and their W^T
+ * copies), so that no re-packing pass over the weights runs between optimizer and the next forward.  The flat buffer is
+ * described as segments in ascending order that tile [0, count): dst == NULL: a plain span of `count` elements;
+ * otherwise the fp32 matrix [rows, cols] at `offset` (cols % 4 == 0) whose bf16 copy dst [rows, dst_ld] and optional
+ * transpose dst_t [cols, dst_t_ld >= rows, % 8 == 0] are rewritten from the updated values.  segs_host / segs_dev: the
+ * same table in host memory (grid layout) and device memory (read by the kernel; it must stay valid under graph replay). */
+#define MMT_ADAM_SEG_MAX 160
+typedef struct MmtAdamSeg {
+  int64_t offset, count;
+  void* dst;
+  void* dst_t;
+  int32_t rows, cols, dst_ld, dst_t_ld;
+} MmtAdamSeg;
+int mmt_adam_fused_blocks(const MmtAdamSeg* seg);
+int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                        const MmtAdamSeg* segs_host, const MmtAdamSeg* segs_dev, int n_segs, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, const int32_t* step_dev, const float* lr_dev,
+                        void* stream);
+
 /* ---- video tokens (assemble.hip) -------------------------------------------------------------------
  * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip. */
 #define MMT_MAX_EXPERTS 16

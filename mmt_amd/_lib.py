@@ -24,6 +24,11 @@ class MmtPackItem(ctypes.Structure):
               ('reserved', ctypes.c_int32)]
 
 
+class MmtAdamSeg(ctypes.Structure):
+  _fields_ = [('offset', c_i64), ('count', c_i64), ('dst', c_vp), ('dst_t', c_vp), ('rows', ctypes.c_int32),
+              ('cols', ctypes.c_int32), ('dst_ld', ctypes.c_int32), ('dst_t_ld', ctypes.c_int32)]
+
+
 class MmtGemmItem(ctypes.Structure):
   _fields_ = [('A', c_vp), ('B', c_vp), ('C', c_vp), ('bias', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldc', c_i64),
               ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('tile_begin', ctypes.c_int32)]
@@ -148,6 +153,9 @@ SIGNATURES = {
     'mmt_dropout_f32': (c_int, [c_vp, c_vp, c_i64, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_debug_dispatch_probe': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_adam_step': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    'mmt_adam_fused_blocks': (c_int, [ctypes.POINTER(MmtAdamSeg)]),
+    'mmt_adam_step_fused': (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtAdamSeg), c_vp, c_int, c_f32, c_f32, c_f32,
+                                    c_f32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_vp]),

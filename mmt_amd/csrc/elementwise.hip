@@ -133,6 +133,147 @@ extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, 
   return (int)hipGetLastError();
 }
 
+// ---- fused Adam + bf16 shadow refresh ------------------------------------------------------------------------------
+// The GEMMs read bf16 shadows (W, and W^T for the input-gradient GEMMs) of the fp32 master weights.  Re-packing them
+// after every optimizer step was a pure re-layout pass over every GEMM weight (pack_weights_kernel: 48 us of a 1.65 ms
+// step, 9 % together with Adam).  Here the optimizer writes them itself: the flat buffer is cut into SEGMENTS, each
+// either a shadowed matrix [rows, cols] (worked on in 64x64 tiles: Adam update, bf16 row-major store, transposed
+// bf16 store through an LDS tile) or a plain span (biases, LayerNorm, embeddings, fp32 text heads).  One launch,
+// one 4096-element unit of work per block either way.  The segment table lives in device memory (built once by the
+// host side); the first-block prefix of every segment travels by value so a block finds its segment without a
+// dependent chain of loads.
+struct AdamSegIndex { int32_t n; int32_t begin[MMT_ADAM_SEG_MAX + 1]; };
+
+__device__ __forceinline__ void adam_update4(f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, float beta1, float beta2,
+                                             float eps, float weight_decay, float step_size, float inv_sqrt_bc2) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gg = gv[k] + weight_decay * pv[k];
+    mv[k] = beta1 * mv[k] + (1.0f - beta1) * gg;
+    vv[k] = beta2 * vv[k] + (1.0f - beta2) * gg * gg;
+    const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+    pv[k] -= step_size * (mv[k] / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const MmtAdamSeg* __restrict__ segs, AdamSegIndex idx, float lr,
+                                                         float beta1, float beta2, float eps, float weight_decay,
+                                                         const int32_t* __restrict__ step_dev,
+                                                         const float* __restrict__ lr_dev) {
+  __shared__ float tile[64][65];
+  if (lr_dev) lr = *lr_dev;
+  const float t = (float)*step_dev;
+  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  int s = 0;
+#pragma unroll 1
+  for (int q = 1; q < idx.n; ++q)
+    if ((int)blockIdx.x >= idx.begin[q]) s = q;
+  const MmtAdamSeg seg = segs[s];
+  const int lb = (int)blockIdx.x - idx.begin[s];
+  const int tid = threadIdx.x;
+  if (!seg.dst) {  // plain span: 4096 elements per block, 16 B per lane, four sweeps
+    const int64_t base = seg.offset + (int64_t)lb * 4096;
+    const int64_t end = seg.offset + seg.count;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t e = base + (int64_t)(i * 256 + tid) * 4;
+      if (e < end) {
+        f32x4 pv = *(const f32x4*)(p + e), gv = __builtin_nontemporal_load((const f32x4*)(g + e));
+        f32x4 mv = __builtin_nontemporal_load((const f32x4*)(m + e)), vv = __builtin_nontemporal_load((const f32x4*)(v + e));
+        adam_update4(pv, gv, mv, vv, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2);
+        *(f32x4*)(p + e) = pv;
+        __builtin_nontemporal_store(mv, (f32x4*)(m + e));
+        __builtin_nontemporal_store(vv, (f32x4*)(v + e));
+      }
+    }
+    return;
+  }
+  // shadowed matrix: tile (tr, tc) of 64x64; thread (r = tid/16 + 16 i, c = 4 (tid%16))
+  const int tiles_c = (seg.cols + 63) >> 6;
+  const int r0 = (lb / tiles_c) * 64, c0 = (lb % tiles_c) * 64;
+  const int c = c0 + (tid & 15) * 4;
+  bf16_t* __restrict__ dst = (bf16_t*)seg.dst;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (tid >> 4) + 16 * i, r = r0 + rl;
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+    if (r < seg.rows && c < seg.cols) {  // cols % 4 == 0: a 4-group is inside or outside as a whole
+      const int64_t e = seg.offset + (int64_t)r * seg.cols + c;
+      pv = *(const f32x4*)(p + e);
+      const f32x4 gv = __builtin_nontemporal_load((const f32x4*)(g + e));
+      f32x4 mv = __builtin_nontemporal_load((const f32x4*)(m + e)), vv = __builtin_nontemporal_load((const f32x4*)(v + e));
+      adam_update4(pv, gv, mv, vv, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2);
+      *(f32x4*)(p + e) = pv;
+      __builtin_nontemporal_store(mv, (f32x4*)(m + e));
+      __builtin_nontemporal_store(vv, (f32x4*)(v + e));
+      u32x2 o = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
+      *(u32x2*)(dst + (int64_t)r * seg.dst_ld + c) = o;
+    }
+    if (seg.dst_t) {
+      const int cl = (tid & 15) * 4;
+      tile[rl][cl] = pv[0]; tile[rl][cl + 1] = pv[1]; tile[rl][cl + 2] = pv[2]; tile[rl][cl + 3] = pv[3];
+    }
+  }
+  if (!seg.dst_t) return;
+  __syncthreads();
+  // transposed copy: row = source column, 16 consecutive source rows (32 B) per thread
+  bf16_t* __restrict__ dst_t = (bf16_t*)seg.dst_t;
+  const int tcl = tid >> 2, rq = (tid & 3) * 16;
+  const int tcol = c0 + tcl;  // row of dst_t
+  if (tcol < seg.cols) {
+    unsigned w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = pack_bf2(tile[rq + 2 * k][tcl], tile[rq + 2 * k + 1][tcl]);
+    bf16_t* out = dst_t + (int64_t)tcol * seg.dst_t_ld + r0 + rq;
+    if (r0 + rq + 15 < seg.rows) {
+      *(u32x4*)out = (u32x4){w[0], w[1], w[2], w[3]};
+      *(u32x4*)(out + 8) = (u32x4){w[4], w[5], w[6], w[7]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (r0 + rq + k < seg.rows) out[k] = (bf16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+    }
+  }
+}
+
+extern "C" int mmt_adam_fused_blocks(const MmtAdamSeg* seg) {
+  if (!seg) return MMT_ERR_ARG;
+  if (!seg->dst) return (int)((seg->count + 4095) / 4096);
+  return ((seg->rows + 63) / 64) * ((seg->cols + 63) / 64);
+}
+
+extern "C" int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   const MmtAdamSeg* segs_host, const MmtAdamSeg* segs_dev, int n_segs, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, const int32_t* step_dev, const float* lr_dev,
+                                   void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !segs_host || !segs_dev || !step_dev || n_segs <= 0 ||
+      n_segs > MMT_ADAM_SEG_MAX)
+    return MMT_ERR_ARG;
+  AdamSegIndex idx;
+  idx.n = n_segs;
+  int blocks = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const MmtAdamSeg& sg = segs_host[i];
+    if ((sg.offset & 3) || sg.count <= 0) return MMT_ERR_ARG;
+    if (sg.dst) {
+      if (sg.rows <= 0 || sg.cols <= 0 || (sg.cols & 3) || sg.dst_ld < sg.cols || (sg.dst_ld & 3) || ((uintptr_t)sg.dst & 7))
+        return MMT_ERR_ARG;
+      if (sg.dst_t && (sg.dst_t_ld < sg.rows || (sg.dst_t_ld & 7) || ((uintptr_t)sg.dst_t & 15))) return MMT_ERR_ALIGN;
+    } else if (sg.count & 3) {
+      return MMT_ERR_ARG;
+    }
+    idx.begin[i] = blocks;
+    blocks += mmt_adam_fused_blocks(&sg);
+  }
+  idx.begin[n_segs] = blocks;
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                     segs_dev, idx, lr, beta1, beta2, eps, weight_decay, step_dev, lr_dev);
+  return (int)hipGetLastError();
+}
+
 
 // ---- stand-alone dropout (the MoE-logit input of the text heads, model/model.py:274) ------------------------------
 // y = keep ? x * scale : 0 with the engine's counter-based RNG, so that a captured training step contains no framework

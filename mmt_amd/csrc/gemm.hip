@@ -13,6 +13,7 @@
 //       ds_read_b64_tr_b16 (hardware 4x16 transpose) because the contraction index is the ROW.
 // MFMA operands are swapped (a = B-side fragment) so each lane ends up with 4 consecutive output
 // columns of one row: 8/16-byte stores instead of 2-byte scatters.
+#include <stdlib.h>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -507,6 +508,35 @@ static int launch_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 
+// Wide outputs whose width is a multiple of 192 (QKV: 1536, FFN: 3072): a 192-column tile can cover the live rows in ONE
+// round of <= 256 blocks where the 128x128 tile needs 1.3 rounds at 2 blocks per CU (config B, ~3600 live rows of 6976:
+// 14 x 16 = 224 tiles of 256x192 for N = 3072, 28 x 8 = 224 tiles of 128x192 for N = 1536).  Under token packing the
+// live row count is only known on the device; MMT_LIVE_FRACTION (default 0.52 = the synthetic MSRVTT fill, U{0..30} valid
+// tokens of 30) is the host's estimate for choosing the tile.  MMT_TILE_N3072 / MMT_TILE_N1536 force a tile (lab).
+static int wide192_tile(int M, int N, bool packed) {
+  static int forced3072 = -1, forced1536 = -1, enabled = -1;
+  static double live_fraction = 0.52;
+  if (enabled < 0) {
+    const char* a = getenv("MMT_TILE_N3072");
+    const char* b = getenv("MMT_TILE_N1536");
+    const char* f = getenv("MMT_LIVE_FRACTION");
+    const char* en = getenv("MMT_TILE_192");
+    forced3072 = a ? atoi(a) : 0;
+    forced1536 = b ? atoi(b) : 0;
+    if (f && atof(f) > 0.0) live_fraction = atof(f);
+    enabled = en ? atoi(en) : 0;
+  }
+  if (N == 3072 && forced3072) return forced3072;
+  if (N == 1536 && forced1536) return forced1536;
+  if (!enabled) return 0;
+  const int est = packed ? (int)(M * live_fraction) : M;
+  const int cols = N / 192;
+  const int big = ((est + 255) / 256) * cols, mid = ((est + 127) / 128) * cols;
+  if (big > 128 && big <= 256) return 15;   // 256x192, one block per CU, one round
+  if (mid > 128 && mid <= 256) return 16;   // 128x192
+  return 0;
+}
+
 template <int EPI>
 static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
@@ -520,6 +550,10 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
   //   * short batches (M <= 1024: the text tower's ~560..960 token rows): too few 128x128 tiles for 256 CUs; the
   //     128x64 8-wave tile wins everywhere (tools/gemm_lab.py --text: 10.3 vs 13.2 us FFN-up at 560 live rows).
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
+    const int t = wide192_tile(M, N, nr != nullptr);
+    if (t) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
   if (e.reserved == 0 && M <= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
     return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if (e.reserved == 0 && M >= 512) {

@@ -106,9 +106,14 @@ __device__ __forceinline__ void gemm2_body(
     const int32_t* __restrict__ n_rows_dev, const int bid, const int nblk) {
   constexpr int NW = WGM * WGN, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
   constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
-  constexpr int CG = BN / 4;       // 4-column groups per row
+  // the epilogue sweeps the image in column blocks of CB columns: the whole width when the thread count divides into
+  // whole rows of it, 64-column blocks otherwise (BN = 192: 3 blocks of 16 lanes x 16 B per row)
+  constexpr int CB = (NT * 4) % BN == 0 ? BN : 64;
+  constexpr int NCB = BN / CB;     // column blocks
+  constexpr int CG = CB / 4;       // 4-column groups per row of a column block
   constexpr int RG = NT / CG;      // rows covered per sweep of the block
   constexpr int CH = BM < 64 ? BM : 64;  // rows per epilogue chunk
+  static_assert(BN % CB == 0 && NT % CG == 0 && CH % RG == 0, "epilogue geometry");
   // 8-wave blocks run as two groups in opposite phase (waves w and w+4 share a SIMD): group 0 issues the next
   // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
   // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
@@ -246,14 +251,19 @@ __device__ __forceinline__ void gemm2_body(
   float* st = (float*)smem_raw;
   float* red = st + CH * P;  // [RG][BN] column-sum scratch (DGELU)
   const int cg = tid % CG, rg = tid / CG;
-  const int col = n0 + cg * 4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_BIAS_DROP_RES ||
-                EPI == MMT_EPI_BIAS_F32)
-    bias4 = *(const f32x4*)(epi.bias + col);
+  f32x4 bias4[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    bias4[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_BIAS_DROP_RES ||
+                  EPI == MMT_EPI_BIAS_F32)
+      bias4[cb] = *(const f32x4*)(epi.bias + n0 + cb * CB + cg * 4);
+  }
   unsigned dkey = 0;
   if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  float csum[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) csum[cb][0] = csum[cb][1] = csum[cb][2] = csum[cb][3] = 0.f;
   __syncthreads();  // every wave is done with the stage buffers
 #pragma unroll
   for (int ch = 0; ch < BM / CH; ++ch) {
@@ -270,57 +280,65 @@ __device__ __forceinline__ void gemm2_body(
     }
     __syncthreads();
 #pragma unroll
-    for (int r0 = 0; r0 < CH; r0 += RG) {
-      const int r = r0 + rg;
-      const int row = m0 + ch * CH + r;
-      if (row < M) {
-        f32x4 v = *(const f32x4*)(st + r * P + cg * 4);
-        v += bias4;
-        if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
-          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
-        } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
-          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
-          // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
-          const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
-          const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
-          u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
-          *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
-        } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
-          if (epi.drop_thr16) {
-            const int orow = epi.row_index ? epi.row_index[row] : row;
-            bool k[4];
-            keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int lcol = cb * CB + cg * 4;  // column inside the tile
+      const int col = n0 + lcol;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
+      for (int r0 = 0; r0 < CH; r0 += RG) {
+        const int r = r0 + rg;
+        const int row = m0 + ch * CH + r;
+        if (row < M) {
+          f32x4 v = *(const f32x4*)(st + r * P + lcol);
+          v += bias4[cb];
+          if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+          } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
+            const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
+            const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
+            u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
+            *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
+          } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+            if (epi.drop_thr16) {
+              const int orow = epi.row_index ? epi.row_index[row] : row;
+              bool k[4];
+              keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
+            }
+            v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+          } else if constexpr (EPI == MMT_EPI_DGELU) {
+            const u32x2 a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+            v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
+            v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
+            v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
+            v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            if (row < nrows) {
+              csum[cb][0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[cb][1] += bf2f((bf16_t)(o[0] >> 16));
+              csum[cb][2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[cb][3] += bf2f((bf16_t)(o[1] >> 16));
+            }
+          } else if constexpr (EPI == MMT_EPI_ADD_F32) {
+            v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+          } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
+            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
           }
-          v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
-        } else if constexpr (EPI == MMT_EPI_DGELU) {
-          const u32x2 a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
-          v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
-          v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
-          v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
-          v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
-          u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
-          if (row < nrows) {
-            csum[0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[1] += bf2f((bf16_t)(o[0] >> 16));
-            csum[2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[3] += bf2f((bf16_t)(o[1] >> 16));
-          }
-        } else if constexpr (EPI == MMT_EPI_ADD_F32) {
-          v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
-        } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
-          *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
         }
       }
     }
     if constexpr (EPI == MMT_EPI_DGELU) {
       if (epi.colsum && BM >= 128 && (ch & 1)) {  // one partial row of column sums per 128 output rows
-        *(f32x4*)(red + rg * BN + cg * 4) = (f32x4){csum[0], csum[1], csum[2], csum[3]};
-        csum[0] = csum[1] = csum[2] = csum[3] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          *(f32x4*)(red + rg * BN + cb * CB + cg * 4) = (f32x4){csum[cb][0], csum[cb][1], csum[cb][2], csum[cb][3]};
+          csum[cb][0] = csum[cb][1] = csum[cb][2] = csum[cb][3] = 0.f;
+        }
         __syncthreads();
         const int half_row = m0 / 128 + (ch >> 1);
         if (tid < BN && half_row * 128 < M) {
@@ -552,7 +570,8 @@ template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
 static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   constexpr int NT = WGM * WGN * 64;
-  constexpr int RG = NT / (BN / 4);
+  constexpr int CB = (NT * 4) % BN == 0 ? BN : 64;
+  constexpr int RG = NT / (CB / 4);
   constexpr int CH = BM < 64 ? BM : 64;
   static_assert(CH % RG == 0 && (BM + BN) % (8 * WGM * WGN) == 0 && BM % (8 * WGM * WGN) == 0 && BN % (8 * WGM * WGN) == 0,
                 "tile geometry");
@@ -588,6 +607,10 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 12: if (N % 128 == 0) G2(64, 128, 2, 4, 3); break;   // 8 waves on 64x128 (wave 32x32), staggered, 2 blocks/CU
     case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
     case 14: if (N % 128 == 0) G2(128, 128, 2, 4, 2); break;  // 8 waves on 128x128, in phase, 2 blocks/CU
+    case 15: if (N % 192 == 0) G2(256, 192, 4, 2, 2); break;  // 8 waves on 256x192 (wave 64x96), 1 block/CU: N = 3072 at
+                                                              // <= 4096 live rows is ONE round of <= 256 tiles
+    case 16: if (N % 192 == 0) G2(128, 192, 4, 2, 3); break;  // 8 waves on 128x192 (wave 32x96), staggered
+    case 17: if (N % 192 == 0) G2(128, 192, 2, 2, 3); break;  // 4 waves on 128x192 (wave 64x96)
   }
 #undef G2
   return MMT_ERR_ARG;

@@ -77,87 +77,110 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 
 // DROP: 0 none, 1 dropout applied BEFORE the LN input (dy = mask*dz*scale), 2 dropout applied AFTER the
 // LN output (incoming dout is masked first; embeddings).
-template <int DROP>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+// 8 waves per block, RPW rows per wave with every load of the wave's rows issued up front (the previous version -- 4 waves
+// walking 4 rows each with a one-row prefetch -- ran at 2.3 TB/s with 3.5 waves per CU: latency-bound); the column
+// partials of the block's waves are combined through LDS with 16-byte accesses.
+#define LNB_WAVES 8
+template <int DROP, int RPW, int NCH>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ z, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, float* __restrict__ dz_out,
-    bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows, int d, int rows_per_block,
+    bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows,
     const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
     uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
-  extern __shared__ __attribute__((aligned(16))) float red_raw[];  // [4 waves][3][d]
+  extern __shared__ __attribute__((aligned(16))) float red_raw[];  // [LNB_WAVES][3][d]
   const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
-  const int nch = d >> 8;
-  f32x4 dg[MAXC], db[MAXC], dbias[MAXC];
+  constexpr int d = NCH * 256;
+  f32x4 dg[NCH], db[NCH], dbias[NCH];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = dbias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int r_begin = blockIdx.x * rows_per_block;
-  const int r_end = min(nrows, r_begin + rows_per_block);
-  // software prefetch: the next row's dout / z are in flight while the current row is reduced
-  f32x4 go_n[MAXC], zz_n[MAXC];
-  float mean_n = 0.f, rstd_n = 0.f;
-  int orow_n = 0;
-  auto fetch = [&](int row) {
-    mean_n = mean_in[row]; rstd_n = rstd_in[row];
-    orow_n = row_index ? row_index[row] : row;
+  for (int c = 0; c < NCH; ++c) dg[c] = db[c] = dbias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int r_begin = blockIdx.x * (LNB_WAVES * RPW);
+  f32x4 go[RPW][NCH], zz[RPW][NCH];
+  float mean[RPW], rstd[RPW];
+  int orow[RPW];
+  bool live[RPW];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < nch) {
+  for (int q = 0; q < RPW; ++q) {  // all loads of the wave's rows in flight together
+    const int row = r_begin + q * LNB_WAVES + wave;
+    live[q] = row < nrows;
+    const int rr = live[q] ? row : 0;
+    mean[q] = mean_in[rr]; rstd[q] = rstd_in[rr];
+    orow[q] = row_index ? row_index[rr] : rr;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      {
         const int col = c * 256 + lane * 4;
-        go_n[c] = *(const f32x4*)(dout + (int64_t)row * d + col);
-        zz_n[c] = *(const f32x4*)(z + (int64_t)row * d + col);
+        go[q][c] = *(const f32x4*)(dout + (int64_t)rr * d + col);
+        zz[q][c] = *(const f32x4*)(z + (int64_t)rr * d + col);
       }
-  };
-  if (r_begin + wave < r_end) fetch(r_begin + wave);
-  for (int row = r_begin + wave; row < r_end; row += 4) {
-    const float mean = mean_n, rstd = rstd_n;
-    const int orow = orow_n;
-    f32x4 xh[MAXC], g[MAXC], go_c[MAXC], zz_c[MAXC];
+  }
+  f32x4 gm[NCH];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) { go_c[c] = go_n[c]; zz_c[c] = zz_n[c]; }
-    if (row + 4 < r_end) fetch(row + 4);
-    float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < NCH; ++c)
+    gm[c] = *(const f32x4*)(gamma + c * 256 + lane * 4);
+  f32x4 xh[RPW][NCH], g[RPW][NCH];
+  float s1[RPW], s2[RPW];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < nch) {
+  for (int q = 0; q < RPW; ++q) {
+    s1[q] = s2[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      {
         const int col = c * 256 + lane * 4;
-        f32x4 go = go_c[c];
         if constexpr (DROP == 2) {
           if (thr16) {
             bool kp[4];
-            keep4(drop_key, (unsigned long long)orow * (unsigned)d + (unsigned)col, thr16, kp);
+            keep4(drop_key, (unsigned long long)orow[q] * (unsigned)d + (unsigned)col, thr16, kp);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) go[k] = kp[k] ? go[k] * drop_scale : 0.f;
+            for (int k = 0; k < 4; ++k) go[q][c][k] = kp[k] ? go[q][c][k] * drop_scale : 0.f;
           }
         }
-        const f32x4 zz = zz_c[c];
-        const f32x4 gm = *(const f32x4*)(gamma + col);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          xh[c][k] = (zz[k] - mean) * rstd;
-          g[c][k] = go[k] * gm[k];
-          s1 += g[c][k];
-          s2 += g[c][k] * xh[c][k];
-          dg[c][k] += go[k] * xh[c][k];
-          db[c][k] += go[k];
+          xh[q][c][k] = (zz[q][c][k] - mean[q]) * rstd[q];
+          g[q][c][k] = go[q][c][k] * gm[c][k];
+          s1[q] += g[q][c][k];
+          s2[q] += g[q][c][k] * xh[q][c][k];
+        }
+        if (live[q]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            dg[c][k] += go[q][c][k] * xh[q][c][k];
+            db[c][k] += go[q][c][k];
+          }
         }
       }
-    const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+  }
+  // the 2*RPW wave reductions are independent chains: interleaved by the compiler
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < nch) {
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      s1[q] += __shfl_xor(s1[q], o, 64);
+      s2[q] += __shfl_xor(s2[q], o, 64);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    if (!live[q]) continue;  // wave-uniform
+    const int row = r_begin + q * LNB_WAVES + wave;
+    const float m1 = s1[q] / (float)d, m2 = s2[q] / (float)d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      {
         const int col = c * 256 + lane * 4;
         f32x4 dzv;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dzv[k] = rstd * (g[c][k] - m1 - xh[c][k] * m2);
+        for (int k = 0; k < 4; ++k) dzv[k] = rstd[q] * (g[q][c][k] - m1 - xh[q][c][k] * m2);
         if (dz_out) *(f32x4*)(dz_out + (int64_t)row * d + col) = dzv;
         if (dy_out) {
           f32x4 dyv = dzv;
           if constexpr (DROP == 1) {
             if (thr16) {
               bool kp[4];
-              keep4(drop_key, (unsigned long long)orow * (unsigned)d + (unsigned)col, thr16, kp);
+              keep4(drop_key, (unsigned long long)orow[q] * (unsigned)d + (unsigned)col, thr16, kp);
 #pragma unroll
               for (int k = 0; k < 4; ++k) dyv[k] = kp[k] ? dyv[k] * drop_scale : 0.f;
             }
@@ -170,24 +193,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         }
       }
   }
-  // cross-wave reduction of the column partials, one [3][d] record per block
+  // cross-wave reduction of the column partials, one [3][d] record per block (fixed order => deterministic)
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c)
-    if (c < nch) {
+  for (int c = 0; c < NCH; ++c)
+    {
       const int col = c * 256 + lane * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        red_raw[(wave * 3 + 0) * d + col + k] = dg[c][k];
-        red_raw[(wave * 3 + 1) * d + col + k] = db[c][k];
-        red_raw[(wave * 3 + 2) * d + col + k] = dbias[c][k];
-      }
+      *(f32x4*)(red_raw + (wave * 3 + 0) * d + col) = dg[c];
+      *(f32x4*)(red_raw + (wave * 3 + 1) * d + col) = db[c];
+      *(f32x4*)(red_raw + (wave * 3 + 2) * d + col) = dbias[c];
     }
   __syncthreads();
-  for (int e = threadIdx.x; e < 3 * d; e += 256) {
-    const int which = e / d, col = e % d;
-    partials[((int64_t)blockIdx.x * 3 + which) * d + col] =
-        red_raw[(0 * 3 + which) * d + col] + red_raw[(1 * 3 + which) * d + col] + red_raw[(2 * 3 + which) * d + col] +
-        red_raw[(3 * 3 + which) * d + col];
+  for (int e = threadIdx.x; e < 3 * d / 4; e += 64 * LNB_WAVES) {
+    f32x4 acc = *(const f32x4*)(red_raw + e * 4);
+#pragma unroll
+    for (int w = 1; w < LNB_WAVES; ++w) acc += *(const f32x4*)(red_raw + w * 3 * d + e * 4);
+    *(f32x4*)(partials + (int64_t)blockIdx.x * 3 * d + e * 4) = acc;
   }
 }
 
@@ -406,9 +426,9 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
   return (int)hipGetLastError();
 }
 
-// rows per block: 16 for big inputs; 4 (one row per wave) when there are few rows, so that a compact last-layer
-// LayerNorm is not a 14-block launch
-extern "C" int mmt_ln_bwd_rows_per_block(int rows) { return rows <= 2048 ? 4 : 16; }
+// rows per block: 16 (two rows per wave) for big inputs; 8 (one row per wave) when there are few rows, so that a
+// compact last-layer LayerNorm is not a 14-block launch
+extern "C" int mmt_ln_bwd_rows_per_block(int rows) { return rows <= 2048 ? 8 : 16; }
 
 extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
                           const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
@@ -419,13 +439,33 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   const int rpb = mmt_ln_bwd_rows_per_block(rows), grid = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
-#define LN_BWD_LAUNCH(MODE)                                                                            \
-  hipLaunchKernelGGL(ln_bwd_kernel<MODE>, dim3(grid), dim3(256), (size_t)4 * 3 * d * sizeof(float), s, dout, z, mean, rstd, gamma, dz, \
-                     (bf16_t*)dy, partials, rows, d, rpb, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev)
-  if (drop_mode == 0) LN_BWD_LAUNCH(0);
-  else if (drop_mode == 1) LN_BWD_LAUNCH(1);
-  else if (drop_mode == 2) LN_BWD_LAUNCH(2);
-  else return MMT_ERR_ARG;
+  const size_t lds = (size_t)LNB_WAVES * 3 * d * sizeof(float);
+#define LN_BWD_LAUNCH(MODE, RPW, NCH)                                                                             \
+  do {                                                                                                            \
+    static bool configured = false;                                                                               \
+    if (!configured && lds > 64 * 1024) {                                                                         \
+      hipError_t rc = hipFuncSetAttribute((const void*)ln_bwd_kernel<MODE, RPW, NCH>,                             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      if (rc != hipSuccess) return (int)rc;                                                                       \
+      configured = true;                                                                                          \
+    }                                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<MODE, RPW, NCH>), dim3(grid), dim3(64 * LNB_WAVES), lds, s, dout, z, mean, rstd, gamma, \
+                       dz, (bf16_t*)dy, partials, rows, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev); \
+  } while (0)
+#define LN_BWD_NCH(MODE, RPW)                                    \
+  switch (d >> 8) {                                              \
+    case 1: LN_BWD_LAUNCH(MODE, RPW, 1); break;                  \
+    case 2: LN_BWD_LAUNCH(MODE, RPW, 2); break;                  \
+    case 3: LN_BWD_LAUNCH(MODE, RPW, 3); break;                  \
+    default: LN_BWD_LAUNCH(MODE, RPW, 4); break;                 \
+  }
+  if (drop_mode < 0 || drop_mode > 2) return MMT_ERR_ARG;
+  if (rpb == 16) {
+    if (drop_mode == 0) { LN_BWD_NCH(0, 2) } else if (drop_mode == 1) { LN_BWD_NCH(1, 2) } else { LN_BWD_NCH(2, 2) }
+  } else {
+    if (drop_mode == 0) { LN_BWD_NCH(0, 1) } else if (drop_mode == 1) { LN_BWD_NCH(1, 1) } else { LN_BWD_NCH(2, 1) }
+  }
+#undef LN_BWD_NCH
 #undef LN_BWD_LAUNCH
   return (int)hipGetLastError();
 }

@@ -161,3 +161,32 @@ class FlatParams:
     self._packed_versions = ver
     self._dirty = False
     return True
+
+  def shadows_fresh(self):
+    """Called by an optimizer that rewrote the bf16 shadows together with the weights (FlatAdam's fused step)."""
+    self._packed_versions = self._versions()
+    self._dirty = False
+
+  def adam_segments(self):
+    """The flat buffer as an ascending list of segments that tile [0, count): ('plain', offset, count) spans and
+    ('matrix', offset, shadow) entries, one per bf16 shadow (mmt_adam_step_fused).  None if a shadow cannot be
+    refreshed by the optimizer (odd column count, not allocated yet)."""
+    mats = []
+    for sh in self.shadows:
+      if sh['dst'] is None or sh['cols'] % 4 or (sh['transpose'] and sh['dst_t'] is None):
+        return None
+      mats.append((self.offsets[id(sh['params'][0])], sh))
+    mats.sort(key=lambda t: t[0])
+    segs, pos = [], 0
+    for off, sh in mats:
+      if off < pos:
+        return None  # overlapping shadows: not a partition
+      if off > pos:
+        segs.append(('plain', pos, off - pos))
+      segs.append(('matrix', off, sh))
+      pos = off + sh['rows'] * sh['cols']
+    if pos % 4:
+      return None
+    if pos < self.count:
+      segs.append(('plain', pos, self.count - pos))
+    return segs

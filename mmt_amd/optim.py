@@ -93,10 +93,51 @@ class FlatAdam:
     self.sync_lr()
     g = self._grad()
     self.step_dev.add_(1)
+    table = self._segment_table() if self.fuse_shadows else None
+    if table is not None:
+      # ONE launch: Adam over every segment of the flat buffer + the bf16 W / W^T shadows of the GEMM weights
+      host, dev, n = table
+      check(_lib.lib().mmt_adam_step_fused(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
+                                           host, ops._p(dev), n, float(self.lr), self.betas[0], self.betas[1], self.eps,
+                                           self.weight_decay, ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()),
+            'mmt_adam_step_fused')
+      f.shadows_fresh()
+      return
     check(_lib.lib().mmt_adam_step(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
                                    f.count, float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                    ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()), 'mmt_adam_step')
     f._dirty = True  # the bf16 shadows are stale now (the kernel wrote through raw pointers)
+
+  fuse_shadows = True
+  _seg_key = _seg_table = None
+
+  def _segment_table(self):
+    """(host ctypes array, device copy, n) of the flat buffer's segments for mmt_adam_step_fused, rebuilt when the
+    master or a shadow moved.  None: shadows not allocated yet / not refreshable -> plain step + lazy re-pack."""
+    from ._lib import MmtAdamSeg
+    f = self.flat
+    key = (f.master.data_ptr(),) + tuple((sh['dst'].data_ptr() if sh['dst'] is not None else 0) for sh in f.shadows)
+    if self._seg_key == key:
+      return self._seg_table
+    segs = f.adam_segments() if f.shadows else None
+    table = None
+    if segs is not None and 0 < len(segs) <= 160:
+      arr = (MmtAdamSeg * len(segs))()
+      for i, sg in enumerate(segs):
+        it = arr[i]
+        if sg[0] == 'plain':
+          it.offset, it.count = sg[1], sg[2]
+        else:
+          sh = sg[2]
+          it.offset, it.count = sg[1], sh['rows'] * sh['cols']
+          it.dst = sh['dst'].data_ptr()
+          it.dst_t = sh['dst_t'].data_ptr() if sh['transpose'] else None
+          it.rows, it.cols, it.dst_ld = sh['rows'], sh['cols'], sh['dst_ld']
+          it.dst_t_ld = sh['rows'] if sh['transpose'] else 0
+      raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+      table = (arr, raw.to(f.master.device), len(segs))
+    self._seg_key, self._seg_table = key, table
+    return table
 
 
 def build_optimizers(model, lr=5e-5, **kw):

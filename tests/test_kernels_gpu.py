@@ -100,6 +100,18 @@ def test_gemm_nt_fused_epilogues(tile):
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (777, 512, 192), (7168, 1536, 512)])
 def test_gemm_nt_wide_tiles(tile, M, N, K):
   """gemm2.hip (256x128 / 256x256 / 128x128 / 128x256 tiles, 32x32x16 MFMA, LDS-staged epilogue): every epilogue."""
+  _wide_tile_case(tile, M, N, K)
+
+
+@pytest.mark.parametrize('tile', [15, 16, 17])
+@pytest.mark.parametrize('M,N,K', [(300, 384, 128), (777, 576, 192), (3583, 3072, 512), (7168, 1536, 512)])
+def test_gemm_nt_192_wide_tiles(tile, M, N, K):
+  """gemm2.hip tiles with 192 output columns (256x192 / 128x192: N = 3072 and 1536 in ONE round of <= 256 tiles at
+  ~3600 live rows); the epilogue sweeps them as three 64-column blocks."""
+  _wide_tile_case(tile, M, N, K)
+
+
+def _wide_tile_case(tile, M, N, K):
   from mmt_amd import ops
   R = ops.pad_rows(M)
   a = _rand((R, K), seed=21, dtype=torch.bfloat16)
