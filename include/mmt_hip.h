@@ -383,18 +383,34 @@ typedef struct MmtTextHeads {
   float *g_bn_gamma[MMT_MAX_EXPERTS], *g_bn_beta[MMT_MAX_EXPERTS], *g_moe_w[MMT_MAX_EXPERTS], *g_moe_b[MMT_MAX_EXPERTS];
 } MmtTextHeads;
 int64_t mmt_text_heads_workspace_floats(int N, int M, int d);
+/* Optional extras of the small-batch path (mmt_text_heads_fast() != 0: N <= 32 caption rows, every training
+ * configuration of the reference), all nullable / zero:
+ *   moe_drop_*: nn.Dropout in front of the MoE logits (model.py:274) applied on the fly by the kernels that read the
+ *     text (pass text_moe = NULL): stream key = hash(moe_drop_key, *seed_dev) at forward time, stored in *key_dev and
+ *     re-read from there by the backward (which runs after the seed has moved on);
+ *   num_batches_tracked: int64 [M], += 1 per training forward with use_bn (BatchNorm1d bookkeeping, on the device). */
+typedef struct MmtTextHeadsOpts {
+  uint32_t moe_drop_key, moe_drop_thr16;
+  float moe_drop_scale;
+  int32_t reserved;
+  const uint32_t* seed_dev;
+  uint32_t* key_dev;
+  int64_t* num_batches_tracked;
+} MmtTextHeadsOpts;
+int mmt_text_heads_fast(int N, int M, int d, int K);
 /* text [N = B*C, K] -> text_embds (B, M, C, d) L2-normalised, text_weights (B, C, M) (NULL: txt_wgh='none').
  * use_bn: txt_pro 'gbn' (1) / 'gem' (0).  training: batch statistics + running-stat update.
  * text_moe (nullable): the copy of text the MoE branch reads (after moe_txt_dropout, model.py:274). */
 int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M, int d,
                        int K, int use_bn, int training, float* ws, float* text_embds, float* text_weights,
-                       void* stream);
+                       const MmtTextHeadsOpts* opts, void* stream);
 /* gradients are WRITTEN through the g_* pointers; dtext [N, K] (nullable) receives the gradient for the text
- * tower; w1_all = the M fc.weight matrices contiguous as [M*d, K]. */
+ * tower; w1_all = the M fc.weight matrices contiguous as [M*d, K].  dtext_moe [N, K] (nullable): gradient wrt the MoE
+ * branch's input (with the on-the-fly dropout: already masked, i.e. the gradient wrt text through that branch). */
 int mmt_text_heads_bwd(const MmtTextHeads* h, const float* text, const float* text_moe, const float* w1_all, int N,
                        int C, int M, int d, int K, int use_bn, int training, float* ws, const float* dtext_embds,
                        const float* text_weights, const float* dtext_weights, float* dtext, float* dtext_moe,
-                       void* stream);
+                       const MmtTextHeadsOpts* opts, void* stream);
 
 /* ---- whole-encoder engine (bert_engine.hip) --------------------------------------------------------
  * One call runs every kernel of model/bert.py BertModel.forward (bert.py:371-414, without the unused

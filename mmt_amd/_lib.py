@@ -99,6 +99,11 @@ class MmtTextHeads(ctypes.Structure):
   _fields_ = [(n, _PTR16) for n in _TEXT_HEAD_FIELDS]
 
 
+class MmtTextHeadsOpts(ctypes.Structure):
+  _fields_ = [('moe_drop_key', c_u32), ('moe_drop_thr16', c_u32), ('moe_drop_scale', c_f32), ('reserved', ctypes.c_int32),
+              ('seed_dev', c_vp), ('key_dev', c_vp), ('num_batches_tracked', c_vp)]
+
+
 EPI = dict(BF16=0, BIAS_BF16=1, BIAS_GELU=2, BIAS_DROP_RES=3, DGELU=4, ADD_F32=5, F32=6, BIAS_F32=7)
 
 # name -> (restype, argtypes); must list every symbol declared in include/mmt_hip.h
@@ -186,10 +191,12 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_vp]),
     'mmt_sgemm_batched': (c_int, [ctypes.POINTER(MmtSgemm), c_vp]),
     'mmt_text_heads_workspace_floats': (c_i64, [c_int, c_int, c_int]),
+    'mmt_text_heads_fast': (c_int, [c_int, c_int, c_int, c_int]),
     'mmt_text_heads_fwd': (c_int, [ctypes.POINTER(MmtTextHeads), c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_vp, c_vp, c_vp, c_vp]),
+                                   c_int, c_vp, c_vp, c_vp, ctypes.POINTER(MmtTextHeadsOpts), c_vp]),
     'mmt_text_heads_bwd': (c_int, [ctypes.POINTER(MmtTextHeads), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                   c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtTextHeadsOpts),
+                                   c_vp]),
     'mmt_probe_arm': (c_int, [c_vp, c_vp, c_int]),
     'mmt_probe_count': (c_int, []),
 }

@@ -7,6 +7,7 @@
 //   moe           : softmax_m(text . w_m + b_m)
 // and the matching backward kernels.  Activations are [N, M, d] (row n contiguous over experts) so that
 // the text gradient is ONE GEMM over K = M*d.  Arithmetic is fp32 like the reference (the work is ~0.3 GFLOP).
+#include <stdlib.h>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -333,16 +334,38 @@ static int check_heads(const MmtTextHeads* h, const float* text, int N, int M, i
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-// ws layout (floats): y [N*M*d] | x1 [N*M*d] | mean [M*d] | rstd [M*d] | dyg [N*M*d] | dz [N*M*d] | dlogit [N*M]
+// ws layout (floats): y [N*M*d] | x1 [N*M*d] | mean [M*d] | rstd [M*d] | dyg [N*M*d] | dz [N*M*d] | dlogit [N*M] |
+//                     (small-batch path, texthead2.hip) sigmoid gate [N*M*d] | un-normalised output [N*M*d] | row partials
 extern "C" int64_t mmt_text_heads_workspace_floats(int N, int M, int d) {
-  return 4LL * N * M * d + 2LL * M * d + (int64_t)N * M + 64;
+  return 6LL * N * M * d + 2LL * M * d + (((int64_t)N * M + 63) & ~63LL) + (int64_t)N * M * ((d + 31) / 32) + 64;
 }
+
+// texthead2.hip: N <= 32 rows in 3 + 3 launches
+int mmt_text_heads_fwd_small(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M, int d,
+                             int K, int use_bn, int training, float* ws, float* text_embds, float* text_weights,
+                             const MmtTextHeadsOpts* opts, hipStream_t s);
+int mmt_text_heads_bwd_small(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M, int d,
+                             int K, int use_bn, int training, float* ws, const float* dtext_embds, const float* text_weights,
+                             const float* dtext_weights, float* dtext_moe, const MmtTextHeadsOpts* opts, hipStream_t s);
+static bool small_path(int N, int M, int d, int K) {
+  static int off = -1;
+  if (off < 0) off = getenv("MMT_TEXT_HEADS_V1") ? 1 : 0;  // lab switch: the one-kernel-per-op path
+  return !off && mmt_text_heads_fast(N, M, d, K);
+}
+static bool fused_dropout(const MmtTextHeadsOpts* o, const float* text_moe) { return o && o->moe_drop_thr16 && !text_moe; }
 
 extern "C" int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, const float* text_moe, int N, int C, int M,
                                   int d, int K, int use_bn, int training, float* ws, float* text_embds,
-                                  float* text_weights, void* stream) {
+                                  float* text_weights, const MmtTextHeadsOpts* opts, void* stream) {
   TRY(check_heads(h, text, N, M, d, K));
   if (!ws || !text_embds || C <= 0 || N % C) return MMT_ERR_ARG;
+  if (text_weights)
+    for (int m = 0; m < M; ++m)
+      if (!h->moe_w[m] || !h->moe_b[m]) return MMT_ERR_ARG;
+  if (small_path(N, M, d, K))
+    return mmt_text_heads_fwd_small(h, text, text_moe, N, C, M, d, K, use_bn, training, ws, text_embds, text_weights, opts,
+                                    (hipStream_t)stream);
+  if (fused_dropout(opts, text_moe) || (opts && opts->num_batches_tracked)) return MMT_ERR_ARG;  // small-batch path only
   const int64_t nmd = (int64_t)N * M * d;
   float *y = ws, *x1 = ws + nmd, *mean = ws + 2 * nmd, *rstd = mean + (int64_t)M * d;
   hipStream_t s = (hipStream_t)stream;
@@ -376,13 +399,30 @@ extern "C" int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, cons
 extern "C" int mmt_text_heads_bwd(const MmtTextHeads* h, const float* text, const float* text_moe, const float* w1_all,
                                   int N, int C, int M, int d, int K, int use_bn, int training, float* ws,
                                   const float* dtext_embds, const float* text_weights, const float* dtext_weights,
-                                  float* dtext, float* dtext_moe, void* stream) {
+                                  float* dtext, float* dtext_moe, const MmtTextHeadsOpts* opts, void* stream) {
   TRY(check_heads(h, text, N, M, d, K));
   if (!ws || !dtext_embds || C <= 0 || N % C) return MMT_ERR_ARG;
   const int64_t nmd = (int64_t)N * M * d;
   float *y = ws, *x1 = ws + nmd, *mean = ws + 2 * nmd, *rstd = mean + (int64_t)M * d;
   float *dyg = rstd + (int64_t)M * d, *dz = dyg + nmd, *dlogit = dz + nmd;
   hipStream_t s = (hipStream_t)stream;
+  if (small_path(N, M, d, K)) {
+    // the masked MoE-input gradient needs its own buffer when the dropout is applied on the fly
+    if (fused_dropout(opts, text_moe) && dtext && !dtext_moe) return MMT_ERR_ARG;
+    if (dtext && !w1_all) return MMT_ERR_ARG;
+    TRY(mmt_text_heads_bwd_small(h, text, text_moe, N, C, M, d, K, use_bn, training, ws, dtext_embds, text_weights,
+                                 dtext_weights, dtext_moe, opts, s));
+    if (dtext) {  // dtext = dy_all [N, M*d] . W1_all [M*d, K]   (dyg holds dy after th_bwd3)
+      MmtSgemm t = {};
+      t.batch = 1; t.M = N; t.N = K; t.K = M * d; t.sai = (int64_t)M * d; t.sak = 1; t.sbj = 1; t.sbk = K; t.ldc = K;
+      t.A[0] = dyg; t.B[0] = w1_all; t.C[0] = dtext;
+      TRY(mmt_sgemm_batched(&t, stream));
+      if (text_weights && dtext_weights && !dtext_moe)  // no separate MoE input: its gradient joins dtext
+        hipLaunchKernelGGL(moe_bwd_row_kernel, dim3(N), dim3(256), 0, s, text_weights, dtext_weights, K, M, *h, dlogit, dtext, 1);
+    }
+    return (int)hipGetLastError();
+  }
+  if (fused_dropout(opts, text_moe)) return MMT_ERR_ARG;  // small-batch path only
   int gb = (N * M + 3) / 4;
   if (gb > 2048) gb = 2048;
   hipLaunchKernelGGL(gate_norm_kernel<true>, dim3(gb), dim3(256), 0, s, y, x1, mean, rstd, *h, N, M, d, C, use_bn, nullptr,

@@ -10,8 +10,11 @@ What runs where:
   * video side -- ReduceDim per expert, token assembly, video BERT, expert read-out + L2 norm
     (model/model.py:426-437, 485-587, 621-625): libmmt_hip.so, forward and backward;
   * similarity (model/model.py:789-837) and the losses: libmmt_hip.so;
-  * text tower (HF BertModel, third party) and the small text heads (GatedEmbeddingUnit, MoE weights,
-    model/model.py:229-283, 683-750): stock PyTorch-ROCm ops on the GPU (SURVEY.md section 8f.2 = next row).
+  * text heads (GatedEmbeddingUnit per expert, text MoE weights, model/model.py:229-283, 683-750): libmmt_hip.so
+    (texthead.hip / texthead2.hip), forward and backward, fp32 on the exact-fp32 matrix cores;
+  * text tower: `mmt_amd.text_bert.TextBertModel` on the same engine (HF parameter names; txt_bert='native' or a
+    pretrained HF BertModel moved over by TextBertModel.from_hf); a foreign `txt_bert` module is accepted and then runs as
+    stock PyTorch-ROCm outside the native path.
 Only the configuration every published config uses is implemented natively (vid_cont='bert',
 vid_inp='both', out_tok='mxp', pos_enc='tint'|'none', vid_wgh='none', keep_missing_modalities=True);
 anything else raises NotImplementedError instead of silently taking a slow path.
@@ -26,7 +29,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, ops
-from ._lib import MmtExpertIO, MmtTextHeads, check
+from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, check
 from .bert import BertModel, EngineBatch
 from .flat import FlatParams
 
@@ -178,9 +181,10 @@ class _TextHeadsFn(torch.autograd.Function):
   (model.py:413-417, 683-750) and the text MoE softmax (model.py:262-283, 610-618) in one native pass."""
 
   @staticmethod
-  def forward(ctx, net, text, text_moe, caps, *params):
+  def forward(ctx, net, text, text_moe, caps, moe_drop_p, *params):
+    """moe_drop_p > 0 (text_moe None): moe_txt_dropout (model.py:274) is applied on the fly inside the kernels."""
     tm = None if text_moe is None else text_moe.detach().contiguous().float()
-    out = net._text_heads_forward(text.detach().contiguous().float(), tm, caps)
+    out = net._text_heads_forward(text.detach().contiguous().float(), tm, caps, moe_drop_p)
     ctx.net, ctx.caps, ctx.generation, ctx.training = net, caps, net._th_generation, net.training
     ctx.need_dtext = text.requires_grad
     ctx.need_dmoe = text_moe is not None and text_moe.requires_grad
@@ -192,7 +196,7 @@ class _TextHeadsFn(torch.autograd.Function):
     if net._th_generation != ctx.generation:
       raise RuntimeError('mmt_amd.CENet: text-head buffers were overwritten by a later forward')
     dtext, dmoe, grads = net._text_heads_backward(ctx.caps, de, dtw, ctx.need_dtext, ctx.need_dmoe, ctx.training)
-    return (None, dtext, dmoe, None) + tuple(grads)
+    return (None, dtext, dmoe, None, None) + tuple(grads)
 
 
 def cross_view_similarity(vid_embds, text_embds, vid_weights, text_weights, merge='avg'):
@@ -552,7 +556,25 @@ class CENet(nn.Module):
       h.running_var[i] = bn.running_var.data_ptr()
     return h
 
-  def _text_heads_forward(self, text, text_moe, caps):
+  def _text_heads_fast(self, n, k):
+    """True iff the small-batch kernels (3 + 3 launches, texthead2.hip) serve n caption rows of width k."""
+    return bool(_lib.lib().mmt_text_heads_fast(n, len(self.modalities), self.same_dim, k))
+
+  def _text_heads_opts(self, moe_drop_p, nbt):
+    o = MmtTextHeadsOpts()
+    if moe_drop_p > 0.0:
+      if self._th_key is None or self._th_key.device != self.vid_bert._seed_dev.device:
+        self._th_key = torch.zeros(1, dtype=torch.int32, device=self.vid_bert._seed_dev.device)
+      o.moe_drop_key = _MoeDropoutFn.SITE_KEY
+      o.moe_drop_thr16, o.moe_drop_scale = ops.dropout_params(moe_drop_p)
+      o.seed_dev, o.key_dev = self.vid_bert._seed_dev.data_ptr(), self._th_key.data_ptr()
+    if nbt is not None:
+      o.num_batches_tracked = nbt.data_ptr()
+    return o
+
+  _th_key = None
+
+  def _text_heads_forward(self, text, text_moe, caps, moe_drop_p=0.0):
     n, k = text.shape
     m, d = len(self.modalities), self.same_dim
     L = _lib.lib()
@@ -563,6 +585,10 @@ class CENet(nn.Module):
     self._th_generation += 1
     self._th_text, self._th_text_moe = text, text_moe
     use_bn = int(self.txt_pro == 'gbn')
+    fast = self._text_heads_fast(n, k)
+    if moe_drop_p > 0.0 and not fast:
+      raise RuntimeError('on-the-fly MoE dropout needs the small-batch text-head kernels')
+    nbt = None
     if self.training and use_bn:
       if n <= 1:
         raise ValueError('Expected more than 1 value per channel when training')  # as nn.BatchNorm1d does
@@ -573,12 +599,16 @@ class CENet(nn.Module):
         self._nbt = torch.tensor(vals, dtype=torch.long, device=text.device)
         for i, mod in enumerate(self.modalities):
           self.text_GU[mod].cg.batch_norm.num_batches_tracked.data = self._nbt[i]
-      self._nbt.add_(1)
+      if fast:
+        nbt = self._nbt  # incremented by the BatchNorm kernel itself (one launch less per step)
+      else:
+        self._nbt.add_(1)
     embds = torch.empty(n // caps, m, caps, d, device=text.device, dtype=torch.float32)
     tw = torch.empty(n // caps, caps, m, device=text.device, dtype=torch.float32) if self.txt_wgh == 'emb' else None
     h = self._text_heads_struct(None)
+    self._th_opts = self._text_heads_opts(moe_drop_p, nbt)
     check(L.mmt_text_heads_fwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), n, caps, m, d, k, use_bn, int(self.training), ops._p(ws),
-                               ops._p(embds), ops._p(tw), ops._stream()), 'mmt_text_heads_fwd')
+                               ops._p(embds), ops._p(tw), ctypes.byref(self._th_opts), ops._stream()), 'mmt_text_heads_fwd')
     if tw is None:
       tw = torch.full((n // caps, caps, m), 1.0 / m, device=text.device)  # ones, L1-normalised (model.py:612,618)
     self._th_tw = tw
@@ -595,11 +625,20 @@ class CENet(nn.Module):
     dmoe = torch.empty_like(text) if (need_dmoe and text_moe is not None) else None
     w1_all = self._flat.ptr(self.text_GU[self.modalities[0]].fc.weight)
     has_moe = self.txt_wgh == 'emb'
+    opts = self._th_opts
+    fused_drop = opts.moe_drop_thr16 != 0 and text_moe is None
+    # on-the-fly MoE dropout: the (masked) gradient through the MoE branch arrives in its own buffer and joins dtext
+    dmoe_fused = torch.empty_like(text) if (fused_drop and need_dtext and has_moe) else None
+    bwd_opts = MmtTextHeadsOpts.from_buffer_copy(opts)
+    bwd_opts.num_batches_tracked = None
     check(L.mmt_text_heads_bwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), ctypes.c_void_p(w1_all), n, caps, m, d, k,
                                int(self.txt_pro == 'gbn'), int(training), ops._p(self._th_ws[(n, text.device)]),
                                ops._p(de.contiguous()), ops._p(self._th_tw) if has_moe else None,
                                ops._p(dtw.contiguous()) if has_moe and dtw is not None else None, ops._p(dtext),
-                               ops._p(dmoe), ops._stream()), 'mmt_text_heads_bwd')
+                               ops._p(dmoe_fused if dmoe_fused is not None else dmoe), ctypes.byref(bwd_opts), ops._stream()),
+          'mmt_text_heads_bwd')
+    if dmoe_fused is not None and dtw is not None:
+      dtext.add_(dmoe_fused)
     grads = [self._flat.view(p, grad_buf) if p.requires_grad else None for p in self._text_head_params()]
     return dtext, dmoe, grads
 
@@ -652,14 +691,16 @@ class CENet(nn.Module):
           side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
       with torch.cuda.stream(side if side is not None else cur):
-        text_moe = None
+        text_moe, moe_drop_p = None, 0.0
         if self.txt_wgh == 'emb' and self.training and self.moe_txt_dropout.training and self.moe_txt_dropout.p > 0:
           # model.py:274: dropout only in front of the MoE logits
-          if text.numel() % 4 == 0 and self.vid_bert._seed_dev is not None:
+          if self.vid_bert._seed_dev is not None and self._text_heads_fast(text.shape[0], text.shape[1]):
+            moe_drop_p = float(self.moe_txt_dropout.p)  # applied on the fly by the text-head kernels
+          elif text.numel() % 4 == 0 and self.vid_bert._seed_dev is not None:
             text_moe = _MoeDropoutFn.apply(text, self.moe_txt_dropout.p, self.vid_bert._seed_dev)
           else:
             text_moe = self.moe_txt_dropout(text)
-        text_embds, text_weights = _TextHeadsFn.apply(self, text, text_moe, c, *self._text_head_params())
+        text_embds, text_weights = _TextHeadsFn.apply(self, text, text_moe, c, moe_drop_p, *self._text_head_params())
     else:
       text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417
       tv = text.view(b, c, -1)
