@@ -63,13 +63,14 @@ def encoder_flops_per_step(batch, seq):
 
 
 class KernelProbe:
-  """HIP events around the dominant kernel's launch inside the timed steps (engine hook mmt_probe_arm)."""
+  """HIP events around one launch per step of a kernel family, recorded on the launch stream by the engine
+  (mmt_probe_arm_site): site 0 = FFN up-projection GEMM, 1 = FFN down-projection GEMM, 2 = grouped weight gradients."""
 
-  def __init__(self, n):
+  def __init__(self, n, site=0):
     import ctypes
 
     from mmt_amd import _lib
-    self.n = n
+    self.n, self.site = n, site
     self.start = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
     self.stop = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
     for e in self.start + self.stop:
@@ -78,60 +79,72 @@ class KernelProbe:
     self._a = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.start])
     self._b = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.stop])
     self._lib = _lib.lib()
-    self._lib.mmt_probe_arm(self._a, self._b, n)
+    self._lib.mmt_probe_arm_site(site, self._a, self._b, n)
 
   def finish(self, stride=1, offset=0):
     """stride/offset: with the native text tower every step runs TWO encoder forwards (text first, then video): the
     video tower's launches are the odd ones."""
-    used = self._lib.mmt_probe_count()
-    self._lib.mmt_probe_arm(None, None, 0)
+    used = self._lib.mmt_probe_count_site(self.site)
+    self._lib.mmt_probe_arm_site(self.site, None, None, 0)
     ms = [self.start[i].elapsed_time(self.stop[i]) for i in range(offset, used, stride)]
     return sum(ms) / max(1, len(ms)) * 1e-3, len(ms)
 
 
-def time_dominant_kernel(rows, iters=40):
-  """Dominant kernel = the bf16 MFMA NT GEMM (FFN up-projection shape: rows x 3072 x 512, bias+GELU
-  epilogue).  Timed alone with HIP events on the launch stream; algorithmic flops = 2*rows*I*d."""
-  dev = torch.device('cuda')
-  R = ops.pad_rows(rows)
-  a = (torch.randn(R, HIDDEN, device=dev)).to(torch.bfloat16)
-  w = (torch.randn(INTER, HIDDEN, device=dev) * 0.05).to(torch.bfloat16)
-  bias = torch.randn(INTER, device=dev)
-  out = torch.empty(R, INTER, device=dev, dtype=torch.bfloat16)
-  out2 = torch.empty_like(out)
-  for _ in range(5):
-    ops.gemm_nt(a, w, out, 'BIAS_GELU', m=rows, bias=bias, out2=out2)
-  torch.cuda.synchronize()
-  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  s.record()
-  for _ in range(iters):
-    ops.gemm_nt(a, w, out, 'BIAS_GELU', m=rows, bias=bias, out2=out2)
-  e.record()
-  torch.cuda.synchronize()
-  sec = s.elapsed_time(e) * 1e-3 / iters
-  flops = 2.0 * rows * INTER * HIDDEN
-  return dict(bound='mfma', achieved=flops / sec / 1e12, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
-              frac=flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, traffic=None,
-              kernel='gemm2_kernel<128,128,2x4 waves,NS2,BIAS_GELU> rows=%d N=%d K=%d' % (rows, INTER, HIDDEN),
-              avg_launch_us=sec * 1e6)
+PMC_CSV = os.path.join('profiles', 'r02_pmc_kernels.csv')
 
 
-def pmc_traffic(kernel_sub='gemm2_kernel<128, 128, 2, 4, 2, 2', grid_sub='[grid 1320 '):
-  """HBM traffic of the dominant kernel per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_kernels.csv,
-  separate --pmc runs of this same command): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a
-  wide coalesced read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
+def pmc_traffic(kernel_subs, grid_sub):
+  """HBM traffic per launch of a kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this same command,
+  tools/final_profiles.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a wide coalesced
+  read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
   import csv
-  path = os.path.join(ROOT, 'profiles', 'r01_pmc_kernels.csv')
+  path = os.path.join(ROOT, PMC_CSV)
   if not os.path.exists(path):
     return None
   with open(path) as f:
     for row in csv.DictReader(f):
-      if kernel_sub in row['kernel'] and grid_sub in row['kernel']:
+      if any(k in row['kernel'] for k in kernel_subs) and grid_sub in row['kernel']:
         try:
           return (2.0 * float(row['FETCH_SIZE']) + float(row['WRITE_SIZE'])) * 1024.0
         except (KeyError, ValueError):
           return None
   return None
+
+
+def site_roofline(site, rows, sec, used):
+  """Roofline entry of a probed kernel family: algorithmic FLOPs of ONE launch at `rows` live token rows / its average
+  HIP-event duration inside real training steps, against the dense bf16 MFMA peak (the more demanding roof: the
+  algorithmic bytes of these GEMMs at ~5 TB/s would take 30-45 % of the measured time)."""
+  d, i = HIDDEN, INTER
+  if site == 0:
+    name, flops = 'FFN up-projection GEMM + bias + erf-GELU (N=%d, K=%d; gemm2_kernel, EPI BIAS_GELU)' % (i, d), 2.0 * rows * i * d
+    nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
+    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2'], '[grid '
+  elif site == 1:
+    name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64>, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
+    nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
+    subs, grid = ['gemm2_kernel<128, 64, 4, 2, 3, 3'], '[grid 440 '
+  else:
+    name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_grouped_kernel)'
+    flops = 2.0 * rows * (2 * i * d + 4 * d * d)
+    nbytes = rows * (2 * i + 6 * d) * 2 + (2 * i * d + 4 * d * d) * 4
+    subs, grid = ['wgrad_grouped_kernel'], '[grid 256 '
+  tf = flops / sec / 1e12
+  return dict(kernel=name, bound='mfma', achieved=tf, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
+              frac=tf / BF16_DENSE_PEAK_TFLOPS, flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes,
+              hbm_frac_of_8TBps=nbytes / sec / 8e12, avg_launch_us=sec * 1e6, launches_timed=used,
+              traffic=pmc_traffic(subs, grid), traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV)
+
+
+def executed_flops_per_step(batch, live_rows, seq_lens_sq_sum, m_experts):
+  """Encoder FLOPs actually executed with token packing + last-layer row elimination (fwd; x3 for fwd+bwd):
+  L-1 full layers on the live rows, the last layer's QKV projection on the live rows and the rest of it on the B*M
+  read-out rows only; attention over the live keys of every sample."""
+  d, i = HIDDEN, INTER
+  full = live_rows * (8 * d * d + 4 * d * i) + 4 * seq_lens_sq_sum * d
+  tail_rows = batch * m_experts
+  last = live_rows * 6 * d * d + tail_rows * (2 * d * d + 4 * d * i) + 4 * tail_rows * (live_rows / batch) * d
+  return 3.0 * ((LAYERS - 1) * full + last)
 
 
 def cpu_baseline(steps=6):
@@ -178,6 +191,11 @@ def main():
   ap.add_argument('--force-collectives', action='store_true',
                   help='N=1 only: run the all-gather / all-reduce plumbing on a 1-rank RCCL group (measures its overhead)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
+  ap.add_argument('--no-dense', action='store_true', help='skip the second (unpacked) timing of the same step')
+  ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default='fp32',
+                  help='wire format of the gradient all-reduces at N > 1 (bf16: half the bytes over xGMI)')
+  ap.add_argument('--comm-log', action='store_true',
+                  help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -198,15 +216,17 @@ def main():
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if args.comm_log:
+      os.environ['NCCL_DEBUG'] = 'INFO'
+      os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,COLL,TUNING')
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
 
-  torch.manual_seed(0)
-  model = build_model(pack=not args.dense, text_tower=args.text_tower).to(dev).train()
-  mdist.broadcast_parameters(model)
   loss_fn = MaxMarginRankingLoss(margin=0.05, fix_norm=True)
+  seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
+  grad_dtype = torch.bfloat16 if args.grad_dtype == 'bf16' else None
 
   # NBATCH different synthetic minibatches resident in HBM; each step copies one (device-to-device) into
   # the static input buffers of the captured graphs.
@@ -217,54 +237,80 @@ def main():
     mb['text'] = text.view(-1, 768)
     # one contiguous buffer per minibatch (HBM, or pinned host memory with --host-inputs): load = ONE copy
     batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
-  static = FlatMinibatch(batches[0], dev)
-  if args.text_tower == 'synthetic':
-    model.txt_bert.text = static['text']
-  seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
-  runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
-                            overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
-                            force_collectives=args.force_collectives)
-  it = 0
-  first_loss = None
-  for _ in range(args.warmup):
-    runner.load(batches[it % NBATCH]); it += 1
-    l = runner.step()
-    if first_loss is None:
-      first_loss = float(l.item())  # loss of the first replayed step (after the runner's own eager warm-up steps)
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    runner.load(batches[it % NBATCH]); it += 1
-    loss = runner.step()
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
-  final_loss = float(loss.item())
 
-  # dominant-kernel duration: HIP events around its launch (engine probe) in eager steps of the same
-  # workload right after the timed region (events cannot be read back from inside a graph replay)
+  def timed_run(pack, steps, warmup):
+    """Builds the model + captured step for one token layout and times `steps` steps as the contract prescribes
+    (barrier + synchronize on both sides, MAX over ranks).  -> dict(model, runner, elapsed, first_loss, final_loss)"""
+    torch.manual_seed(0)
+    model = build_model(pack=pack, text_tower=args.text_tower).to(dev).train()
+    mdist.broadcast_parameters(model)
+    static = FlatMinibatch(batches[0], dev)
+    if args.text_tower == 'synthetic':
+      model.txt_bert.text = static['text']
+    runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
+                              overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
+                              force_collectives=args.force_collectives, grad_dtype=grad_dtype)
+    it, first = 0, None
+    for _ in range(warmup):
+      runner.load(batches[it % NBATCH]); it += 1
+      l = runner.step()
+      if first is None:
+        first = float(l.item())  # loss of the FIRST optimisation step (the runner's warm-up does not train)
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      runner.load(batches[it % NBATCH]); it += 1
+      loss = runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      elapsed = t.item()
+    return dict(model=model, runner=runner, elapsed=elapsed, first_loss=first, final_loss=float(loss.item()), it=it)
+
+  main_run = timed_run(not args.dense, args.steps, args.warmup)
+  model, runner, elapsed, it = main_run['model'], main_run['runner'], main_run['elapsed'], main_run['it']
+  main_first, main_final = main_run['first_loss'], main_run['final_loss']
+
+  # Kernel-family durations: HIP events around one launch per step of the three kernel families that lead the rocprof
+  # time table, recorded by the engine on the launch stream in eager steps of the same workload right after the timed
+  # region (events cannot be read back from inside a graph replay).
   probe_steps = 8
   towers = 2 if args.text_tower == 'native' else 1
-  probe = KernelProbe(probe_steps * towers) if rank == 0 else None
-  live_rows = []
+  sites = [0, 1, 2] if towers == 1 else [0]
+  probes = {st: KernelProbe(probe_steps * towers, st) for st in sites} if rank == 0 else {}
+  live_rows, sq_sums = [], []
   plan0 = model._plans[next(iter(model._plans))]
   for _ in range(probe_steps):
     runner.load(batches[it % NBATCH]); it += 1
-    runner._eager_step()
+    runner.eager_step()
     live_rows.append(int(plan0.n_rows.item()))
+    cu = plan0.cu.to(torch.float64)
+    sq_sums.append(float(((cu[1:] - cu[:-1]) ** 2).sum().item()) if not args.dense else float(BATCH * seq * seq))
   torch.cuda.synchronize()
+  site_times = {st: pr.finish(stride=towers, offset=towers - 1) for st, pr in probes.items()}
+  staged = runner.staged
+  del runner, model, main_run
+
+  # the fill-independent figure in the same invocation: the same step WITHOUT token packing (every padded token computed)
+  dense_run = None
+  if not args.dense and not args.no_dense and world == 1 and not args.eager:
+    dense_run = timed_run(False, max(10, args.steps // 2), max(3, args.warmup // 2))
+    dense_ms = dense_run['elapsed'] / max(10, args.steps // 2) * 1e3
+    dense_run = dict(ms_per_step=dense_ms, pairs_per_s=BATCH / dense_ms * 1e3)
 
   if rank == 0:
     live = int(round(sum(live_rows) / len(live_rows)))  # mean live token rows per launch over the probe steps
+    dense_rows = BATCH * seq
     pairs_per_s = world * BATCH * args.steps / elapsed
     flops = encoder_flops_per_step(BATCH, seq)
+    rows = live if not args.dense else dense_rows
+    executed = executed_flops_per_step(BATCH, rows, sum(sq_sums) / len(sq_sums), len(synthetic.MSRVTT_MODALITIES))
     out = {
         'metric': 'video-text pairs/sec (fwd+bwd+Adam), MSRVTT 7-expert d512 L4', 'value': pairs_per_s,
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -275,22 +321,32 @@ def main():
                                ('text tower replaced by synthetic (B,768) vectors' if args.text_tower == 'synthetic' else
                                 'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
                    'global_batch': world * BATCH, 'seq_len': seq,
-                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager, 'inputs': 'pinned host, uploaded every step' if args.host_inputs else 'resident in HBM', 'text_tower': args.text_tower, 'grad_sync': 'staged' if runner.staged else 'single',
-                   'live_rows_rank0': live, 'dense_rows': BATCH * seq},
+                   'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager,
+                   'inputs': 'pinned host, uploaded every step' if args.host_inputs else 'resident in HBM',
+                   'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
+                   'grad_wire_dtype': args.grad_dtype,
+                   'live_rows_rank0': live, 'dense_rows': dense_rows},
+        # fraction of the (B, S) token grid that holds a real token in the synthetic batches (valid length ~ U{0..30}
+        # per expert); the packed step computes only those, the dense step all of them.  The fill of real
+        # MSRVTT features is unknown here (no dataset): `dense` below is the fill-independent number.
+        'fill_fraction': live / dense_rows,
+        'dense': dense_run,
         'encoder_dense_tflops': pairs_per_s / BATCH * flops / 1e12 / world,
         'encoder_dense_mfma_frac': pairs_per_s / BATCH * flops / 1e12 / world / BF16_DENSE_PEAK_TFLOPS,
-        'first_loss': first_loss, 'final_loss': final_loss,
+        'executed_tflops': pairs_per_s / BATCH * executed / 1e12 / world,
+        'executed_mfma_frac': pairs_per_s / BATCH * executed / 1e12 / world / BF16_DENSE_PEAK_TFLOPS,
+        'first_loss': main_first, 'final_loss': main_final,
     }
-    rows = live if not args.dense else BATCH * seq
-    sec, used = probe.finish(stride=towers, offset=towers - 1)
-    kflops = 2.0 * rows * INTER * HIDDEN
-    alone = time_dominant_kernel(rows)
-    out['roofline'] = dict(bound='mfma', achieved=kflops / sec / 1e12, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
-                           frac=kflops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS,
-                           traffic=pmc_traffic() if not args.dense else None,
-                           traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_kernels.csv)',
-                           kernel=alone['kernel'], avg_launch_us=sec * 1e6, launches_timed=used,
-                           standalone_us=alone['avg_launch_us'])
+    tops = [site_roofline(st, rows, sec, used) for st, (sec, used) in sorted(site_times.items()) if used]
+    # `roofline`: the family with the largest share of the step (each of the three runs once per full layer, i.e.
+    # LAYERS - 1 times per step with the compact last layer); `roofline_top3`: all three, same accounting
+    for r in tops:
+      r['launches_per_step'] = LAYERS - 1
+      r['share_of_step'] = (LAYERS - 1) * r['avg_launch_us'] * 1e-3 / (elapsed / args.steps * 1e3)
+    tops.sort(key=lambda r: -r['share_of_step'])
+    if tops:
+      out['roofline'] = tops[0]
+      out['roofline_top3'] = tops
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

@@ -199,6 +199,8 @@ SIGNATURES = {
                                    c_vp]),
     'mmt_probe_arm': (c_int, [c_vp, c_vp, c_int]),
     'mmt_probe_count': (c_int, []),
+    'mmt_probe_arm_site': (c_int, [c_int, c_vp, c_vp, c_int]),
+    'mmt_probe_count_site': (c_int, [c_int]),
 }
 
 _lib = None

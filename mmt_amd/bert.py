@@ -236,6 +236,12 @@ class BertModel(nn.Module):
         self._flat.select_grad_buffer()
     if self._seed_dev is None or self._seed_dev.device != torch.device(device):
       seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+      # data-parallel replicas draw INDEPENDENT dropout masks (the reference's replicas each run their own RNG stream,
+      # trainer/trainer.py:134): the masks are keyed on rank-local coordinates, so the rank is folded into the seed --
+      # identical torch seeds on every rank (bench.py, a trainer calling torch.manual_seed) no longer mean identical masks
+      import torch.distributed as dist
+      if dist.is_available() and dist.is_initialized():
+        seed = (seed + 0x3C6EF372 * (dist.get_rank() + 1)) % (2 ** 31 - 1)
       self._seed_dev = torch.tensor([seed], dtype=torch.int32, device=device)
 
   def _struct(self, grad_buf):

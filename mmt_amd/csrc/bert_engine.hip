@@ -91,11 +91,25 @@ int check_model(const MmtBertModel* m, const MmtBertBatch* b) {
   return 0;
 }
 
-// Profiling probe (bench.py): HIP events recorded around ONE launch of the dominant kernel (layer 0's
-// FFN up-projection GEMM) per forward, on the launch stream, until the armed event pairs are used up.
-hipEvent_t* g_probe_start = nullptr;
-hipEvent_t* g_probe_stop = nullptr;
-int g_probe_n = 0, g_probe_i = 0;
+// Profiling probes (bench.py): HIP events recorded on the launch stream around ONE launch per step of the three kernel
+// families that lead the rocprof time table -- site 0: FFN up-projection GEMM (+GELU) of layer 0, site 1: FFN
+// down-projection GEMM (N = hidden, K = intermediate; + bias/dropout/residual) of layer 0, site 2: the grouped
+// weight-gradient launch of layer 0 -- until the armed event pairs of a site are used up.
+enum { PROBE_SITES = 3 };
+hipEvent_t* g_probe_start[PROBE_SITES] = {};
+hipEvent_t* g_probe_stop[PROBE_SITES] = {};
+int g_probe_n[PROBE_SITES] = {}, g_probe_i[PROBE_SITES] = {};
+
+struct ProbeScope {
+  int site; hipStream_t s; bool on;
+  ProbeScope(int site_, bool cond, void* stream) : site(site_), s((hipStream_t)stream) {
+    on = cond && g_probe_i[site] < g_probe_n[site];
+    if (on) (void)hipEventRecord(g_probe_start[site][g_probe_i[site]], s);
+  }
+  ~ProbeScope() {
+    if (on) (void)hipEventRecord(g_probe_stop[site][g_probe_i[site]++], s);
+  }
+};
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -108,14 +122,19 @@ int tail_rows(const MmtBertBatch* b, const Ws& w) {
 
 }  // namespace
 
-extern "C" int mmt_probe_arm(void** start_events, void** stop_events, int n) {
-  g_probe_start = (hipEvent_t*)start_events;
-  g_probe_stop = (hipEvent_t*)stop_events;
-  g_probe_n = (start_events && stop_events) ? n : 0;
-  g_probe_i = 0;
+extern "C" int mmt_probe_arm_site(int site, void** start_events, void** stop_events, int n) {
+  if (site < 0 || site >= PROBE_SITES) return MMT_ERR_ARG;
+  g_probe_start[site] = (hipEvent_t*)start_events;
+  g_probe_stop[site] = (hipEvent_t*)stop_events;
+  g_probe_n[site] = (start_events && stop_events) ? n : 0;
+  g_probe_i[site] = 0;
   return 0;
 }
-extern "C" int mmt_probe_count(void) { return g_probe_i; }
+extern "C" int mmt_probe_arm(void** start_events, void** stop_events, int n) {
+  return mmt_probe_arm_site(0, start_events, stop_events, n);
+}
+extern "C" int mmt_probe_count_site(int site) { return site >= 0 && site < PROBE_SITES ? g_probe_i[site] : 0; }
+extern "C" int mmt_probe_count(void) { return g_probe_i[0]; }
 
 extern "C" int mmt_bert_tail_capacity(int rows_alloc) { return (int)((((size_t)rows_alloc / 4) + 255) & ~(size_t)255); }
 
@@ -195,14 +214,17 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
     TRY(mmt_ln_fwd(L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, b->n_rows_dev, stream));
     e = {};
     e.bias = P.b1; e.out2 = L.g; e.ldout2 = I;
-    const bool probe = l == 0 && g_probe_i < g_probe_n;
-    if (probe) (void)hipEventRecord(g_probe_start[g_probe_i], (hipStream_t)stream);
-    TRY(mmt_gemm_nt_bf16(L.a16, d, P.w1, d, L.hpre, I, rows, I, d, MMT_EPI_BIAS_GELU, &e, b->n_rows_dev, stream));
-    if (probe) (void)hipEventRecord(g_probe_stop[g_probe_i++], (hipStream_t)stream);
+    {
+      ProbeScope probe(0, l == 0, stream);
+      TRY(mmt_gemm_nt_bf16(L.a16, d, P.w1, d, L.hpre, I, rows, I, d, MMT_EPI_BIAS_GELU, &e, b->n_rows_dev, stream));
+    }
     e = {};
     e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-    TRY(gemm_hidden(w, rows, d, L.g, I, P.w2, I, L.z2, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
+    {
+      ProbeScope probe(1, l == 0, stream);
+      TRY(gemm_hidden(w, rows, d, L.g, I, P.w2, I, L.z2, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
+    }
     float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
     TRY(mmt_ln_fwd(L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16, L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
     hin32 = hout32;
@@ -328,6 +350,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       g.item[2].out = P.g_wqkv; g.item[2].bias_out = P.g_bqkv;
       g.item[3].A = w.dy;    g.item[3].lda = d;     g.item[3].B = L.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
       g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo;
+      ProbeScope probe(2, l == 0, stream);
       TRY(mmt_wgrad_grouped(&g, stream));
     }
     dcur = dnext;

@@ -11,11 +11,14 @@ from ._lib import check
 
 
 class FlatAdam:
-  """`param_groups` / `state_dict` are shaped like a torch optimizer's, so `torch.optim.lr_scheduler.LambdaLR/StepLR`-style
-  code that only touches `optimizer.param_groups[i]['lr']` (the reference's StepLR + LinearWarmup,
-  train.py:101-103, trainer/trainer.py:150-160) drives it.  The rate is mirrored into a device scalar that the kernel
-  reads, so a captured optimizer graph follows the schedule: call `sync_lr()` (cheap, no-op when unchanged) before
-  replaying -- `GraphedTrainStep.step` does."""
+  """`param_groups` is shaped like a torch optimizer's, so scheduler code that only touches
+  `optimizer.param_groups[i]['lr']` (the reference's StepLR + LinearWarmup, train.py:101-103,
+  trainer/trainer.py:150-160) drives it.  The rate is mirrored into a device scalar that the kernel reads, so a captured
+  optimizer graph follows the schedule: call `sync_lr()` (cheap, no-op when unchanged) before replaying --
+  `GraphedTrainStep.step` does.  `state_dict()` / `load_state_dict()` use torch.optim.Adam's layout (per-parameter
+  `step` / `exp_avg` / `exp_avg_sq`, parameters numbered in `param_groups` order), so the reference's checkpoints
+  (base/base_trainer.py:353-365 saves `optimizer.state_dict()`, :426-432 restores it) round-trip, also to and from a
+  stock torch.optim.Adam over the same parameter list."""
 
   def __init__(self, flat, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
@@ -35,7 +38,7 @@ class FlatAdam:
   def sync_lr(self):
     """Push param_groups[0]['lr'] to the device scalar if it changed (stream-ordered fill, outside any graph)."""
     lr = float(self.lr)
-    if self.lr_dev is not None and lr != self._lr_on_dev and not torch.cuda.is_current_stream_capturing():
+    if self.lr_dev is not None and lr != self._lr_on_dev and not (self.lr_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
       self.lr_dev.fill_(lr)
       self._lr_on_dev = lr
 
@@ -64,14 +67,67 @@ class FlatAdam:
     g = f.current_grad()
     for o, n in self._frozen_spans():
       g[o:o + n].zero_()
-    lo, hi = g.data_ptr(), g.data_ptr() + 4 * f.count
-    p0 = next((p for p in f.params if p.requires_grad), None)
-    if p0 is not None and p0.grad is not None and not (lo <= p0.grad.data_ptr() < hi):
-      # autograd cloned instead of adopting our views (e.g. gradient accumulation): gather them
-      for p in f.params:
-        if p.grad is not None:
-          f.view(p, g).copy_(p.grad)
-    return g
+    # autograd cloned instead of adopting our views (e.g. gradient accumulation): gather them.  A data-parallel
+    # reduction (GradSync) has done this BEFORE reducing and re-pointed .grad at the flat buffer, so reduced values
+    # are never overwritten here.
+    from .dist import gather_stray_grads
+    return gather_stray_grads(f)
+
+  def _ensure_state(self):
+    f = self.flat
+    if f.master is None:
+      raise RuntimeError('FlatAdam: the parameters are not on a device yet (FlatParams.ensure)')
+    if self.exp_avg is None or self.exp_avg.device != f.master.device:
+      self.exp_avg = torch.zeros_like(f.master)
+      self.exp_avg_sq = torch.zeros_like(f.master)
+      self.step_dev = torch.zeros(1, dtype=torch.int32, device=f.master.device)
+    if self.lr_dev is None or self.lr_dev.device != f.master.device:
+      self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=f.master.device)
+      self._lr_on_dev = float(self.lr)
+
+  def state_dict(self):
+    """torch.optim.Adam layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}."""
+    f = self.flat
+    state = {}
+    if self.exp_avg is not None:
+      step = self.step_dev.detach().to(torch.float32).reshape(()).cpu()
+      for i, p in enumerate(f.params):
+        state[i] = dict(step=step.clone(), exp_avg=f.view(p, self.exp_avg).detach().clone(),
+                        exp_avg_sq=f.view(p, self.exp_avg_sq).detach().clone())
+    group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+    group['params'] = list(range(len(f.params)))
+    return {'state': state, 'param_groups': [group]}
+
+  def load_state_dict(self, sd):
+    f = self.flat
+    groups = sd['param_groups']
+    if len(groups) != 1 or len(groups[0]['params']) != len(f.params):
+      raise ValueError('FlatAdam.load_state_dict: expected one param group of %d parameters' % len(f.params))
+    for k, v in groups[0].items():
+      if k != 'params':
+        self.param_groups[0][k] = v
+    self.betas = tuple(self.param_groups[0].get('betas', self.betas))
+    self.eps = self.param_groups[0].get('eps', self.eps)
+    self.weight_decay = self.param_groups[0].get('weight_decay', self.weight_decay)
+    state = sd.get('state', {})
+    if state:
+      self._ensure_state()
+      steps = set()
+      with torch.no_grad():
+        for i, p in enumerate(f.params):
+          st = state.get(i, state.get(str(i)))
+          if st is None:
+            continue
+          f.view(p, self.exp_avg).copy_(st['exp_avg'])
+          f.view(p, self.exp_avg_sq).copy_(st['exp_avg_sq'])
+          steps.add(int(float(st['step'])))
+      if len(steps) > 1:
+        raise ValueError('FlatAdam keeps ONE step counter for the flat buffer; the checkpoint holds %s' % sorted(steps))
+      if steps:
+        self.step_dev.fill_(steps.pop())
+    if self.lr_dev is not None:
+      self._lr_on_dev = None
+      self.sync_lr()
 
   def zero_grad(self, set_to_none=True):
     for p in self.flat.params:
@@ -83,13 +139,7 @@ class FlatAdam:
   @torch.no_grad()
   def step(self):
     f = self.flat
-    if self.exp_avg is None or self.exp_avg.device != f.master.device:
-      self.exp_avg = torch.zeros_like(f.master)
-      self.exp_avg_sq = torch.zeros_like(f.master)
-      self.step_dev = torch.zeros(1, dtype=torch.int32, device=f.master.device)
-    if self.lr_dev is None or self.lr_dev.device != f.master.device:
-      self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=f.master.device)
-      self._lr_on_dev = float(self.lr)
+    self._ensure_state()
     self.sync_lr()
     g = self._grad()
     self.step_dev.add_(1)

@@ -85,10 +85,14 @@ def _copy_tree(dst, src):
 class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
-               overlap_grad_sync=None, force_collectives=False):
+               overlap_grad_sync=None, force_collectives=False, grad_dtype=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
-    backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward."""
+    backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
+    grad_dtype: torch.bfloat16 sends the gradient all-reduces in bf16 (half the bytes over xGMI, `dist.WireBuffer`);
+    None / torch.float32 reduces the fp32 buffer in place.
+    The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
+    statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -104,8 +108,20 @@ class GraphedTrainStep:
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
     self.opt_flats = [FlatAdam(f, lr=lr) for f in flats]
     self.opt_flat = self.opt_flats[0]
-    self.opt_rest = torch.optim.Adam(rest, lr=lr, capturable=use_graphs) if rest else None
-    self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group) for i, f in enumerate(flats)]
+    # parameters outside the flat buffers (a foreign text tower, txt_pro='lin' heads): stock Adam whose learning rate
+    # lives in a DEVICE tensor when the step is captured -- a python float would be frozen into the graph and the
+    # schedule (set_lr) would silently stop reaching these parameters
+    self._rest_lr = None
+    if rest:
+      dev0 = rest[0].device
+      if use_graphs and dev0.type == 'cuda':
+        self._rest_lr = torch.tensor(float(lr), device=dev0, dtype=torch.float32)
+      self.opt_rest = torch.optim.Adam(rest, lr=self._rest_lr if self._rest_lr is not None else lr, capturable=use_graphs)
+    else:
+      self.opt_rest = None
+    self.grad_dtype = grad_dtype
+    self._wire = mdist.WireBuffer(grad_dtype)
+    self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group, grad_dtype=grad_dtype) for i, f in enumerate(flats)]
     self.sync = self.syncs[0]
     self._extra_flats = flats[1:]
     self.use_graphs = use_graphs
@@ -116,13 +132,57 @@ class GraphedTrainStep:
     self._stream = torch.cuda.Stream()
     self._stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._stream):
+      snap = self._snapshot() if warmup_steps > 0 else None
       for i in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
         self._eager_step()
         if i == 0 and self._want_stages:
           self.staged = self._stageable([p for p in rest if p.grad is not None])  # e.g. the unused pooler: no grad
+      if snap is not None:
+        self._restore(snap)
     torch.cuda.current_stream().wait_stream(self._stream)
     if use_graphs:
       self._capture()
+
+  # ---- warm-up must not train --------------------------------------------------------------------
+  def _snapshot(self):
+    """Everything a training step mutates, captured before the warm-up steps."""
+    m = self.model
+    snap = dict(buffers=[(b, b.detach().clone()) for b in m.buffers()], flats=[], rest=[], seeds=[])
+    for f in (m.flats() if hasattr(m, 'flats') else [m._flat]):
+      if f.master is None or not f.is_flat():
+        f.ensure(f.params[0].device)  # what the first forward would do
+      snap['flats'].append((f, f.master.detach().clone()))
+    flat_ids = {id(p) for f, _ in snap['flats'] for p in f.params}
+    snap['rest'] = [(p, p.detach().clone()) for p in m.parameters() if id(p) not in flat_ids]
+    for mod in m.modules():
+      sd = getattr(mod, '_seed_dev', None)
+      if torch.is_tensor(sd):
+        snap['seeds'].append((mod, sd.detach().clone()))
+    return snap  # (a dropout seed first drawn during the warm-up simply starts its stream a few values later)
+
+  @torch.no_grad()
+  def _restore(self, snap):
+    for b, v in snap['buffers']:
+      b.copy_(v)
+    for f, v in snap['flats']:
+      f.master.copy_(v)
+      f._dirty = True
+      f.pack()  # the bf16 shadows follow the restored weights NOW (not inside the graph that is captured next)
+    for p, v in snap['rest']:
+      p.copy_(v)
+    for mod, v in snap['seeds']:
+      mod._seed_dev.copy_(v)
+    for o in self.opt_flats:  # Adam state as before the first step: zero moments, step 0 (buffers stay allocated)
+      if o.exp_avg is not None:
+        o.exp_avg.zero_()
+        o.exp_avg_sq.zero_()
+        o.step_dev.zero_()
+    if self.opt_rest is not None:
+      for st in self.opt_rest.state.values():
+        for v in st.values():
+          if torch.is_tensor(v):
+            v.zero_()
+    self._zero()
 
   # ---- pieces ------------------------------------------------------------------------------------
   def _forward(self):
@@ -293,9 +353,16 @@ class GraphedTrainStep:
     out = []
     for n in names:
       flat, off, cnt = self._regions[n]
-      out.append(dist.all_reduce(flat.current_grad()[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group,
-                                 async_op=True))
+      out.append(self._wire.reduce(flat.current_grad()[off:off + cnt], self.group))
     return out
+
+  @staticmethod
+  def _finish(handles):
+    """handles: [(work, finish)] of WireBuffer.reduce -- wait for every collective, then unpack the wire buffers."""
+    for h, _ in handles:
+      h.wait()
+    for _, fin in handles:
+      fin()
 
   def _zero(self):
     for o in self.opt_flats:
@@ -318,8 +385,11 @@ class GraphedTrainStep:
     for o in self.opt_flats:
       o.lr = lr
     if self.opt_rest is not None:
-      for g in self.opt_rest.param_groups:
-        g['lr'] = lr
+      if self._rest_lr is not None:
+        self._rest_lr.fill_(float(lr))  # device scalar: the captured optimizer graph reads it at replay
+      else:
+        for g in self.opt_rest.param_groups:
+          g['lr'] = lr
 
 
   def _eager_step(self):
@@ -332,8 +402,7 @@ class GraphedTrainStep:
       for fn, names in self._stage_list(e, g):
         fn()
         handles += self._reduce_async(names)
-      for h in handles:
-        h.wait()
+      self._finish(handles)
     else:
       self.loss = self._loss_backward(e, g)
       self._sync_all()
@@ -389,11 +458,20 @@ class GraphedTrainStep:
     else:
       _copy_tree(self.static, minibatch)
 
+  def eager_step(self):
+    """One un-captured optimisation step on the runner's own stream (the stream the autograd graph's AccumulateGrad nodes
+    are bound to: running the backward from another stream makes autograd insert cross-stream syncs and warn)."""
+    cur = torch.cuda.current_stream()
+    self._stream.wait_stream(cur)
+    with torch.cuda.stream(self._stream):
+      self._eager_step()
+    cur.wait_stream(self._stream)
+    return self.loss
+
   def step(self):
     """Runs one optimisation step on the current static inputs; returns the (device) loss tensor."""
     if not self.use_graphs:
-      self._eager_step()
-      return self.loss
+      return self.eager_step()
     for o in self.opt_flats:
       o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     ga, gb, gc = self._graphs
@@ -407,8 +485,7 @@ class GraphedTrainStep:
       for gs, names in gb:
         gs.replay()
         handles += self._reduce_async(names)
-      for h in handles:
-        h.wait()
+      self._finish(handles)
     else:
       gb.replay()
       self._sync_all()

