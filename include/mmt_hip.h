@@ -211,6 +211,10 @@ int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int voca
  * by mmt_col_reduce / mmt_col_reduce_multi (nvec = 1, d = vocab*d). */
 int mmt_table_grad_partials(const float* g, const int32_t* ids, int rows, int d, int vocab,
                             const int32_t* n_rows_dev, float* scratch, void* stream);
+/* both tables of the video BERT (ids1 nullable) as one-hot x gradient products on the exact-fp32 matrix cores, one launch;
+ * same scratch layout as mmt_table_grad_partials ([chunks][vocab][d]); d % 128 == 0 */
+int mmt_table_grad_partials_pair(const float* g, const int32_t* ids0, int vocab0, float* scratch0, const int32_t* ids1,
+                                 int vocab1, float* scratch1, int rows, int d, const int32_t* n_rows_dev, void* stream);
 int mmt_table_grad_chunks(void);
 /* partials[blk][c] = column sums of a bf16 matrix over 32-row blocks (bias gradients). */
 int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t* n_rows_dev,
@@ -319,6 +323,17 @@ int mmt_sims_fwd(const float* txt, const float* vid, const float* tw, const floa
 int mmt_sims_bwd(const float* txt, const float* vid, const float* tw, const float* vw, float* dots,
                  const float* dsims, int NT, int NV, int M, int d, float* dtxt, float* dvid, float* dtw,
                  float* dvw, void* stream);
+/* Small batches (n <= mmt_simloss_small_max_n() pairs, one caption per video -- the single-rank training step): the loss
+ * (kind 0: MaxMarginRankingLoss(margin, fix_norm), loss.py:38-65; kind 1: InfoNceLoss, :68-81), its gradient wrt the
+ * similarity matrix and the whole similarity backward (model.py:789-837) in ONE launch from the sims / dots of
+ * mmt_sims_fwd.  dtxt/dvid [n, M, d], dtw/dvw [n, M] (each nullable).  dlast (nullable) + inv_norm [n*M]: also the
+ * backward of the read-out normalisation (model.py:621-625): dlast[out_rows ? out_rows[i] : i] for i = v*M + m. */
+int mmt_simloss_small_max_n(void);
+int mmt_simloss_bwd_small(const float* txt, const float* vid, const float* tw, const float* vw, const float* sims,
+                          const float* dots, int n, int M, int d, int kind, float margin, int fix_norm, float* loss,
+                          float* dtxt, float* dvid, float* dtw, float* dvw, const float* inv_norm,
+                          const int32_t* out_rows, float* dlast, void* stream);
+
 /* MaxMarginRankingLoss.forward (loss.py:38-65): loss scalar + d loss/d sims; partial = n floats scratch. */
 int mmt_maxmargin(const float* sims, int n, float margin, int fix_norm, float* partial, float* loss,
                   float* grad, void* stream);

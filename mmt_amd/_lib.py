@@ -135,6 +135,7 @@ SIGNATURES = {
     'mmt_col_reduce_multi': (c_int, [ctypes.POINTER(MmtColReduceJob), c_int, c_vp]),
     'mmt_table_grad_partials': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_table_grad_chunks': (c_int, []),
+    'mmt_table_grad_partials_pair': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_table_grad_scratch_floats': (c_i64, [c_int, c_int]),
     'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mmt_attn_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
@@ -180,6 +181,9 @@ SIGNATURES = {
     'mmt_ls_grad': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64,
                             c_vp, c_vp]),
     'mmt_ls_unfold': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mmt_simloss_small_max_n': (c_int, []),
+    'mmt_simloss_bwd_small': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_vp,
+                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mmt_maxmargin': (c_int, [c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_infonce': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_bert_tail_capacity': (c_int, [c_int]),

@@ -255,8 +255,18 @@ __global__ __launch_bounds__(64 * CR_RG) void col_reduce_multi_kernel(ColJobs jo
   float* out = jb.out[j];
   const float* __restrict__ partials = jb.partials;
   float s = 0.f;
-  if (out && c < d)
-    for (int b = rg; b < nblocks; b += CR_RG) s += partials[((int64_t)b * nvec + j) * d + c];
+  if (out && c < d) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;  // independent chains: the strided loads are in flight together
+    int b = rg;
+    for (; b + 3 * CR_RG < nblocks; b += 4 * CR_RG) {
+      s += partials[((int64_t)b * nvec + j) * d + c];
+      s1 += partials[((int64_t)(b + CR_RG) * nvec + j) * d + c];
+      s2 += partials[((int64_t)(b + 2 * CR_RG) * nvec + j) * d + c];
+      s3 += partials[((int64_t)(b + 3 * CR_RG) * nvec + j) * d + c];
+    }
+    for (; b < nblocks; b += CR_RG) s += partials[((int64_t)b * nvec + j) * d + c];
+    s = (s + s1) + (s2 + s3);
+  }
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
   if (rg == 0 && out && c < d) {
@@ -290,6 +300,51 @@ __global__ __launch_bounds__(256) void table_grad_kernel(
     __syncthreads();
   }
   partial[((int64_t)chunk * vocab + v) * d + col] = s;
+}
+
+// The same partial sums on the exact-fp32 matrix cores: partial[chunk] = onehot(ids)^T . g over the chunk's rows
+// (v_mfma_f32_32x32x2_f32 is an fp32 fma chain, products 1 * g: exact row-order sums).  A = onehot[v][r] built in
+// registers, B = g[r][c0 + lane & 31] (128-byte coalesced).  grid (d / 128, TABLE_CHUNKS, tables): 4 waves per block, one
+// 32-column tile each; up to two tables (token types + temporal positions) in one launch.  The scan kernel above walks
+// its chunk row by row per vocabulary entry (16.9 + 11.8 us for the two tables of config B); this one needs ~4 us.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+struct TablePair { const int32_t* ids[2]; float* partial[2]; int vocab[2]; };
+__global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __restrict__ g, TablePair tp, int rows, int d,
+                                                              const int32_t* __restrict__ n_rows_dev) {
+  const int which = blockIdx.z;
+  const int32_t* __restrict__ ids = tp.ids[which];
+  float* __restrict__ partial = tp.partial[which];
+  const int vocab = tp.vocab[which];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int c0 = (blockIdx.x * 4 + wave) * 32, chunk = blockIdx.y;
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
+  const int per = (nrows + TABLE_CHUNKS - 1) / TABLE_CHUNKS;
+  const int r_begin = chunk * per, r_end = min(nrows, r_begin + per);
+  for (int v0 = 0; v0 < vocab; v0 += 32) {
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int myv = v0 + l31;
+    for (int r0 = r_begin; r0 < r_end; r0 += 16) {  // 8 MFMAs (16 rows) per trip, loads issued together
+      float bv[8];
+      int idv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int r = r0 + 2 * t + h;
+        const bool ok = r < r_end;
+        bv[t] = ok ? g[(int64_t)r * d + c0 + l31] : 0.f;
+        idv[t] = ok ? ids[r] : -1;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(idv[t] == myv ? 1.0f : 0.0f, bv[t], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // lane holds column c0 + l31, rows (r & 3) + 8 (r >> 2) + 4 h
+      const int v = v0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (v < vocab) partial[((int64_t)chunk * vocab + v) * d + c0 + l31] = acc[r];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,6 +563,18 @@ extern "C" int mmt_table_grad_partials(const float* g, const int32_t* ids, int r
   return (int)hipGetLastError();
 }
 extern "C" int mmt_table_grad_chunks(void) { return TABLE_CHUNKS; }
+
+// both embedding tables of the video BERT (token types, temporal positions; ids1 nullable) in ONE launch on the fp32 MFMA
+extern "C" int mmt_table_grad_partials_pair(const float* g, const int32_t* ids0, int vocab0, float* scratch0,
+                                            const int32_t* ids1, int vocab1, float* scratch1, int rows, int d,
+                                            const int32_t* n_rows_dev, void* stream) {
+  if (!g || !ids0 || !scratch0 || rows <= 0 || vocab0 <= 0 || d % 128) return MMT_ERR_ARG;
+  if (ids1 && (!scratch1 || vocab1 <= 0)) return MMT_ERR_ARG;
+  TablePair tp = {{ids0, ids1}, {scratch0, scratch1}, {vocab0, vocab1}};
+  hipLaunchKernelGGL(table_grad_mfma_kernel, dim3(d / 128, TABLE_CHUNKS, ids1 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, g, tp,
+                     rows, d, n_rows_dev);
+  return (int)hipGetLastError();
+}
 
 extern "C" int64_t mmt_table_grad_scratch_floats(int vocab, int d) { return (int64_t)TABLE_CHUNKS * vocab * d; }
 

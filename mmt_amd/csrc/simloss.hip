@@ -79,6 +79,175 @@ __global__ __launch_bounds__(256) void sims_fwd_kernel(const float* __restrict__
   }
 }
 
+// The same for small batches with every (video, expert) pair of a text row spread over 16 waves: the per-expert loop of
+// sims_fwd_kernel is a chain of M dependent wave reductions per wave (10.8 us at n = 32); here all of a wave's dot
+// products are independent (6 us).  LDS: text row [M][d] + dots row [NV][M].
+#define SF_WAVES 16
+__global__ __launch_bounds__(64 * SF_WAVES) void sims_fwd_small_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
+                                                                       const float* __restrict__ tw, const float* __restrict__ vw,
+                                                                       int NT, int NV, int M, int d, float* __restrict__ sims,
+                                                                       float* __restrict__ dots) {
+  extern __shared__ __attribute__((aligned(16))) float ts[];  // [M][d] text row | [NV][M] dots of this row
+  float* drow = ts + M * d;
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x * 4; i < M * d; i += 256 * SF_WAVES) *(f32x4*)(ts + i) = *(const f32x4*)(txt + (int64_t)t * M * d + i);
+  __syncthreads();
+  for (int p = wave; p < NV * M; p += SF_WAVES) {  // pair p = (v, m): row p of vid viewed as [NV*M][d]
+    const int m = p % M;
+    float acc = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 x = *(const f32x4*)(ts + m * d + c), y = *(const f32x4*)(vid + (int64_t)p * d + c);
+      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    const float dm = wave_sum(acc);
+    if (lane == 0) { drow[p] = dm; dots[(int64_t)t * NV * M + p] = dm; }
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < NV; v += 64 * SF_WAVES) {
+    float nrm = 0.f, sacc = 0.f;
+    for (int m = 0; m < M; ++m) nrm += tw[t * M + m] * vw[v * M + m];
+    if (nrm == 0.f) nrm = 1e-5f;  // model.py:816
+    for (int m = 0; m < M; ++m) sacc += tw[t * M + m] * vw[v * M + m] / nrm * drow[v * M + m];
+    sims[(int64_t)t * NV + v] = sacc;
+  }
+}
+
+// ---- loss + d loss / d sims + similarity backward (+ read-out backward) in ONE launch, n <= 64 ------------------------
+// Every block loads the whole n x n similarity matrix (<= 16 KB) and derives what it needs of the loss gradient
+// G = d loss / d sims itself: max-margin (loss.py:38-65) needs s_tv, s_tt, s_vv per entry and the active-hinge counts of
+// row/column k for the diagonal; InfoNCE (loss.py:68-81) the row and column logsumexps.  Block (0, 0, 0) also writes the
+// loss.  Then the similarity backward of sims_bwd_kernel with 16 waves over the other side's rows, and for the video
+// side optionally the backward of the read-out normalisation (readout_bwd_kernel) straight into the engine's dlast.
+#define SB_WAVES 16
+struct SimLossArgs {
+  const float *txt, *vid, *tw, *vw, *sims, *dots;
+  int n, M, d, kind, fix_norm;
+  float margin;
+  float *loss, *dtxt, *dvid, *dtw, *dvw;
+  const float* inv_norm; const int32_t* out_rows; float* dlast;
+};
+__global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sl[];
+  const int n = a.n, M = a.M, d = a.d;
+  float* S = sl;                         // [n][n]
+  float* lse_r = S + n * n;              // [n]  (InfoNCE) / diag counts scratch
+  float* lse_c = lse_r + n;              // [n]
+  float* gself = lse_c + n;              // [n]  G of this block's row (side 0) or column (side 1)
+  float* racc = gself + ((n + 3) & ~3);  // [SB_WAVES][d]
+  float* rw = racc + SB_WAVES * d;       // [SB_WAVES]
+  const int side = blockIdx.z, self = blockIdx.x, m = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n * n; i += 64 * SB_WAVES) S[i] = a.sims[i];
+  __syncthreads();
+  const float norm = a.kind == 0 ? (a.fix_norm ? 2.0f * n * (n - 1) : 2.0f * n * n) : (float)n;
+  if (a.kind == 1) {  // InfoNCE: logsumexp of every row and column
+    for (int k = tid; k < 2 * n; k += 64 * SB_WAVES) {
+      const int r = k % n;
+      const bool col = k >= n;
+      float mx = -INFINITY;
+      for (int c = 0; c < n; ++c) mx = fmaxf(mx, col ? S[c * n + r] : S[r * n + c]);
+      float sum = 0.f;
+      for (int c = 0; c < n; ++c) sum += expf((col ? S[c * n + r] : S[r * n + c]) - mx);
+      (col ? lse_c : lse_r)[r] = mx + logf(sum);
+    }
+    __syncthreads();
+  }
+  // G entry (t, v)
+  auto g_entry = [&](int t, int v) -> float {
+    const float stv = S[t * n + v];
+    if (a.kind == 1) return (expf(stv - lse_r[t]) + expf(stv - lse_c[v]) - (t == v ? 2.f : 0.f)) / norm;
+    if (t != v) return ((a.margin - S[t * n + t] + stv > 0.f ? 1.f : 0.f) + (a.margin - S[v * n + v] + stv > 0.f ? 1.f : 0.f)) / norm;
+    int cnt = 0;  // diagonal: active hinges of row t and column t pull s_tt down
+    for (int c = 0; c < n; ++c) {
+      if (c == t) continue;
+      cnt += (a.margin - stv + S[t * n + c] > 0.f) + (a.margin - stv + S[c * n + t] > 0.f);
+    }
+    return -(float)cnt / norm;
+  };
+  for (int o = tid; o < n; o += 64 * SB_WAVES) gself[o] = side == 0 ? g_entry(self, o) : g_entry(o, self);
+  if (side == 0 && self == 0 && m == 0 && wave == 0) {  // the loss itself (fixed order: deterministic)
+    float acc = 0.f;
+    if (a.kind == 1) {
+      for (int k = lane; k < n; k += 64) acc += (lse_r[k] + lse_c[k] - 2.0f * S[k * n + k]) / norm;
+    } else {
+      for (int e = lane; e < n * n; e += 64) {
+        const int r = e / n, c = e % n;
+        if (r == c && a.fix_norm) continue;
+        acc += (fmaxf(a.margin - S[r * n + r] + S[e], 0.f) + fmaxf(a.margin - S[c * n + c] + S[e], 0.f)) / norm;
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *a.loss = acc;
+  }
+  __syncthreads();
+  // ---- similarity backward for (side, self, m) ----
+  float* __restrict__ dx = side == 0 ? a.dtxt : a.dvid;
+  float* __restrict__ dwt = side == 0 ? a.dtw : a.dvw;
+  const float* other = side == 0 ? a.vid : a.txt;
+  const float* wother = side == 0 ? a.vw : a.tw;
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dws = 0.f;
+  for (int o = wave; o < n; o += SB_WAVES) {
+    const int t = side == 0 ? self : o, v = side == 0 ? o : self;
+    const float g = gself[o];
+    const float* dm = a.dots + ((int64_t)t * n + v) * M;
+    float nrm = 0.f, gw = 0.f;
+    for (int j = 0; j < M; ++j) nrm += a.tw[t * M + j] * a.vw[v * M + j];
+    const bool zero = nrm == 0.f;
+    if (zero) nrm = 1e-5f;
+    for (int j = 0; j < M; ++j) gw += g * dm[j] * a.tw[t * M + j] * a.vw[v * M + j] / nrm;
+    const float w = a.tw[t * M + m] * a.vw[v * M + m] / nrm;
+    const float da = zero ? g * dm[m] / nrm : (g * dm[m] - gw) / nrm;
+    dws += da * wother[o * M + m];
+    const float coef = g * w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < d) acc[c] += *(const f32x4*)(other + ((int64_t)o * M + m) * d + col) * coef;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (col < d) *(f32x4*)(racc + wave * d + col) = acc[c];
+  }
+  if (lane == 0) rw[wave] = dws;
+  __syncthreads();
+  // combine the waves' partial rows: thread i owns column(s) i, i + 1024, ...
+  const bool readout = side == 1 && a.dlast != nullptr;
+  const int64_t row = (int64_t)self * M + m;
+  float part = 0.f;
+  float gx[1];  // d <= 1024 and 1024 threads: one column per thread
+  {
+    const int i = tid;
+    float sum = 0.f;
+    if (i < d) {
+#pragma unroll
+      for (int w = 0; w < SB_WAVES; ++w) sum += racc[w * d + i];
+      if (dx) dx[row * d + i] = sum;
+      if (readout) part = sum * a.vid[row * d + i];
+    }
+    gx[0] = sum;
+  }
+  if (tid == 0 && dwt) {
+    float sum = 0.f;
+    for (int w = 0; w < SB_WAVES; ++w) sum += rw[w];
+    dwt[self * M + m] = sum;
+  }
+  if (readout) {  // dlast = (g - y <y, g>) * inv   (y = normalised read-out row: model.py:621-625 backward)
+    part = wave_sum(part);
+    __syncthreads();  // racc is free again
+    if (lane == 0) racc[wave] = part;
+    __syncthreads();
+    float dot = 0.f;
+    for (int w = 0; w < SB_WAVES; ++w) dot += racc[w];
+    const int64_t orow = a.out_rows ? a.out_rows[row] : row;
+    if (tid < d) a.dlast[orow * d + tid] = (gx[0] - a.vid[row * d + tid] * dot) * a.inv_norm[row];
+  }
+}
+
 // side 0: block per text row t -> dtxt[t], dtw[t];  side 1: block per video v -> dvid[v], dvw[v].
 __global__ __launch_bounds__(256) void sims_bwd_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
                                                        const float* __restrict__ tw, const float* __restrict__ vw,
@@ -339,10 +508,39 @@ extern "C" int mmt_sims_fwd(const float* txt, const float* vid, const float* tw,
   if (NT >= LARGE_N || NV >= LARGE_N) return sims_fwd_large(txt, vid, tw, vw, NT, NV, M, d, sims, dots, stream);
   const size_t lds = (size_t)M * d * sizeof(float);
   if (lds > 64 * 1024) return MMT_ERR_ARG;
+  if (lds + (size_t)NV * M * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(sims_fwd_small_kernel, dim3(NT), dim3(64 * SF_WAVES), lds + (size_t)NV * M * sizeof(float),
+                       (hipStream_t)stream, txt, vid, tw, vw, NT, NV, M, d, sims, dots);
+    return (int)hipGetLastError();
+  }
   int gy = (NV + 3) / 4;
   if (gy > 16) gy = 16;
   hipLaunchKernelGGL(sims_fwd_kernel, dim3(NT, gy), dim3(256), lds, (hipStream_t)stream, txt, vid, tw, vw, NT, NV, M, d,
                      sims, dots);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_simloss_small_max_n(void) { return LARGE_N - 1; }
+
+extern "C" int mmt_simloss_bwd_small(const float* txt, const float* vid, const float* tw, const float* vw, const float* sims,
+                                     const float* dots, int n, int M, int d, int kind, float margin, int fix_norm,
+                                     float* loss, float* dtxt, float* dvid, float* dtw, float* dvw, const float* inv_norm,
+                                     const int32_t* out_rows, float* dlast, void* stream) {
+  if (!txt || !vid || !tw || !vw || !sims || !dots || !loss || n <= 1 || n >= LARGE_N || M <= 0 || M > MAXM || d % 4 ||
+      d > 1024 || (kind != 0 && kind != 1))
+    return MMT_ERR_ARG;
+  if (dlast && !inv_norm) return MMT_ERR_ARG;
+  SimLossArgs a = {txt, vid, tw, vw, sims, dots, n, M, d, kind, fix_norm, margin, loss, dtxt, dvid, dtw, dvw, inv_norm, out_rows,
+                   dlast};
+  const size_t lds = ((size_t)n * n + 2 * n + ((n + 3) & ~3) + (size_t)SB_WAVES * d + SB_WAVES) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)simloss_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((63 * 63 + 2 * 63 + 64 + SB_WAVES * 1024 + SB_WAVES) * sizeof(float)));
+    if (rc != hipSuccess) return (int)rc;
+    configured = true;
+  }
+  hipLaunchKernelGGL(simloss_bwd_small_kernel, dim3(n, M, 2), dim3(64 * SB_WAVES), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

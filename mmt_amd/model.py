@@ -103,7 +103,9 @@ class _ReadoutFn(torch.autograd.Function):
   """vid_embds[b, m] = F.normalize(sequence_output[agg_row[b, m]])  (model.py:583-587, 621-625)."""
 
   @staticmethod
-  def forward(ctx, last, agg_row, bm, compact=False):
+  def forward(ctx, last, agg_row, bm, compact=False, stash=None):
+    """stash (dict, optional): receives the inverse norms, for callers that fuse this backward into theirs
+    (train_step.GraphedTrainStep: loss + similarity backward + read-out backward in one launch)."""
     ctx.compact = compact
     d = last.shape[1]
     out = torch.empty(bm, d, device=last.device, dtype=torch.float32)
@@ -112,6 +114,8 @@ class _ReadoutFn(torch.autograd.Function):
           'mmt_readout_fwd')
     ctx.save_for_backward(out, inv, agg_row)
     ctx.shape = last.shape
+    if stash is not None:
+      stash.update(readout_inv=inv, readout_rows=None if compact else agg_row, readout_compact=compact)
     return out
 
   @staticmethod
@@ -121,7 +125,7 @@ class _ReadoutFn(torch.autograd.Function):
     dlast = (torch.empty if ctx.compact else torch.zeros)(ctx.shape, device=out.device, dtype=torch.float32)
     check(_lib.lib().mmt_readout_bwd(ops._p(out), ops._p(inv), ops._p(dout.contiguous()), ops._p(agg_row),
                                      out.shape[0], out.shape[1], ops._p(dlast), ops._stream()), 'mmt_readout_bwd')
-    return dlast, None, None, None
+    return dlast, None, None, None, None
 
 
 class _SimsFn(torch.autograd.Function):
@@ -524,10 +528,13 @@ class CENet(nn.Module):
     if self.vid_bert.compact_output(batch, plan.rows_alloc):  # the engine returned just the AGG rows, in agg_row order
       if plan.compact_rows is None:
         plan.compact_rows = torch.arange(bsz * len(mods), device=dev, dtype=torch.int32)
-      vid = _ReadoutFn.apply(last, plan.compact_rows, bsz * len(mods), True)
+      vid = _ReadoutFn.apply(last, plan.compact_rows, bsz * len(mods), True, self._stages)
     else:
-      vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods))
-    return vid.view(bsz, len(mods), self.same_dim)
+      vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods), False, self._stages)
+    vid = vid.view(bsz, len(mods), self.same_dim)
+    if self._stages is not None:
+      self._stages['vid_embds'] = vid
+    return vid
 
   # ---- text heads (native) -------------------------------------------------------------------------
   def _text_head_params(self):

@@ -230,7 +230,7 @@ class GraphedTrainStep:
 
   def _loss_backward(self, e, g):
     g = self._globalize(e, g)
-    fast = self._fast_loss_grads(e, g)
+    fast = self._fast_loss_grads(e, g, fuse_readout=True)
     if fast is not None:
       loss, outs, grads = fast
       torch.autograd.backward(outs, grads)
@@ -246,7 +246,7 @@ class GraphedTrainStep:
     torch.autograd.backward([e[k] for k in need], [gr[sl] for gr in grads])
     return loss.detach()
 
-  def _fast_loss_grads(self, e, g):
+  def _fast_loss_grads(self, e, g, fuse_readout=False):
     """Our own similarity + loss kernels called directly (no autograd bookkeeping for this tiny sub-graph: saves the
     ones_like / multiply / slice launches): global sims -> loss + dL/dsims in one kernel -> similarity backward ->
     (loss, [local outputs of graph A that need a gradient], [their gradients]).  None = not applicable (foreign loss
@@ -272,6 +272,40 @@ class GraphedTrainStep:
     check(L.mmt_sims_fwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), n, n, m, d, ops._p(sims), ops._p(dots),
                          ops._stream()), 'mmt_sims_fwd')
     loss = torch.empty((), device=dev, dtype=torch.float32)
+    b = e['vid_embds'].shape[0]
+    sl = slice(self.rank * b, (self.rank + 1) * b)
+    if n <= L.mmt_simloss_small_max_n():
+      # small (single-rank) batches: loss, d loss / d sims and the whole similarity backward in ONE launch -- and, when
+      # the video embeddings are the read-out of this model's own encoder output, the read-out backward too
+      kind = 0 if isinstance(self.loss_fn, MaxMarginRankingLoss) else 1
+      margin = float(getattr(self.loss_fn, 'margin', 0.0))
+      fix_norm = int(getattr(self.loss_fn, 'fix_norm', True))
+      st = getattr(self.model, '_stages', None) if (n == b and fuse_readout) else None
+      fused = st is not None and st.get('vid_embds') is e['vid_embds'] and st.get('readout_inv') is not None
+      dtxt, dtw = torch.empty_like(txt), torch.empty_like(tw)
+      dvid = dlast = None
+      if fused:
+        last = st['last']
+        dlast = (torch.empty if st['readout_compact'] else torch.zeros)(last.shape, device=dev, dtype=torch.float32)
+      else:
+        dvid = torch.empty_like(vid)
+      check(L.mmt_simloss_bwd_small(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), ops._p(sims), ops._p(dots), n, m, d, kind,
+                                    margin, fix_norm, ops._p(loss), ops._p(dtxt), ops._p(dvid), ops._p(dtw), None,
+                                    ops._p(st['readout_inv']) if fused else None,
+                                    ops._p(st['readout_rows']) if fused and st['readout_rows'] is not None else None,
+                                    ops._p(dlast), ops._stream()), 'mmt_simloss_bwd_small')
+      outs, grads = [], []
+      pairs = [('text_embds', dtxt.view(n, m, 1, d)), ('text_weights', dtw.view(n, 1, m))]
+      if fused:
+        outs.append(st['last'])
+        grads.append(dlast)
+      else:
+        pairs.insert(0, ('vid_embds', dvid))
+      for k, gfull in pairs:
+        if e[k].requires_grad:
+          outs.append(e[k])
+          grads.append(gfull[sl])
+      return loss, outs, grads
     grad = torch.empty(n, n, device=dev, dtype=torch.float32)
     scratch = torch.empty(3 * n, device=dev, dtype=torch.float32)
     if isinstance(self.loss_fn, MaxMarginRankingLoss):
@@ -282,8 +316,6 @@ class GraphedTrainStep:
     dtxt, dvid, dtw, dvw = (torch.empty_like(x) for x in (txt, vid, tw, vw))
     check(L.mmt_sims_bwd(ops._p(txt), ops._p(vid), ops._p(tw), ops._p(vw), ops._p(dots), ops._p(grad), n, n, m, d,
                          ops._p(dtxt), ops._p(dvid), ops._p(dtw), ops._p(dvw), ops._stream()), 'mmt_sims_bwd')
-    b = e['vid_embds'].shape[0]
-    sl = slice(self.rank * b, (self.rank + 1) * b)
     outs, grads = [], []
     for k, gfull in (('vid_embds', dvid), ('text_embds', dtxt.view(n, m, 1, d)), ('text_weights', dtw.view(n, 1, m))):
       if e[k].requires_grad:

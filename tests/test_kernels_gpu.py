@@ -503,3 +503,30 @@ def test_standalone_dropout_keep_rate_and_backward_mask():
   _close('dropout.bwd', x.grad, g * keep * sc, 1e-6, 1e-6)
   y2 = _MoeDropoutFn.apply(x.detach(), 0.1, seed)
   assert ((y2 != 0) != keep).float().mean().item() > 0.05
+
+
+@pytest.mark.parametrize('rows,d,v0,v1,live', [(3583, 512, 19, 32, None), (700, 256, 19, 32, 333), (900, 1024, 40, 64, 801),
+                                                (257, 512, 19, 0, None)])
+def test_table_grad_pair_on_matrix_cores(rows, d, v0, v1, live):
+  """Embedding-table gradients (token types + temporal positions, model/bert.py:87-105 backward) as one-hot products on the
+  fp32 MFMA, both tables in one launch: against index_add_ in fp64."""
+  from mmt_amd import _lib, ops
+  from mmt_amd._lib import check
+  L = _lib.lib()
+  R = ops.pad_rows(rows)
+  g = _rand((R, d), seed=61)
+  gen = torch.Generator().manual_seed(62)
+  ids0 = torch.randint(0, v0, (R,), generator=gen, dtype=torch.int32).to(_dev())
+  ids1 = torch.randint(0, max(v1, 1), (R,), generator=gen, dtype=torch.int32).to(_dev()) if v1 else None
+  nr = torch.tensor([live], device=_dev(), dtype=torch.int32) if live else None
+  chunks = L.mmt_table_grad_chunks()
+  s0 = torch.full((chunks, v0, d), 7.0, device=_dev())
+  s1 = torch.full((chunks, v1, d), 7.0, device=_dev()) if v1 else None
+  check(L.mmt_table_grad_partials_pair(ops._p(g), ops._p(ids0), v0, ops._p(s0), ops._p(ids1), v1, ops._p(s1), rows, d,
+                                       ops._p(nr), ops._stream()), 'pair')
+  n = live if live else rows
+  for ids, v, s in ((ids0, v0, s0), (ids1, v1, s1)):
+    if ids is None:
+      continue
+    want = torch.zeros(v, d, device=_dev(), dtype=torch.float64).index_add_(0, ids[:n].long(), g[:n].double())
+    _close('table', s.sum(0), want.float(), 1e-4, 1e-5)
