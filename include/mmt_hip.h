@@ -183,6 +183,24 @@ int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int d, int voc
 int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
                   const int64_t* attention_mask, int B, int W, int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev,
                   int32_t* ids, int32_t* types, int32_t* pos, int32_t* row_index, int32_t* cls_rows, void* stream);
+/* The reduction of split-K partial slabs (mmt_gemm_nt_splitk_ex with no_epilogue = 1; geometry from
+ * mmt_gemm_splitk_geometry) folded into the LayerNorm pass next to it -- the compact last encoder layer, where a launch
+ * costs more than the work it carries:
+ *   mmt_splitk_ln_fwd : z = sum_s slab_s + bias -> dropout -> + residual (res[res_rows ? res_rows[i] : i]); h = LN(z)
+ *                       (bert.py:185-189 / 233-237).  RNG row coordinate: rowidx[i] if given, else
+ *                       row_index[res_rows[i]] (written to rowidx_out for the kernels that follow).
+ *   mmt_ln_bwd_slabs  : mmt_ln_bwd with dout = sum_s slab_s + res. */
+int mmt_gemm_splitk_geometry(int M, int N, int K, int splits_requested, int* splits, int64_t* slab_stride);
+int mmt_splitk_ln_fwd(const float* slabs, int splits, int64_t slab_stride, const float* bias, const float* res,
+                      const int32_t* res_rows, const int32_t* rowidx, const int32_t* row_index, int32_t* rowidx_out,
+                      uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
+                      const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean, float* rstd,
+                      int rows, int d, void* stream);
+int mmt_ln_bwd_slabs(const float* slabs, int splits, int64_t slab_stride, const float* res, const float* z,
+                     const float* mean, const float* rstd, const float* gamma, float* dz, void* dy, float* partials,
+                     int rows, int d, int drop_mode, const int32_t* row_index, uint32_t drop_key, uint32_t thr16,
+                     float drop_scale, const uint32_t* seed_dev, void* stream);
+
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
  * [ceil(rows/rpb)][3][d] per-block column sums (dgamma, dbeta, dbias) for mmt_col_reduce. */
@@ -283,7 +301,9 @@ int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float
                         void* stream);
 
 /* ---- video tokens (assemble.hip) -------------------------------------------------------------------
- * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip. */
+ * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip.
+ * mmt_video_plan: seed_bump (nullable) = the per-step dropout seed word of the encoder, incremented by the plan kernel
+ * (a training forward needs a fresh seed anyway: one launch less than a separate increment). */
 #define MMT_MAX_EXPERTS 16
 typedef struct MmtExpertIO {
   const float* feat;     /* [B, T, D] fp32  features[mod]                                        */
@@ -299,8 +319,8 @@ typedef struct MmtExpertIO {
  * type_ids, pos_ids (clamp(features_t,0,max_pos) model.py:516-520), mask_bias, agg_row[b*M+m].
  * pack=0 keeps all S=1+M*(T+1) slots; pack=1 drops padded FEA tokens (exact, see assemble.hip). */
 int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos, int32_t* counts,
-                   int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot, int32_t* row_index,
-                   int32_t* type_ids, int32_t* pos_ids, float* mask_bias, int32_t* agg_row, void* stream);
+                   int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot, int32_t* row_index, int32_t* type_ids,
+                   int32_t* pos_ids, float* mask_bias, int32_t* agg_row, uint32_t* seed_bump, void* stream);
 int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, void* stream);
 int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
                       float* features, void* stream);

@@ -129,6 +129,11 @@ SIGNATURES = {
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                  c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_ln_bwd_rows_per_block': (c_int, [c_int]),
+    'mmt_gemm_splitk_geometry': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_splitk_ln_fwd': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp,
+                                  c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    'mmt_ln_bwd_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp,
+                                 c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                            c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -163,7 +168,7 @@ SIGNATURES = {
     'mmt_adam_step_fused': (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtAdamSeg), c_vp, c_int, c_f32, c_f32, c_f32,
                                     c_f32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
-                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_vp]),
     'mmt_video_scatter': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_video_scatter_bwd': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -323,8 +323,9 @@ class BertModel(nn.Module):
     m, _ = self._struct(grad_buf)
     if save:
       self._generation += 1
-      if self.training:
+      if self.training and not getattr(self, '_seed_bumped', False):
         self._seed_dev.add_(1)
+    self._seed_bumped = False  # (CENet's token-plan kernel increments the seed itself when it runs in front of us)
     ws = self._workspace(rows_alloc, save, m)
     out = torch.empty(rows_alloc, self.config.hidden_size, device=features.device, dtype=torch.float32)
     b = self._batch_struct(batch, rows_alloc)

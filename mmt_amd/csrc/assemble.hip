@@ -26,12 +26,33 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
                                                    int phase, int32_t* __restrict__ counts, int32_t* __restrict__ cu,
                                                    int32_t* __restrict__ n_rows, int32_t* __restrict__ slot, int32_t* __restrict__ row_index,
                                                    int32_t* __restrict__ type_ids, int32_t* __restrict__ pos_ids,
-                                                   float* __restrict__ mask_bias, int32_t* __restrict__ agg_row) {
+                                                   float* __restrict__ mask_bias, int32_t* __restrict__ agg_row,
+                                                   uint32_t* __restrict__ seed_bump) {
   __shared__ int scan[256];
   __shared__ int carry;
   const int b = blockIdx.x, tid = threadIdx.x;
+  const bool one_launch = phase == 2;
   int base = 0;
-  if (phase == 1) {  // exclusive prefix of the per-sample counts (phase 0), computed by the block itself: no scan launch
+  if (phase == 2 && b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
+  if (phase == 2) {  // ONE launch: the block counts the live tokens of the samples in front of it itself
+    int part = 0;
+    if (pack) {
+      const int per = M * T;  // FEA slots per sample; CLS + M AGG tokens are always live
+      for (int i = tid; i < b * per; i += 256) {
+        const int bb = i / per, r = i % per;
+        part += tab.e[r / T].ind[(int64_t)bb * T + r % T] != 0.f;
+      }
+    }
+    scan[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) scan[tid] += scan[tid + o];
+      __syncthreads();
+    }
+    base = pack ? b * (1 + M) + scan[0] : b * S;
+    __syncthreads();
+    phase = 1;  // fill below; cu / n_rows are written once this sample's own count is known
+  } else if (phase == 1) {  // exclusive prefix of the per-sample counts (phase 0), computed by the block itself: no scan launch
     int part = 0;
     for (int i = tid; i < b; i += 256) part += counts[i];
     scan[tid] = part;
@@ -101,6 +122,11 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
     __syncthreads();
   }
   if (phase == 0 && tid == 0) counts[b] = carry;
+  if (one_launch && tid == 0) {
+    counts[b] = carry;
+    cu[b] = base;
+    if (b == B - 1) { cu[B] = base + carry; *n_rows = base + carry; }
+  }
 }
 
 __global__ void scan_counts_kernel(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ cu,
@@ -278,17 +304,15 @@ extern "C" int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type
 extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos,
                               int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot,
                               int32_t* row_index, int32_t* type_ids, int32_t* pos_ids, float* mask_bias,
-                              int32_t* agg_row, void* stream) {
+                              int32_t* agg_row, uint32_t* seed_bump, void* stream) {
   ExpertTable tab;
   if (int e = make_table(experts, M, tab)) return e;
   if (!counts || !cu_seqlens || !n_rows_dev || !slot || !row_index || !type_ids || !pos_ids || !mask_bias || !agg_row)
     return MMT_ERR_ARG;
   const int S = 1 + M * (T + 1);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, s, tab, B, M, T, S, pack, max_pos, 0, counts, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, s, tab, B, M, T, S, pack, max_pos, 1, counts, cu_seqlens,
-                     n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row);
+  // one launch: every block counts the live tokens of the samples in front of it itself (<= B*M*T flags, trivial)
+  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, 2, counts,
+                     cu_seqlens, n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row, seed_bump);
   return (int)hipGetLastError();
 }
 

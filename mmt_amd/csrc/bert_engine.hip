@@ -185,24 +185,27 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       // the caller reads are computed (as queries against ALL keys).  RNG coordinates travel in t.rowidx, so the
       // dropout masks are the ones the full path would draw. ----
       TailWs& t = w.t;
-      TRY(mmt_rows_gather(hin32, b->out_rows, nc, d, t.res32, b->row_index, t.rowidx, stream));
       TRY(mmt_attn_fwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, b->batch,
                             b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
-      e = {};
-      e.bias = P.bo; e.res = t.res32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
-      e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-      TRY(mmt_gemm_nt_splitk(t.ctx, d, P.wo, d, t.z1, d, nc, d, d, MMT_EPI_BIAS_DROP_RES, &e, t.slabs, stream));
-      TRY(mmt_ln_fwd(t.z1, P.ln1_g, P.ln1_b, m->ln_eps, t.a32, t.a16, t.mean1, t.rstd1, nc, d, nullptr, stream));
+      // The split-K partial slabs of the two N = hidden GEMMs are summed by the LayerNorm pass that follows them, which
+      // also applies bias, dropout and the residual (gathered straight from the previous layer's output rows for the
+      // attention block): one launch instead of reduce-epilogue + LayerNorm (+ a row gather).
+      int sp = 0;
+      int64_t sstride = 0;
+      TRY(mmt_gemm_splitk_geometry(nc, d, d, 0, &sp, &sstride));
+      TRY(mmt_gemm_nt_splitk_ex(t.ctx, d, P.wo, d, nullptr, d, nc, d, d, MMT_EPI_F32, nullptr, t.slabs, 0, 0, nullptr, 1, stream));
+      TRY(mmt_splitk_ln_fwd(t.slabs, sp, sstride, P.bo, hin32, b->out_rows, nullptr, b->row_index, t.rowidx,
+                            site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, t.z1, P.ln1_g, P.ln1_b, m->ln_eps, t.a32, t.a16,
+                            t.mean1, t.rstd1, nc, d, stream));
       e = {};
       e.bias = P.b1; e.out2 = t.g; e.ldout2 = I;
       TRY(mmt_gemm_nt_bf16(t.a16, d, P.w1, d, t.hpre, I, nc, I, d, MMT_EPI_BIAS_GELU, &e, nullptr, stream));
-      e = {};
-      e.bias = P.b2; e.res = t.a32; e.ldres = d; e.row_index = t.rowidx; e.seed_dev = b->seed_dev;
-      e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
-      TRY(mmt_gemm_nt_splitk(t.g, I, P.w2, I, t.z2, d, nc, d, I, MMT_EPI_BIAS_DROP_RES, &e, t.slabs, stream));
+      TRY(mmt_gemm_splitk_geometry(nc, d, I, 0, &sp, &sstride));
+      TRY(mmt_gemm_nt_splitk_ex(t.g, I, P.w2, I, nullptr, d, nc, d, I, MMT_EPI_F32, nullptr, t.slabs, 0, 0, nullptr, 1, stream));
       // the nc read-out rows are returned COMPACT: out_last[i] = sequence_output[out_rows[i]], i < nc
-      TRY(mmt_ln_fwd(t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, t.dy /* bf16 copy nobody reads */, t.mean2, t.rstd2, nc, d,
-                     nullptr, stream));
+      TRY(mmt_splitk_ln_fwd(t.slabs, sp, sstride, P.b2, t.a32, nullptr, t.rowidx, nullptr, nullptr, site_key(l, SITE_FFN_OUT), th,
+                            sh, b->seed_dev, t.z2, P.ln2_g, P.ln2_b, m->ln_eps, out_last, nullptr, t.mean2, t.rstd2, nc, d,
+                            stream));
       break;
     }
     TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
@@ -277,11 +280,16 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       MmtEpilogue e = {};
       e.aux = t.hpre; e.ldaux = I;
       TRY(mmt_gemm_nt_bf16(t.dy2, d, P.w2_t, d, t.dhpre, I, nc, I, d, MMT_EPI_DGELU, &e, nullptr, stream));
-      e = {};
-      e.res = t.dz; e.ldres = d;
-      TRY(mmt_gemm_nt_splitk(t.dhpre, I, P.w1_t, I, t.dA, d, nc, d, I, MMT_EPI_ADD_F32, &e, t.slabs, stream));
-      TRY(mmt_ln_bwd(t.dA, t.z1, t.mean1, t.rstd1, P.ln1_g, t.dz, t.dy, w.ln_partials[2 * l + 1], nc, d, 1, nullptr,
-                     t.rowidx, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+      {  // dA = dhpre . W1 + dz: the split-K slabs and the residual gradient are summed by the LayerNorm backward itself
+        int sp = 0;
+        int64_t sstride = 0;
+        TRY(mmt_gemm_splitk_geometry(nc, d, I, 0, &sp, &sstride));
+        TRY(mmt_gemm_nt_splitk_ex(t.dhpre, I, P.w1_t, I, nullptr, d, nc, d, I, MMT_EPI_F32, nullptr, t.slabs, 0, 0, nullptr, 1,
+                                  stream));
+        // t.dz is read (residual gradient) and rewritten (LN1 input gradient) by the same lanes at the same elements
+        TRY(mmt_ln_bwd_slabs(t.slabs, sp, sstride, t.dz, t.z1, t.mean1, t.rstd1, P.ln1_g, t.dz, t.dy, w.ln_partials[2 * l + 1],
+                             nc, d, 1, t.rowidx, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+      }
       add_job(w.ln_partials[2 * l + 1], cblocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
       e = {};
       TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));

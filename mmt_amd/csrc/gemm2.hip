@@ -425,6 +425,20 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   }
 }
 
+// geometry of the slabs mmt_gemm_nt_splitk_ex(..., no_epilogue = 1) leaves behind: *splits slabs of *slab_stride floats,
+// leading dimension N (for consumers that fold the reduction into their own pass)
+extern "C" int mmt_gemm_splitk_geometry(int M, int N, int K, int splits_requested, int* splits, int64_t* slab_stride) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % BK || !splits || !slab_stride) return MMT_ERR_ARG;
+  const int ksteps = K / BK;
+  int sp = splits_requested <= 0 ? 16 : splits_requested;
+  if (sp > ksteps) sp = ksteps;
+  if (sp > 16) sp = 16;
+  const int per = (ksteps + sp - 1) / sp;
+  *splits = (ksteps + per - 1) / per;
+  *slab_stride = (int64_t)((M + 127) / 128 * 128) * N;
+  return 0;
+}
+
 extern "C" int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K) {
   const int splits = K / BK < 16 ? K / BK : 16;
   return (int64_t)(splits < 1 ? 1 : splits) * ((M + 127) / 128 * 128) * N;

@@ -75,6 +75,94 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   }
 }
 
+// Split-K GEMM epilogue + LayerNorm in one pass (the compact last layer: a few hundred rows, where every extra launch
+// is ~5 us of pure latency): z = sum_s slab[s][row] + bias -> dropout -> + residual (optionally gathered through
+// res_rows) -> saved; h = LN(z).  One wave per row.  orow (RNG coordinate) = rowidx[row] if given, else derived as
+// row_index[res_rows[row]] and written to rowidx_out for the kernels that follow.
+struct SplitkLnArgs {
+  const float* slabs; int splits; int64_t slab_stride;
+  const float *bias, *res; const int32_t *res_rows, *rowidx, *row_index; int32_t* rowidx_out;
+  uint32_t drop_key, thr16; float drop_scale; const uint32_t* seed_dev;
+  float* z_out; const float *gamma, *beta; float eps;
+  float* h32; bf16_t* h16; float *mean, *rstd;
+  int rows, d;
+};
+__global__ __launch_bounds__(256) void splitk_ln_fwd_kernel(SplitkLnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int d = a.d, nch = d >> 8;
+  const int64_t rrow = a.res_rows ? a.res_rows[row] : row;
+  int orow;
+  if (a.rowidx) orow = a.rowidx[row];
+  else {
+    orow = a.row_index ? a.row_index[rrow] : (int)rrow;
+    if (a.rowidx_out && lane == 0) a.rowidx_out[row] = orow;
+  }
+  const unsigned dkey = eff_key(a.drop_key, a.seed_dev);
+  f32x4 x[MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nch) {
+      const int col = c * 256 + lane * 4;
+      const float* p0 = a.slabs + (int64_t)row * d + col;
+      f32x4 v = *(const f32x4*)p0;
+      int sp = 1;
+      for (; sp + 3 < a.splits; sp += 4) {  // fixed association (deterministic), four loads in flight
+        const f32x4 a0 = *(const f32x4*)(p0 + (int64_t)sp * a.slab_stride), a1 = *(const f32x4*)(p0 + (int64_t)(sp + 1) * a.slab_stride);
+        const f32x4 a2 = *(const f32x4*)(p0 + (int64_t)(sp + 2) * a.slab_stride), a3 = *(const f32x4*)(p0 + (int64_t)(sp + 3) * a.slab_stride);
+        v += (a0 + a1) + (a2 + a3);
+      }
+      for (; sp < a.splits; ++sp) v += *(const f32x4*)(p0 + (int64_t)sp * a.slab_stride);
+      v += *(const f32x4*)(a.bias + col);
+      if (a.thr16) {
+        bool k[4];
+        keep4(dkey, (unsigned long long)orow * (unsigned)d + (unsigned)col, a.thr16, k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * a.drop_scale : 0.f;
+      }
+      v += *(const f32x4*)(a.res + rrow * d + col);
+      *(f32x4*)(a.z_out + (int64_t)row * d + col) = v;
+      x[c] = v;
+      s += v[0] + v[1] + v[2] + v[3];
+    }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nch) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float t = x[c][k] - mean; q += t * t; }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + a.eps);
+  if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nch) {
+      const int col = c * 256 + lane * 4;
+      const f32x4 g = *(const f32x4*)(a.gamma + col), b = *(const f32x4*)(a.beta + col);
+      f32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = (x[c][k] - mean) * rstd * g[k] + b[k];
+      if (a.h32) *(f32x4*)(a.h32 + (int64_t)row * d + col) = y;
+      if (a.h16) *(u32x2*)(a.h16 + (int64_t)row * d + col) = (u32x2){pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+    }
+}
+
+extern "C" int mmt_splitk_ln_fwd(const float* slabs, int splits, int64_t slab_stride, const float* bias, const float* res,
+                                 const int32_t* res_rows, const int32_t* rowidx, const int32_t* row_index, int32_t* rowidx_out,
+                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
+                                 const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean,
+                                 float* rstd, int rows, int d, void* stream) {
+  if (!slabs || splits <= 0 || !bias || !res || !z_out || !gamma || !beta || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  SplitkLnArgs a = {slabs, splits, slab_stride, bias, res, res_rows, rowidx, row_index, rowidx_out, drop_key, thr16, drop_scale,
+                    seed_dev, z_out, gamma, beta, eps, h32, (bf16_t*)h16, mean, rstd, rows, d};
+  hipLaunchKernelGGL(splitk_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 // DROP: 0 none, 1 dropout applied BEFORE the LN input (dy = mask*dz*scale), 2 dropout applied AFTER the
 // LN output (incoming dout is masked first; embeddings).
 // 8 waves per block, RPW rows per wave with every load of the wave's rows issued up front (the previous version -- 4 waves
@@ -87,7 +175,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, float* __restrict__ dz_out,
     bf16_t* __restrict__ dy_out, float* __restrict__ partials, int rows,
     const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
-    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev) {
+    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev, int slab_splits, int64_t slab_stride,
+    const float* slab_res) {
+  // slab_splits > 0: `dout` is the first of slab_splits split-K partial slabs and the incoming gradient is their sum
+  // (+ slab_res): the epilogue of the input-gradient GEMM that precedes this LayerNorm backward, folded in
   extern __shared__ __attribute__((aligned(16))) float red_raw[];  // [LNB_WAVES][3][d]
   const unsigned drop_key = eff_key(drop_key_in, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,6 +205,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
         const int col = c * 256 + lane * 4;
         go[q][c] = *(const f32x4*)(dout + (int64_t)rr * d + col);
         zz[q][c] = *(const f32x4*)(z + (int64_t)rr * d + col);
+        if (slab_splits > 0) {  // block-uniform
+          for (int sp = 1; sp < slab_splits; ++sp) go[q][c] += *(const f32x4*)(dout + (int64_t)sp * slab_stride + (int64_t)rr * d + col);
+          if (slab_res) go[q][c] += *(const f32x4*)(slab_res + (int64_t)rr * d + col);
+        }
       }
   }
   f32x4 gm[NCH];
@@ -485,11 +580,11 @@ extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, 
 // compact last-layer LayerNorm is not a 14-block launch
 extern "C" int mmt_ln_bwd_rows_per_block(int rows) { return rows <= 2048 ? 8 : 16; }
 
-extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
+static int ln_bwd_impl(const float* dout, const float* z, const float* mean, const float* rstd,
                           const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
                           int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
                           uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
-                          void* stream) {
+                          int slab_splits, int64_t slab_stride, const float* slab_res, void* stream) {
   if (!dout || !z || !mean || !rstd || !gamma || !partials || rows <= 0) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   const int rpb = mmt_ln_bwd_rows_per_block(rows), grid = (rows + rpb - 1) / rpb;
@@ -505,7 +600,8 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
       configured = true;                                                                                          \
     }                                                                                                             \
     hipLaunchKernelGGL((ln_bwd_kernel<MODE, RPW, NCH>), dim3(grid), dim3(64 * LNB_WAVES), lds, s, dout, z, mean, rstd, gamma, \
-                       dz, (bf16_t*)dy, partials, rows, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev); \
+                       dz, (bf16_t*)dy, partials, rows, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev,  \
+                       slab_splits, slab_stride, slab_res);                                                       \
   } while (0)
 #define LN_BWD_NCH(MODE, RPW)                                    \
   switch (d >> 8) {                                              \
@@ -523,6 +619,26 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
 #undef LN_BWD_NCH
 #undef LN_BWD_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, const float* rstd,
+                          const float* gamma, float* dz, void* dy, float* partials, int rows, int d,
+                          int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
+                          uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
+                          void* stream) {
+  return ln_bwd_impl(dout, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, n_rows_dev, row_index, drop_key, thr16,
+                     drop_scale, seed_dev, 0, 0, nullptr, stream);
+}
+
+// the same with the incoming gradient given as split-K partial slabs (+ an optional residual gradient): dout = sum_s
+// slabs[s] + res -- the ADD_F32 epilogue of the input-gradient GEMM in front of this LayerNorm, without its own launch
+extern "C" int mmt_ln_bwd_slabs(const float* slabs, int splits, int64_t slab_stride, const float* res, const float* z,
+                                const float* mean, const float* rstd, const float* gamma, float* dz, void* dy,
+                                float* partials, int rows, int d, int drop_mode, const int32_t* row_index,
+                                uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
+  if (splits <= 0) return MMT_ERR_ARG;
+  return ln_bwd_impl(slabs, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, nullptr, row_index, drop_key, thr16,
+                     drop_scale, seed_dev, splits, slab_stride, res, stream);
 }
 
 extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,

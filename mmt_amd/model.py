@@ -462,10 +462,15 @@ class CENet(nn.Module):
     L, m, d = _lib.lib(), len(self.modalities), self.same_dim
     io, stream = plan.io, ops._stream()
     max_pos = self.vid_bert_params['max_position_embeddings'] - 1
+    # a training forward draws a fresh dropout seed: the plan kernel bumps the encoder's seed word itself (and the
+    # encoder is told not to), one launch less per step
+    vb = self.vid_bert
+    bump = vb._seed_dev if (vb.training and torch.is_grad_enabled() and vb._seed_dev is not None) else None
+    vb._seed_bumped = bump is not None
     check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
                            ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
                            ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
-                           stream), 'mmt_video_plan')
+                           ops._p(bump), stream), 'mmt_video_plan')
     check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, stream), 'mmt_video_cast')
     ops.gemm_nt_grouped([(plan.x[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
                           self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows)
