@@ -36,11 +36,11 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
   if (phase == 2 && b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
   if (phase == 2) {  // ONE launch: the block counts the live tokens of the samples in front of it itself
     int part = 0;
-    if (pack) {
-      const int per = M * T;  // FEA slots per sample; CLS + M AGG tokens are always live
-      for (int i = tid; i < b * per; i += 256) {
-        const int bb = i / per, r = i % per;
-        part += tab.e[r / T].ind[(int64_t)bb * T + r % T] != 0.f;
+    if (pack) {  // FEA slots of the samples 0..b-1 (CLS + M AGG tokens are always live): ind is [B, T] per expert
+#pragma unroll 1
+      for (int ex = 0; ex < M; ++ex) {  // uniform expert loop: the table entry stays in scalar registers
+        const float* __restrict__ ind_e = tab.e[ex].ind;
+        for (int i = tid; i < b * T; i += 256) part += ind_e[i] != 0.f;
       }
     }
     scan[tid] = part;

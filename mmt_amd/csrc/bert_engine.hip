@@ -371,8 +371,13 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   const int chunks = mmt_table_grad_chunks();
   const bool pos_partials = b->pos_ids && m->max_pos <= 64;
   // token-type table (+ the temporal-position table when it is small) as one-hot MFMA products, ONE launch for both
-  TRY(mmt_table_grad_partials_pair(dfeatures, b->type_ids, m->type_vocab, w.table_scratch[0], pos_partials ? b->pos_ids : nullptr,
-                                   m->max_pos, w.table_scratch[1], rows, d, nr, stream));
+  if (m->type_vocab <= 64) {
+    TRY(mmt_table_grad_partials_pair(dfeatures, b->type_ids, m->type_vocab, w.table_scratch[0],
+                                     pos_partials ? b->pos_ids : nullptr, m->max_pos, w.table_scratch[1], rows, d, nr, stream));
+  } else {  // large token-type vocabularies: the scan kernel
+    TRY(mmt_table_grad_partials(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch[0], stream));
+    if (pos_partials) TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], stream));
+  }
   add_job(w.table_scratch[0], chunks, 1, 1, m->type_vocab * d, m->g_type_emb, nullptr);
   if (pos_partials) add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
   else if (b->pos_ids)  // BERT-base position table (512 rows, a few dozen in use): no vocab-sized partial sums

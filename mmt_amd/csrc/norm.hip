@@ -107,14 +107,14 @@ __global__ __launch_bounds__(256) void splitk_ln_fwd_kernel(SplitkLnArgs a) {
     if (c < nch) {
       const int col = c * 256 + lane * 4;
       const float* p0 = a.slabs + (int64_t)row * d + col;
-      f32x4 v = *(const f32x4*)p0;
-      int sp = 1;
-      for (; sp + 3 < a.splits; sp += 4) {  // fixed association (deterministic), four loads in flight
-        const f32x4 a0 = *(const f32x4*)(p0 + (int64_t)sp * a.slab_stride), a1 = *(const f32x4*)(p0 + (int64_t)(sp + 1) * a.slab_stride);
-        const f32x4 a2 = *(const f32x4*)(p0 + (int64_t)(sp + 2) * a.slab_stride), a3 = *(const f32x4*)(p0 + (int64_t)(sp + 3) * a.slab_stride);
-        v += (a0 + a1) + (a2 + a3);
-      }
-      for (; sp < a.splits; ++sp) v += *(const f32x4*)(p0 + (int64_t)sp * a.slab_stride);
+      f32x4 part[16];  // every slab load of the chunk in flight together (splits <= 16), fixed summation order
+#pragma unroll
+      for (int sp = 0; sp < 16; ++sp)
+        part[sp] = sp < a.splits ? *(const f32x4*)(p0 + (int64_t)sp * a.slab_stride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 resv = *(const f32x4*)(a.res + rrow * d + col);
+      f32x4 v = part[0];
+#pragma unroll
+      for (int sp = 1; sp < 16; ++sp) v += part[sp];
       v += *(const f32x4*)(a.bias + col);
       if (a.thr16) {
         bool k[4];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void splitk_ln_fwd_kernel(SplitkLnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * a.drop_scale : 0.f;
       }
-      v += *(const f32x4*)(a.res + rrow * d + col);
+      v += resv;
       *(f32x4*)(a.z_out + (int64_t)row * d + col) = v;
       x[c] = v;
       s += v[0] + v[1] + v[2] + v[3];
@@ -155,7 +155,7 @@ extern "C" int mmt_splitk_ln_fwd(const float* slabs, int splits, int64_t slab_st
                                  uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
                                  const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean,
                                  float* rstd, int rows, int d, void* stream) {
-  if (!slabs || splits <= 0 || !bias || !res || !z_out || !gamma || !beta || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
+  if (!slabs || splits <= 0 || splits > 16 || !bias || !res || !z_out || !gamma || !beta || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   SplitkLnArgs a = {slabs, splits, slab_stride, bias, res, res_rows, rowidx, row_index, rowidx_out, drop_key, thr16, drop_scale,
                     seed_dev, z_out, gamma, beta, eps, h32, (bf16_t*)h16, mean, rstd, rows, d};
@@ -205,9 +205,17 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
         const int col = c * 256 + lane * 4;
         go[q][c] = *(const f32x4*)(dout + (int64_t)rr * d + col);
         zz[q][c] = *(const f32x4*)(z + (int64_t)rr * d + col);
-        if (slab_splits > 0) {  // block-uniform
-          for (int sp = 1; sp < slab_splits; ++sp) go[q][c] += *(const f32x4*)(dout + (int64_t)sp * slab_stride + (int64_t)rr * d + col);
-          if (slab_res) go[q][c] += *(const f32x4*)(slab_res + (int64_t)rr * d + col);
+        if (slab_splits > 0) {  // block-uniform; every slab load in flight together (splits <= 16), fixed order
+          f32x4 part[15];
+#pragma unroll
+          for (int sp = 1; sp < 16; ++sp)
+            part[sp - 1] = sp < slab_splits ? *(const f32x4*)(dout + (int64_t)sp * slab_stride + (int64_t)rr * d + col)
+                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if (slab_res) rv = *(const f32x4*)(slab_res + (int64_t)rr * d + col);
+#pragma unroll
+          for (int sp = 0; sp < 15; ++sp) go[q][c] += part[sp];
+          go[q][c] += rv;
         }
       }
   }
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * CR_RG) void col_reduce_multi_kernel(ColJobs jo
 
 // partial[chunk][v][c] = sum over the chunk's rows with ids[row] == v of g[row][c].  grid = (vocab, d/256, chunks);
 // the chunks are then summed by col_reduce_kernel (fixed order => deterministic, no atomics).
-#define TABLE_CHUNKS 32
+#define TABLE_CHUNKS 64
 __global__ __launch_bounds__(256) void table_grad_kernel(
     const float* __restrict__ g, const int32_t* __restrict__ ids, int rows, int d, int vocab,
     const int32_t* __restrict__ n_rows_dev, float* __restrict__ partial) {
@@ -404,41 +412,64 @@ __global__ __launch_bounds__(256) void table_grad_kernel(
 // its chunk row by row per vocabulary entry (16.9 + 11.8 us for the two tables of config B); this one needs ~4 us.
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct TablePair { const int32_t* ids[2]; float* partial[2]; int vocab[2]; };
+#define TG_ROWS 64  // rows per burst: [64][128] fp32 = 32 KiB of LDS, one memory round trip
 __global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __restrict__ g, TablePair tp, int rows, int d,
                                                               const int32_t* __restrict__ n_rows_dev) {
-  const int which = blockIdx.z;
-  const int32_t* __restrict__ ids = tp.ids[which];
-  float* __restrict__ partial = tp.partial[which];
-  const int vocab = tp.vocab[which];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const int c0 = (blockIdx.x * 4 + wave) * 32, chunk = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float gt[TG_ROWS][128 + 4];
+  __shared__ int32_t idt[2][TG_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int cb = blockIdx.x * 128, chunk = blockIdx.y;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int per = (nrows + TABLE_CHUNKS - 1) / TABLE_CHUNKS;
   const int r_begin = chunk * per, r_end = min(nrows, r_begin + per);
-  for (int v0 = 0; v0 < vocab; v0 += 32) {
-    f32x16_t acc;
+  const int ntab = tp.ids[1] ? 2 : 1;
+  f32x16_t acc[2][2];  // [table][vocabulary tile of 32]: vocab <= 64
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int myv = v0 + l31;
-    for (int r0 = r_begin; r0 < r_end; r0 += 16) {  // 8 MFMAs (16 rows) per trip, loads issued together
-      float bv[8];
-      int idv[8];
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int r = r0 + 2 * t + h;
-        const bool ok = r < r_end;
-        bv[t] = ok ? g[(int64_t)r * d + c0 + l31] : 0.f;
-        idv[t] = ok ? ids[r] : -1;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  for (int r0 = r_begin; r0 < r_end; r0 += TG_ROWS) {
+    // burst: 64 rows x 128 columns of g (512-byte row segments, 16 B per lane) + the ids of both tables
+#pragma unroll
+    for (int i = 0; i < TG_ROWS * 32 / 256; ++i) {
+      const int e = i * 256 + tid, rr = e >> 5, c4 = (e & 31) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + rr < r_end) v = *(const f32x4*)(g + (int64_t)(r0 + rr) * d + cb + c4);
+      *(f32x4*)(&gt[rr][c4]) = v;
+    }
+    if (tid < 2 * TG_ROWS) {
+      const int t = tid / TG_ROWS, rr = tid % TG_ROWS;
+      idt[t][rr] = (t < ntab && r0 + rr < r_end) ? tp.ids[t][r0 + rr] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t >= ntab) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u * 32 >= tp.vocab[t]) continue;
+        const int myv = u * 32 + l31;
+#pragma unroll 8
+        for (int kk = 0; kk < TG_ROWS / 2; ++kk) {
+          const int k = 2 * kk + h;
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(idt[t][k] == myv ? 1.0f : 0.0f, gt[k][wave * 32 + l31], acc[t][u], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(idv[t] == myv ? 1.0f : 0.0f, bv[t], acc, 0, 0, 0);
     }
+    __syncthreads();
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {  // lane holds column c0 + l31, rows (r & 3) + 8 (r >> 2) + 4 h
-      const int v = v0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (v < vocab) partial[((int64_t)chunk * vocab + v) * d + c0 + l31] = acc[r];
-    }
+  for (int t = 0; t < 2; ++t) {
+    if (t >= ntab) continue;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // lane holds column cb + 32 wave + l31, vocabulary rows (r & 3) + 8 (r >> 2) + 4 h
+        const int v = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (v < tp.vocab[t]) tp.partial[t][((int64_t)chunk * tp.vocab[t] + v) * d + cb + wave * 32 + l31] = acc[t][u][r];
+      }
   }
 }
 
@@ -636,7 +667,7 @@ extern "C" int mmt_ln_bwd_slabs(const float* slabs, int splits, int64_t slab_str
                                 const float* mean, const float* rstd, const float* gamma, float* dz, void* dy,
                                 float* partials, int rows, int d, int drop_mode, const int32_t* row_index,
                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
-  if (splits <= 0) return MMT_ERR_ARG;
+  if (splits <= 0 || splits > 16) return MMT_ERR_ARG;
   return ln_bwd_impl(slabs, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, nullptr, row_index, drop_key, thr16,
                      drop_scale, seed_dev, splits, slab_stride, res, stream);
 }
@@ -684,10 +715,10 @@ extern "C" int mmt_table_grad_chunks(void) { return TABLE_CHUNKS; }
 extern "C" int mmt_table_grad_partials_pair(const float* g, const int32_t* ids0, int vocab0, float* scratch0,
                                             const int32_t* ids1, int vocab1, float* scratch1, int rows, int d,
                                             const int32_t* n_rows_dev, void* stream) {
-  if (!g || !ids0 || !scratch0 || rows <= 0 || vocab0 <= 0 || d % 128) return MMT_ERR_ARG;
-  if (ids1 && (!scratch1 || vocab1 <= 0)) return MMT_ERR_ARG;
+  if (!g || !ids0 || !scratch0 || rows <= 0 || vocab0 <= 0 || vocab0 > 64 || d % 128) return MMT_ERR_ARG;
+  if (ids1 && (!scratch1 || vocab1 <= 0 || vocab1 > 64)) return MMT_ERR_ARG;
   TablePair tp = {{ids0, ids1}, {scratch0, scratch1}, {vocab0, vocab1}};
-  hipLaunchKernelGGL(table_grad_mfma_kernel, dim3(d / 128, TABLE_CHUNKS, ids1 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, g, tp,
+  hipLaunchKernelGGL(table_grad_mfma_kernel, dim3(d / 128, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, tp,
                      rows, d, n_rows_dev);
   return (int)hipGetLastError();
 }

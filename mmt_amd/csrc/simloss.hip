@@ -83,31 +83,46 @@ __global__ __launch_bounds__(256) void sims_fwd_kernel(const float* __restrict__
 // sims_fwd_kernel is a chain of M dependent wave reductions per wave (10.8 us at n = 32); here all of a wave's dot
 // products are independent (6 us).  LDS: text row [M][d] + dots row [NV][M].
 #define SF_WAVES 16
+#define SF_VCHUNK 8  // videos per block
 __global__ __launch_bounds__(64 * SF_WAVES) void sims_fwd_small_kernel(const float* __restrict__ txt, const float* __restrict__ vid,
                                                                        const float* __restrict__ tw, const float* __restrict__ vw,
                                                                        int NT, int NV, int M, int d, float* __restrict__ sims,
                                                                        float* __restrict__ dots) {
-  extern __shared__ __attribute__((aligned(16))) float ts[];  // [M][d] text row | [NV][M] dots of this row
+  extern __shared__ __attribute__((aligned(16))) float ts[];  // [M][d] text row | [SF_VCHUNK][M] dots of this block
   float* drow = ts + M * d;
-  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x, v0 = blockIdx.y * SF_VCHUNK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = min(SF_VCHUNK, NV - v0);
   for (int i = threadIdx.x * 4; i < M * d; i += 256 * SF_WAVES) *(f32x4*)(ts + i) = *(const f32x4*)(txt + (int64_t)t * M * d + i);
   __syncthreads();
-  for (int p = wave; p < NV * M; p += SF_WAVES) {  // pair p = (v, m): row p of vid viewed as [NV*M][d]
-    const int m = p % M;
-    float acc = 0.f;
+  const int npair = nv * M;
+  for (int p = wave; p < npair; p += 2 * SF_WAVES) {  // pair p = (video v0 + p / M, expert p % M); two pairs per trip
+    const int p1 = p + SF_WAVES;
+    const bool two = p1 < npair;
+    const int m0 = p % M, m1 = two ? p1 % M : 0;
+    const float* y0 = vid + ((int64_t)v0 * M + p) * d;
+    const float* y1 = vid + ((int64_t)v0 * M + (two ? p1 : p)) * d;
+    float a0 = 0.f, a1 = 0.f;
     for (int c = lane * 4; c < d; c += 256) {
-      const f32x4 x = *(const f32x4*)(ts + m * d + c), y = *(const f32x4*)(vid + (int64_t)p * d + c);
-      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      const f32x4 u0 = *(const f32x4*)(y0 + c), u1 = *(const f32x4*)(y1 + c);
+      const f32x4 x0 = *(const f32x4*)(ts + m0 * d + c), x1 = *(const f32x4*)(ts + m1 * d + c);
+      a0 += x0[0] * u0[0] + x0[1] * u0[1] + x0[2] * u0[2] + x0[3] * u0[3];
+      a1 += x1[0] * u1[0] + x1[1] * u1[1] + x1[2] * u1[2] + x1[3] * u1[3];
     }
-    const float dm = wave_sum(acc);
-    if (lane == 0) { drow[p] = dm; dots[(int64_t)t * NV * M + p] = dm; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+    if (lane == 0) {
+      drow[p] = a0;
+      dots[((int64_t)t * NV + v0) * M + p] = a0;
+      if (two) { drow[p1] = a1; dots[((int64_t)t * NV + v0) * M + p1] = a1; }
+    }
   }
   __syncthreads();
-  for (int v = threadIdx.x; v < NV; v += 64 * SF_WAVES) {
+  if ((int)threadIdx.x < nv) {
+    const int v = v0 + threadIdx.x;
     float nrm = 0.f, sacc = 0.f;
     for (int m = 0; m < M; ++m) nrm += tw[t * M + m] * vw[v * M + m];
     if (nrm == 0.f) nrm = 1e-5f;  // model.py:816
-    for (int m = 0; m < M; ++m) sacc += tw[t * M + m] * vw[v * M + m] / nrm * drow[v * M + m];
+    for (int m = 0; m < M; ++m) sacc += tw[t * M + m] * vw[v * M + m] / nrm * drow[threadIdx.x * M + m];
     sims[(int64_t)t * NV + v] = sacc;
   }
 }
@@ -135,9 +150,12 @@ __global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLos
   float* gself = lse_c + n;              // [n]  G of this block's row (side 0) or column (side 1)
   float* racc = gself + ((n + 3) & ~3);  // [SB_WAVES][d]
   float* rw = racc + SB_WAVES * d;       // [SB_WAVES]
+  float* twl = rw + SB_WAVES;            // [n][M] text / video mixture weights
+  float* vwl = twl + n * M;
   const int side = blockIdx.z, self = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < n * n; i += 64 * SB_WAVES) S[i] = a.sims[i];
+  for (int i = tid; i < n * M; i += 64 * SB_WAVES) { twl[i] = a.tw[i]; vwl[i] = a.vw[i]; }
   __syncthreads();
   const float norm = a.kind == 0 ? (a.fix_norm ? 2.0f * n * (n - 1) : 2.0f * n * n) : (float)n;
   if (a.kind == 1) {  // InfoNCE: logsumexp of every row and column
@@ -184,29 +202,43 @@ __global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLos
   float* __restrict__ dx = side == 0 ? a.dtxt : a.dvid;
   float* __restrict__ dwt = side == 0 ? a.dtw : a.dvw;
   const float* other = side == 0 ? a.vid : a.txt;
-  const float* wother = side == 0 ? a.vw : a.tw;
   f32x4 acc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dws = 0.f;
-  for (int o = wave; o < n; o += SB_WAVES) {
-    const int t = side == 0 ? self : o, v = side == 0 ? o : self;
-    const float g = gself[o];
-    const float* dm = a.dots + ((int64_t)t * n + v) * M;
-    float nrm = 0.f, gw = 0.f;
-    for (int j = 0; j < M; ++j) nrm += a.tw[t * M + j] * a.vw[v * M + j];
-    const bool zero = nrm == 0.f;
-    if (zero) nrm = 1e-5f;
-    for (int j = 0; j < M; ++j) gw += g * dm[j] * a.tw[t * M + j] * a.vw[v * M + j] / nrm;
-    const float w = a.tw[t * M + m] * a.vw[v * M + m] / nrm;
-    const float da = zero ? g * dm[m] / nrm : (g * dm[m] - gw) / nrm;
-    dws += da * wother[o * M + m];
-    const float coef = g * w;
+  const float* wo = side == 0 ? vwl : twl;
+  for (int o0 = wave; o0 < n; o0 += 2 * SB_WAVES) {  // two rows of the other side per trip: their loads fly together
+    float coef[2];
+    f32x4 rowv[2][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < d) acc[c] += *(const f32x4*)(other + ((int64_t)o * M + m) * d + col) * coef;
+    for (int q = 0; q < 2; ++q) {
+      const int o = o0 + q * SB_WAVES;
+      coef[q] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rowv[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (o >= n) continue;  // wave-uniform
+      const int t = side == 0 ? self : o, v = side == 0 ? o : self;
+      const float g = gself[o];
+      const float* dm = a.dots + ((int64_t)t * n + v) * M;
+      float nrm = 0.f, gw = 0.f;
+      for (int j = 0; j < M; ++j) nrm += twl[t * M + j] * vwl[v * M + j];
+      const bool zero = nrm == 0.f;
+      if (zero) nrm = 1e-5f;
+      for (int j = 0; j < M; ++j) gw += g * dm[j] * twl[t * M + j] * vwl[v * M + j] / nrm;
+      const float w = twl[t * M + m] * vwl[v * M + m] / nrm;
+      const float da = zero ? g * dm[m] / nrm : (g * dm[m] - gw) / nrm;
+      dws += da * wo[o * M + m];
+      coef[q] = g * w;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < d) rowv[q][c] = *(const f32x4*)(other + ((int64_t)o * M + m) * d + col);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += rowv[q][c] * coef[q];
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -508,9 +540,10 @@ extern "C" int mmt_sims_fwd(const float* txt, const float* vid, const float* tw,
   if (NT >= LARGE_N || NV >= LARGE_N) return sims_fwd_large(txt, vid, tw, vw, NT, NV, M, d, sims, dots, stream);
   const size_t lds = (size_t)M * d * sizeof(float);
   if (lds > 64 * 1024) return MMT_ERR_ARG;
-  if (lds + (size_t)NV * M * sizeof(float) <= 64 * 1024) {
-    hipLaunchKernelGGL(sims_fwd_small_kernel, dim3(NT), dim3(64 * SF_WAVES), lds + (size_t)NV * M * sizeof(float),
-                       (hipStream_t)stream, txt, vid, tw, vw, NT, NV, M, d, sims, dots);
+  if (lds + (size_t)SF_VCHUNK * M * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(sims_fwd_small_kernel, dim3(NT, (NV + SF_VCHUNK - 1) / SF_VCHUNK), dim3(64 * SF_WAVES),
+                       lds + (size_t)SF_VCHUNK * M * sizeof(float), (hipStream_t)stream, txt, vid, tw, vw, NT, NV, M, d, sims,
+                       dots);
     return (int)hipGetLastError();
   }
   int gy = (NV + 3) / 4;
@@ -532,11 +565,11 @@ extern "C" int mmt_simloss_bwd_small(const float* txt, const float* vid, const f
   if (dlast && !inv_norm) return MMT_ERR_ARG;
   SimLossArgs a = {txt, vid, tw, vw, sims, dots, n, M, d, kind, fix_norm, margin, loss, dtxt, dvid, dtw, dvw, inv_norm, out_rows,
                    dlast};
-  const size_t lds = ((size_t)n * n + 2 * n + ((n + 3) & ~3) + (size_t)SB_WAVES * d + SB_WAVES) * sizeof(float);
+  const size_t lds = ((size_t)n * n + 2 * n + ((n + 3) & ~3) + (size_t)SB_WAVES * d + SB_WAVES + 2 * (size_t)n * M) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     hipError_t rc = hipFuncSetAttribute((const void*)simloss_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((63 * 63 + 2 * 63 + 64 + SB_WAVES * 1024 + SB_WAVES) * sizeof(float)));
+                                        (int)((63 * 63 + 2 * 63 + 64 + SB_WAVES * 1024 + SB_WAVES + 2 * 63 * MAXM) * sizeof(float)));
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }

@@ -340,17 +340,19 @@ class GraphedTrainStep:
     st = {}
 
     def head():
-      fast = self._fast_loss_grads(e, self._globalize(e, g))
+      fast = self._fast_loss_grads(e, self._globalize(e, g), fuse_readout=True)
       if fast is None:
         raise RuntimeError('staged backward needs one caption per video and the native losses')
       self.loss, outs, grads = fast
       pairs = list(zip(outs, grads))
-      txt = [(o, gr) for o, gr in pairs if o is not e['vid_embds']]
+      h = model._stages
+      txt = [(o, gr) for o, gr in pairs if o is not e['vid_embds'] and o is not h['last']]
       if txt:
         torch.autograd.backward([o for o, _ in txt], [gr for _, gr in txt])  # text heads
-      gvid = next(gr for o, gr in pairs if o is e['vid_embds'])
-      h = model._stages
-      dlast, = torch.autograd.grad([e['vid_embds']], [h['last']], [gvid])  # read-out backward only
+      dlast = next((gr for o, gr in pairs if o is h['last']), None)  # the fused kernel already ran the read-out backward
+      if dlast is None:
+        gvid = next(gr for o, gr in pairs if o is e['vid_embds'])
+        dlast, = torch.autograd.grad([e['vid_embds']], [h['last']], [gvid])  # read-out backward only
       st['run'] = vb.backward_ranges(h['batch'], dlast, vb.training)
 
     def bottom():
