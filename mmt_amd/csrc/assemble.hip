@@ -37,10 +37,18 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
   if (phase == 2) {  // ONE launch: the block counts the live tokens of the samples in front of it itself
     int part = 0;
     if (pack) {  // FEA slots of the samples 0..b-1 (CLS + M AGG tokens are always live): ind is [B, T] per expert
-#pragma unroll 1
-      for (int ex = 0; ex < M; ++ex) {  // uniform expert loop: the table entry stays in scalar registers
-        const float* __restrict__ ind_e = tab.e[ex].ind;
-        for (int i = tid; i < b * T; i += 256) part += ind_e[i] != 0.f;
+      const int bT = b * T;
+#pragma unroll
+      for (int ex = 0; ex < MMT_MAX_EXPERTS; ++ex) {  // uniform, unrolled: every expert's flag loads are in flight together
+        if (ex < M) {
+          const float* __restrict__ ind_e = tab.e[ex].ind;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u;
+            if (i < bT) part += ind_e[i] != 0.f;
+          }
+          for (int i = tid + 1024; i < bT; i += 256) part += ind_e[i] != 0.f;
+        }
       }
     }
     scan[tid] = part;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void sims_fwd_small_kernel(const flo
 // row/column k for the diagonal; InfoNCE (loss.py:68-81) the row and column logsumexps.  Block (0, 0, 0) also writes the
 // loss.  Then the similarity backward of sims_bwd_kernel with 16 waves over the other side's rows, and for the video
 // side optionally the backward of the read-out normalisation (readout_bwd_kernel) straight into the engine's dlast.
-#define SB_WAVES 16
+#define SB_WAVES 8  // 118 VGPRs: two 8-wave blocks per CU, so the n * M * 2 = 448 blocks of config B are resident at once
 struct SimLossArgs {
   const float *txt, *vid, *tw, *vw, *sims, *dots;
   int n, M, d, kind, fix_norm;
@@ -247,21 +247,22 @@ __global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLos
   }
   if (lane == 0) rw[wave] = dws;
   __syncthreads();
-  // combine the waves' partial rows: thread i owns column(s) i, i + 1024, ...
+  // combine the waves' partial rows: thread i owns columns i and i + 512 (d <= 1024)
   const bool readout = side == 1 && a.dlast != nullptr;
   const int64_t row = (int64_t)self * M + m;
   float part = 0.f;
-  float gx[1];  // d <= 1024 and 1024 threads: one column per thread
-  {
-    const int i = tid;
-    float sum = 0.f;
+  float gx[2] = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + u * 64 * SB_WAVES;
     if (i < d) {
+      float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < SB_WAVES; ++w) sum += racc[w * d + i];
       if (dx) dx[row * d + i] = sum;
-      if (readout) part = sum * a.vid[row * d + i];
+      if (readout) part += sum * a.vid[row * d + i];
+      gx[u] = sum;
     }
-    gx[0] = sum;
   }
   if (tid == 0 && dwt) {
     float sum = 0.f;
@@ -276,7 +277,12 @@ __global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLos
     float dot = 0.f;
     for (int w = 0; w < SB_WAVES; ++w) dot += racc[w];
     const int64_t orow = a.out_rows ? a.out_rows[row] : row;
-    if (tid < d) a.dlast[orow * d + tid] = (gx[0] - a.vid[row * d + tid] * dot) * a.inv_norm[row];
+    const float inv = a.inv_norm[row];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + u * 64 * SB_WAVES;
+      if (i < d) a.dlast[orow * d + i] = (gx[u] - a.vid[row * d + i] * dot) * inv;
+    }
   }
 }
 
