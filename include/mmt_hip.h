@@ -244,22 +244,29 @@ int mmt_colsum_bf16(const void* x, int64_t ld, int rows, int cols, const int32_t
  * mask_bias fp32 [rows] is the additive key mask (0 / -10000, bert.py:395); lse fp32 [rows, H]. */
 int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx, float* lse,
                  int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
-                 float drop_scale, const uint32_t* seed_dev, void* stream);
+                 float drop_scale, const uint32_t* seed_dev,
+                 const int32_t* row_index, void* stream);
 /* Backward of the above (autograd of bert.py:141-168): dqkv bf16 [rows, 3d]; delta fp32 [rows,H] scratch. */
 int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                  const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H, int d,
                  float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                 const uint32_t* seed_dev, void* stream);
+                 const uint32_t* seed_dev,
+                 const int32_t* row_index, void* stream);
 /* Query-subset attention (last encoder layer: only the rows that are read out need a context vector): queries are the
  * rows qsel[b*nq + i]; ctx / lse / dctx / delta are compact [B*nq, .]; qkv / dqkv keep the full layout.  dqkv must be
  * zero on entry in the Q section of the non-selected rows. */
 int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
                       void* ctx, float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
-                      float drop_scale, const uint32_t* seed_dev, void* stream);
+                      float drop_scale, const uint32_t* seed_dev,
+                 const int32_t* row_index, void* stream);
 int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
                       const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
                       int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                      const uint32_t* seed_dev, void* stream);
+                      const uint32_t* seed_dev,
+                 const int32_t* row_index, void* stream);
+/* (all four) row_index (nullable): token packing -- row_index[row] = b*S + original position of the token; the
+ * attention-probability dropout mask is keyed on ORIGINAL (query, key) positions, so packed and dense runs draw the same
+ * mask. */
 /* Test helper: the keep-mask mmt_attn_fwd draws, uint8 [B,H,S,S] (dense layout). */
 int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,
                           const uint32_t* seed_dev, void* stream);

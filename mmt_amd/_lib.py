@@ -144,13 +144,13 @@ SIGNATURES = {
     'mmt_table_grad_scratch_floats': (c_i64, [c_int, c_int]),
     'mmt_table_grad': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mmt_attn_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
-                             c_f32, c_vp, c_vp]),
+                             c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
-                             c_u32, c_u32, c_f32, c_vp, c_vp]),
+                             c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_fwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
-                                  c_f32, c_vp, c_vp]),
+                                  c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_bwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                  c_f32, c_u32, c_u32, c_f32, c_vp, c_vp]),
+                                  c_f32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_ln_fwd_scatter': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mmt_rows_gather': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_rows_scatter': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),

@@ -15,8 +15,9 @@
 // SWZ16(row) = ((row&7)<<1)|((row>>3)&1): conflict-free for both the b128 (row-per-lane) and the
 // transpose reads.  Tiles arrive by LDS-DMA with the swizzle applied on the source address.
 //
-// Dropout mask of element (b,h,q,k): hash of (key, (b*H+h)*S4+q) then of (k>>1); q,k are positions
-// inside the sample's (packed) sequence.  Backward regenerates it.
+// Dropout mask of element (b,h,q,k): hash of (key, (b*H+h)*S4+q) then of (k>>1); q,k are the ORIGINAL positions of the
+// tokens inside the sample (row_index[row] - b*S when the rows are packed), so a packed run draws exactly the mask of
+// the dense run.  Backward regenerates it.
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -130,15 +131,35 @@ struct AttnArgs {
   // the row of sample b's i-th selected query; ctx / lse / dctx / delta are then COMPACT [B*nq, .] buffers, while
   // qkv / dqkv keep the full token layout (every key still participates).
   const int32_t* qsel; int nq;
+  // token packing: row_index[row] = b * S_dense + original position (nullable: rows are dense, position = row - b*S)
+  const int32_t* row_index;
 };
+
+// original position of (packed) row `row` of sample b
+__device__ __forceinline__ int orig_pos(const AttnArgs& a, int b, int off, int row) {
+  return a.row_index ? a.row_index[row] - b * a.S_dense : row - off;
+}
+// keep flags of four consecutive (packed) keys whose original positions are kp[0..3]
+__device__ __forceinline__ void keep4_keys(unsigned rowkey, const int* kp, bool contiguous, unsigned thr16, bool keep[4]) {
+  if (contiguous) {  // dense rows: kp = k0 .. k0+3 with k0 % 4 == 0 -> two hashes serve four keys
+    const unsigned k0 = (unsigned)kp[0];
+    const unsigned r01 = mix32(rowkey ^ (k0 >> 1)), r23 = mix32(rowkey ^ ((k0 >> 1) + 1));
+    keep[0] = (r01 & 0xffffU) >= thr16; keep[1] = (r01 >> 16) >= thr16;
+    keep[2] = (r23 & 0xffffU) >= thr16; keep[3] = (r23 >> 16) >= thr16;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) keep[e] = attn_keep(rowkey, (unsigned)kp[e], thr16);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (q tiles of 64, H, B), 4 waves x 16 queries
 // ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2 + 2 * 64 * 2];
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][64]
+  int* kpos_s = (int*)(bias_s + 2 * 64);              // [2][64] original positions of the tile's keys
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
@@ -150,12 +171,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int nkt = (Sb + 63) >> 6;
   const bf16_t* Kg = a.qkv + a.d + h * DH;
   const bf16_t* Vg = a.qkv + 2 * a.d + h * DH;
+  const bool dense_keys = a.row_index == nullptr;
 
   const int qi = q0 + wave * 16 + li;
   const int qic = min(qi, nqs - 1);
   const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
   const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / lse
-  const int q_local = a.qsel ? qrow - off : qi;
+  const int q_local = orig_pos(a, b, off, qrow);
   bf16x8_t qf[DH / 32];
 #pragma unroll
   for (int kk = 0; kk < DH / 32; ++kk)
@@ -175,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (tid < 64) {
       const int k = kt * 64 + tid;
       bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
+      kpos_s[st * 64 + tid] = k < Sb ? orig_pos(a, b, off, off + k) : k;
     }
   };
   stage(0, 0);
@@ -210,12 +233,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s[f][r] = exp2f(s[f][r] - m_new); psum += s[f][r]; }
       if (a.thr16) {
-        const unsigned k0 = (unsigned)(kt * 64 + f * 16 + 4 * lg);
-        const unsigned r01 = mix32(rowkey ^ (k0 >> 1)), r23 = mix32(rowkey ^ ((k0 >> 1) + 1));
-        s[f][0] = (r01 & 0xffffU) >= a.thr16 ? s[f][0] * a.drop_scale : 0.f;
-        s[f][1] = (r01 >> 16) >= a.thr16 ? s[f][1] * a.drop_scale : 0.f;
-        s[f][2] = (r23 & 0xffffU) >= a.thr16 ? s[f][2] * a.drop_scale : 0.f;
-        s[f][3] = (r23 >> 16) >= a.thr16 ? s[f][3] * a.drop_scale : 0.f;
+        bool kp[4];
+        keep4_keys(rowkey, kpos_s + cur * 64 + f * 16 + 4 * lg, dense_keys, a.thr16, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[f][r] = kp[r] ? s[f][r] * a.drop_scale : 0.f;
       }
     }
     psum += __shfl_xor(psum, 16, 64);
@@ -248,8 +269,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2 + 2 * 64 * 2];
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);
+  int* kpos_s = (int*)(bias_s + 2 * 64);
+  const bool dense_keys = a.row_index == nullptr;
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int qic = min(qi, nqs - 1);
   const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
   const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / dctx / lse / delta
-  const int q_local = a.qsel ? qrow - off : qi;
+  const int q_local = orig_pos(a, b, off, qrow);
   if (a.qsel && blockIdx.x == 0) {
     // query-subset mode: dQ of the non-selected rows is zero -- this block (sample b, head h) clears its 128 columns
     // of every row of the sample; the selected rows are overwritten at the end (after the K-loop's barriers)
@@ -304,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if (tid < 64) {
       const int k = kt * 64 + tid;
       bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
+      kpos_s[st * 64 + tid] = k < Sb ? orig_pos(a, b, off, off + k) : k;
     }
   };
   stage(0, 0);
@@ -328,14 +352,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const f32x4 bv = *(const f32x4*)(bias_s + cur * 64 + f * 16 + 4 * lg);
-      const unsigned k0 = (unsigned)(kt * 64 + f * 16 + 4 * lg);
-      unsigned r01 = 0xffffffffU, r23 = 0xffffffffU;
-      if (a.thr16) { r01 = mix32(rowkey ^ (k0 >> 1)); r23 = mix32(rowkey ^ ((k0 >> 1) + 1)); }
-      const unsigned u[4] = {r01 & 0xffffU, r01 >> 16, r23 & 0xffffU, r23 >> 16};
+      bool kp[4] = {true, true, true, true};
+      if (a.thr16) keep4_keys(rowkey, kpos_s + cur * 64 + f * 16 + 4 * lg, dense_keys, a.thr16, kp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = exp2f(s[f][r] * c1 + bv[r] - lse2);
-        const float dp = (u[r] >= a.thr16) ? da[f][r] * a.drop_scale : 0.f;
+        const float dp = kp[r] ? da[f][r] * a.drop_scale : 0.f;
         s[f][r] = p * (dp - dl);  // dS
       }
     }
@@ -378,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int key_local = k0 + wave * 16 + li;
   const bool key_ok = key_local < Sb;
   const int krow = off + min(key_local, Sb - 1);
+  const int key_pos = orig_pos(a, b, off, krow);  // RNG coordinate of this lane's key
   bf16x8_t kf[DH / 32], vf[DH / 32];
 #pragma unroll
   for (int kk = 0; kk < DH / 32; ++kk) {
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int q = qt * 64 + tid;
       const int qc = min(q, nqs - 1);
       const int row = a.qsel ? b * a.nq + qc : off + qc;               // row in lse / delta
-      const int qpos = a.qsel ? a.qsel[b * a.nq + qc] - off : q;       // position inside the sample (RNG coordinate)
+      const int qpos = orig_pos(a, b, off, a.qsel ? a.qsel[b * a.nq + qc] : off + qc);  // original position (RNG coordinate)
       float* ax = aux_s + st * 192;
       ax[tid] = q < nqs ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
       ax[64 + tid] = a.delta[(int64_t)row * a.H + h];
@@ -444,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const float p = exp2f(s[f][r] * c1 + bias2 - l2[r]);
         bool keep = true;
-        if (a.thr16) keep = attn_keep(__float_as_uint(rkf[r]), (unsigned)key_local, a.thr16);
+        if (a.thr16) keep = attn_keep(__float_as_uint(rkf[r]), (unsigned)key_pos, a.thr16);
         pa[f][r] = keep ? p * a.drop_scale : 0.f;                 // A = dropout(P)
         const float dp = keep ? da[f][r] * a.drop_scale : 0.f;
         s[f][r] = p * (dp - dlt[r]);                              // dS
@@ -490,13 +513,14 @@ static int check_args(const void* qkv, int B, int S, int H, int d) {
 
 extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx,
                             float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key,
-                            uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
+                            uint32_t thr16, float drop_scale, const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.row_index = row_index;
   if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
@@ -505,7 +529,7 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
 extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                             const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
                             int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                            const uint32_t* seed_dev, void* stream) {
+                            const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta) return MMT_ERR_ARG;
   AttnArgs a = {};
@@ -513,6 +537,7 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.row_index = row_index;
   const dim3 grid((S + 63) / 64, H, B);
   if (d == H * 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -529,14 +554,14 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
 // Q section of non-selected rows (the kernels write dQ of the selected rows and dK / dV of every row).
 extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel,
                                  int nq, void* ctx, float* lse, int B, int S, int H, int d, float scale,
-                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
-                                 void* stream) {
+                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse || !qsel || nq <= 0) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
   if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -546,7 +571,7 @@ extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, con
 extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel,
                                  int nq, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta,
                                  int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
-                                 float drop_scale, const uint32_t* seed_dev, void* stream) {
+                                 float drop_scale, const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta || !qsel || nq <= 0) return MMT_ERR_ARG;
   AttnArgs a = {};
@@ -554,6 +579,7 @@ extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
+  a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
   if (d == H * 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);

@@ -186,7 +186,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       // dropout masks are the ones the full path would draw. ----
       TailWs& t = w.t;
       TRY(mmt_attn_fwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, b->batch,
-                            b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+                            b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
       // The split-K partial slabs of the two N = hidden GEMMs are summed by the LayerNorm pass that follows them, which
       // also applies bias, dropout and the residual (gathered straight from the previous layer's output rows for the
       // attention block): one launch instead of reduce-epilogue + LayerNorm (+ a row gather).
@@ -209,7 +209,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       break;
     }
     TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
-                     site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+                     site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
     e = {};
     e.bias = P.bo; e.res = hin32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
@@ -297,7 +297,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       // gradient t.dz likewise: the input-gradient GEMM runs without residual and t.dz is scatter-added afterwards
       TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
                             w.dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
-                            b->seed_dev, stream));
+                            b->seed_dev, b->row_index, stream));
       e = {};
       float* dnext = w.dA;
       TRY(gemm_hidden(w, rows, d, w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
@@ -340,7 +340,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     TRY(mmt_gemm_nt_bf16(w.dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
     TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, w.dqkv, w.delta, b->batch, b->seq,
-                     m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, stream));
+                     m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
     e = {};
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA

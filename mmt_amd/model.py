@@ -524,7 +524,8 @@ class CENet(nn.Module):
     plan.inputs = keep
     feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
     batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
-                        plan.rows, bsz, plan.seq, cu_seqlens=plan.cu, row_index=plan.row_index,
+                        plan.rows, bsz, plan.seq, cu_seqlens=plan.cu,
+                        row_index=plan.row_index if self.pack_tokens else None,  # dense rows ARE the original coordinates
                         n_rows_dev=plan.n_rows if self.pack_tokens else None,
                         out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
     last = self.vid_bert.run_engine(batch, feats)

@@ -230,7 +230,7 @@ def table_grad(g, ids, vocab, rows=None, n_rows_dev=None):
   return out
 
 
-def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0, seed_dev=None):
+def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0, seed_dev=None, row_index=None):
   _need_cuda(qkv)
   R, d3 = qkv.shape
   d = d3 // 3
@@ -238,12 +238,12 @@ def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p
   lse = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
   thr, sc = dropout_params(drop_p)
   check(_lib.lib().mmt_attn_fwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), B, S, H, d, scale,
-                                drop_key, thr, sc, _p(seed_dev), _stream()), 'mmt_attn_fwd')
+                                drop_key, thr, sc, _p(seed_dev), _p(row_index), _stream()), 'mmt_attn_fwd')
   return ctx, lse
 
 
 def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0,
-             seed_dev=None):
+             seed_dev=None, row_index=None):
   _need_cuda(qkv)
   R, d3 = qkv.shape
   d = d3 // 3
@@ -251,7 +251,7 @@ def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, dr
   delta = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
   thr, sc = dropout_params(drop_p)
   check(_lib.lib().mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
-                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _stream()), 'mmt_attn_bwd')
+                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _p(row_index), _stream()), 'mmt_attn_bwd')
   return dqkv
 
 

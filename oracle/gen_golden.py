@@ -62,6 +62,10 @@ FIXTURES = {
     # BASELINE.json configs[3] shape (long sequences): 7 experts x 100 tokens -> S = 708, max_pos 102; small batch
     'config4': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=4, max_tokens=100,
                     vb=dict(hidden=512, layers=4, heads=4, inter=3072, max_pos=102), seed=14),
+    # ... and the same shape at the BENCHMARK batch (32 pairs: 22 656 token rows, 177 row tiles of 128; attention scores
+    # (32, 4, 708, 708)): what BASELINE.json configs[3] is timed on
+    'config4b32': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=32, max_tokens=100,
+                       vb=dict(hidden=512, layers=4, heads=4, inter=3072, max_pos=102), seed=16),
     # BASELINE.json configs[4] encoder shape (HowTo100M-scale): d1024, 6 layers, 8 heads, I = 6144; small batch
     'config5': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=4, max_tokens=10,
                     vb=dict(hidden=1024, layers=6, heads=8, inter=6144, max_pos=32), seed=15),

@@ -530,3 +530,45 @@ def test_table_grad_pair_on_matrix_cores(rows, d, v0, v1, live):
       continue
     want = torch.zeros(v, d, device=_dev(), dtype=torch.float64).index_add_(0, ids[:n].long(), g[:n].double())
     _close('table', s.sum(0), want.float(), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize('DH', [128, 64])
+def test_attention_dropout_is_keyed_on_original_positions(DH):
+  """Token packing must not change which attention probabilities are dropped: the packed run (rows compacted, row_index
+  = b*S + original position) draws exactly the mask of the dense run on the same tokens -- forward and backward."""
+  from mmt_amd import ops
+  B, S, H = 3, 70, 2
+  d, scale = H * DH, 1.0 / math.sqrt(DH)
+  rows = B * S
+  R = ops.pad_rows(rows)
+  qkv = _rand((R, 3 * d), 1.0, seed=71, dtype=torch.bfloat16)
+  dctx = _rand((R, d), seed=72, dtype=torch.bfloat16)
+  gen = torch.Generator().manual_seed(73)
+  keep = torch.rand(B, S, generator=gen) > 0.4
+  keep[:, 0] = True
+  keep[1, 1::2] = False  # parity changes inside a sample: consecutive packed keys are NOT consecutive originally
+  bias = torch.zeros(R, device=_dev())
+  bias[:rows] = (~keep).reshape(-1).float().to(_dev()) * -10000.0
+  ctx_d, lse_d = ops.attn_fwd(qkv, bias, B, S, H, scale, drop_key=31, drop_p=0.2)
+  dq_d = ops.attn_bwd(qkv, bias, ctx_d, lse_d, dctx, B, S, H, scale, drop_key=31, drop_p=0.2)
+  idx = keep.reshape(-1).nonzero().reshape(-1).to(_dev())          # dense rows that survive, in order
+  n = idx.numel()
+  qkv_p, dctx_p = torch.zeros_like(qkv), torch.zeros_like(dctx)
+  qkv_p[:n], dctx_p[:n] = qkv[idx], dctx[idx]
+  cu = torch.zeros(B + 1, dtype=torch.int32)
+  cu[1:] = keep.sum(1).cumsum(0).int()
+  cu = cu.to(_dev())
+  row_index = torch.zeros(R, dtype=torch.int32, device=_dev())
+  row_index[:n] = idx.int()
+  bias_p = torch.zeros(R, device=_dev())
+  ctx_p, lse_p = ops.attn_fwd(qkv_p, bias_p, B, S, H, scale, cu_seqlens=cu, drop_key=31, drop_p=0.2, row_index=row_index)
+  dq_p = ops.attn_bwd(qkv_p, bias_p, ctx_p, lse_p, dctx_p, B, S, H, scale, cu_seqlens=cu, drop_key=31, drop_p=0.2,
+                      row_index=row_index)
+  # kept queries see the same keys with the same mask; (dense) padded keys carry exp(-10000) = 0
+  _close('ctx', ctx_p[:n], ctx_d[idx], 2e-2, 1e-2)
+  # dQ of kept rows, dK/dV of kept rows: the dense backward also lets the PADDED queries push gradient into the kept keys
+  # (the engine never reads a padded query's output, here dctx of those rows is simply zeroed for the comparison)
+  dctx_z = dctx.clone()
+  dctx_z[:rows][~keep.reshape(-1).to(_dev())] = 0
+  dq_dz = ops.attn_bwd(qkv, bias, ctx_d, lse_d, dctx_z, B, S, H, scale, drop_key=31, drop_p=0.2)
+  _close('dqkv', dq_p[:n], dq_dz[idx], 4e-2, 2e-2)
