@@ -114,8 +114,11 @@ def test_packed_equals_dense_in_train_mode_with_dropout(name):
     sims = _run(model, _to_dev(fx.batch), t)['cross_view_conf_matrix']
     sims.sum().backward()
     outs.append((sims.detach().cpu(), model.vid_bert.encoder.layer[0].intermediate.dense.weight.grad.cpu().clone()))
-  assert (outs[0][0] - outs[1][0]).abs().max() < 2e-4
-  assert _cos(outs[0][1].numpy(), outs[1][1].numpy()) > 0.9999
+  # one layer: fp32 summation order only; four layers: the bf16 roundings of the stored activations diverge a little
+  # further (a DIFFERENT mask anywhere moves the similarities by > 1e-2)
+  tol, cos_min = (2e-4, 0.9999) if name == 'configA' else (1e-3, 0.999)
+  assert (outs[0][0] - outs[1][0]).abs().max() < tol
+  assert _cos(outs[0][1].numpy(), outs[1][1].numpy()) > cos_min
 
 
 def test_bert_standalone_matches_reference():
@@ -373,7 +376,7 @@ def test_every_parameter_gradient_matches_oracle_autograd(name, tol, pack):
   test_cenet_matches_reference.  Relative L2 error per parameter <= tol (bf16 GEMM operands through 2 x L GEMM layers:
   medians 0.4 / 0.5 / 1.0 % for tiny / configA / configB), with two documented exceptions:
     * gradients that are ZERO in exact arithmetic (key.bias: softmax is shift-invariant; cg.fc.bias: BatchNorm removes
-      the mean) must be negligible next to their weight's gradient;
+      the mean) must be negligible next to their weight's gradient (<= 0.5 %: sums of bf16-rounded rows);
     * moe_fc_txt.*.bias sums softmax gradients that cancel across experts: looser bound."""
   from oracle import mmt_oracle as O
   fx = load_cenet_fixture(name)
@@ -398,7 +401,7 @@ def test_every_parameter_gradient_matches_oracle_autograd(name, tol, pack):
     zero_in_exact_arithmetic = k.endswith('attention.self.key.bias') or (k.endswith('.cg.fc.bias') and 'text_GU' in k)
     if zero_in_exact_arithmetic:
       sibling = params[k[:-4] + 'weight'].grad.detach().double().norm().item()
-      assert g.norm().item() <= 1e-3 * sibling and r.norm().item() <= 1e-6 * sibling, (k, g.norm().item(), sibling)
+      assert g.norm().item() <= 5e-3 * sibling and r.norm().item() <= 1e-6 * sibling, (k, g.norm().item(), sibling)
       continue
     rels[k] = float((g - r).norm() / r.norm())
     got.append(g.reshape(-1))

@@ -3,4 +3,4 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/c6
 mkdir -p $O
 cd $R
-TOPN=14 timeout 900 python tools/grad_parity_lab.py tiny configA configB > $O/grad_parity.txt 2>&1
+timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -25 > $O/pytest_gpu.txt
