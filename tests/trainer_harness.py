@@ -1,0 +1,207 @@
+"""TEST INFRASTRUCTURE: what it takes to drive a CENet through the reference's training loop without the reference's
+config system, datasets and logging.
+
+  * `HashTextTower`       a deterministic stand-in for the HuggingFace text tower (its weights are unavailable offline):
+                          token ids -> (B*C, W, 768) through a frozen seeded table; same module on both sides.
+  * `SyntheticLoader`     in-memory minibatches exactly as the reference's collate hands them to the trainer
+                          (data_loader/mix_dataset.py:112-144): tensors + the non-tensor entries that
+                          `move_dict_to_device` drops (trainer/trainer.py:36-52).
+  * `real_trainer`        the reference's OWN `trainer.trainer.Trainer` (needs /root/reference: build container only),
+                          constructed around its `__init__` (which wants the config parser, data loaders, visualiser ...).
+  * `mimic_train_epoch`   a line-by-line restatement of `Trainer._train_epoch` (trainer/trainer.py:120-249) for the GPU box,
+                          where the reference tree does not exist.  tests/test_reference_integration_cpu.py pins it to the
+                          real method: same model, same loader => bit-identical losses and weights.
+"""
+import collections
+import time
+
+import numpy as np
+import torch
+
+from mmt_amd import synthetic
+
+MODS = ['s3d', 'vggish']                     # BASELINE.json configs[0]: 2 experts, 1 BERT layer, batch 8
+VB = dict(hidden=512, layers=1, heads=4, inter=3072, max_pos=32)
+BATCH, TOKENS, ITERS, EPOCHS, SEED = 8, 30, 3, 2, 41
+
+
+class HashTextTower(torch.nn.Module):
+  """(input_ids, attention_mask, ...) -> (sequence [N, W, 768],): mean of frozen table rows over the valid words, in
+  slot 0 (CENet reads out[0][:, 0] for txt_agg='bert...' post-aggregation 'cls', model/model.py:371-379)."""
+
+  def __init__(self, seed=SEED, buckets=1024, dim=768):
+    super().__init__()
+    g = torch.Generator().manual_seed(seed)
+    self.register_buffer('table', torch.randn(buckets, dim, generator=g))
+    self.config = type('C', (), {'hidden_size': dim})()
+    self.embeddings = torch.nn.Module()
+
+  @classmethod
+  def from_pretrained(cls, name, **kw):
+    return cls()
+
+  def forward(self, input_ids, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None):
+    rows = self.table[input_ids.long() % self.table.shape[0]]            # [N, W, dim]
+    m = attention_mask.to(rows.dtype)[..., None]
+    cls = (rows * m).sum(1) / m.sum(1).clamp_min(1.0)
+    return (cls[:, None, :].expand(-1, input_ids.shape[1], -1),)
+
+
+def arch_args(dropout=0.0):
+  vb = synthetic.vid_bert_params(dropout=dropout, **VB)
+  return dict(l2renorm=False, keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn',
+              txt_agg='bertftn', txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both', pos_enc='tint',
+              out_tok='mxp', vid_bert_params=vb, txt_pro='gbn', same_dim=VB['hidden'],
+              txt_bert_params={'hidden_dropout_prob': dropout, 'attention_probs_dropout_prob': dropout})
+
+
+class _Dataset:
+  dataset_name = 'SyntheticMSRVTT'
+  n_pairs = 1
+
+
+class _TrainSet(dict):
+  """data_loaders['train_sets'][i]: attribute AND item access (trainer/trainer.py:136-142)."""
+  until_epoch = 10 ** 9
+  batch_size = BATCH
+  n_pairs = 1
+
+
+class SyntheticLoader:
+  """len() / iteration / .batch_size / .dataset as torch's DataLoader; the same ITERS minibatches every epoch."""
+
+  def __init__(self, iters=ITERS, batch=BATCH, seed=SEED):
+    self.batch_size, self.dataset = batch, _Dataset()
+    self._mbs = []
+    for i in range(iters):
+      mb, _ = synthetic.make_batch(seed + i, batch, MODS, TOKENS, max_pos=VB['max_pos'])
+      mb['raw_captions'] = [['a caption']] * batch        # non-tensor entries: dropped by move_dict_to_device
+      mb['paths'] = ['video%d' % k for k in range(batch)]
+      mb['sources'] = ['SyntheticMSRVTT'] * batch
+      self._mbs.append(mb)
+
+  def __len__(self):
+    return len(self._mbs)
+
+  def __iter__(self):
+    for mb in self._mbs:
+      out = {}
+      for k, v in mb.items():  # fresh containers: the trainer mutates the dict it is given
+        out[k] = collections.OrderedDict((kk, vv.clone()) for kk, vv in v.items()) if isinstance(v, dict) else (
+            v.clone() if torch.is_tensor(v) else list(v))
+      yield out
+
+
+class _Recorder(torch.nn.Module):
+  """Wraps the loss module: the trainer only logs averages, the test wants every step."""
+
+  def __init__(self, inner):
+    super().__init__()
+    self.inner, self.values = inner, []
+
+  def forward(self, x):
+    out = self.inner(x)
+    self.values.append(float(out.detach().cpu()))
+    return out
+
+
+def real_trainer(R, model, loss, optimizer, lr_scheduler, loader, device):
+  """The reference's Trainer object with exactly the state `_train_epoch` touches (trainer/trainer.py:120-249)."""
+  import importlib
+  T = importlib.import_module('trainer.trainer')
+  timing = importlib.import_module('utils.timing_utils')
+  tr = T.Trainer.__new__(T.Trainer)
+  ts = _TrainSet(dataset=loader.dataset, loader=loader)
+  tr.model, tr.loss, tr.optimizer, tr.lr_scheduler, tr.device = model, loss, optimizer, lr_scheduler, device
+  tr.data_loaders = {'train_sets': [ts], 'continuous_eval_sets': []}
+  tr.train_loaders, tr.train_datasets = [loader], [loader.dataset]
+  tr.batch_size, tr.n_pairs = loader.batch_size, 1
+  tr.max_samples_per_epoch = 10 ** 9
+  tr.batches_per_epoch = len(loader)
+  tr.samples_per_epoch = len(loader) * loader.batch_size
+  tr.log_step = int(np.sqrt(loader.batch_size))
+  tr.timer = timing.AverageMeter()
+  tr.debug_dataloader, tr.warmup_scheduler = False, None
+  tr.n_samples = tr.n_steps = 0
+  tr.modalities = list(MODS)
+  return tr
+
+
+def move_dict_to_device(res, device, only_tensors=True):
+  """trainer/trainer.py:36-52."""
+  for key in list(res.keys()):
+    value = res[key]
+    if isinstance(value, np.ndarray):
+      res[key] = torch.from_numpy(res[key])
+      if device is not None:
+        res[key] = res[key].to(device)
+    elif isinstance(value, torch.Tensor):
+      if device is not None:
+        res[key] = value.to(device)
+    elif isinstance(value, (collections.OrderedDict, dict)):
+      res[key] = move_dict_to_device(res[key], device)
+    elif only_tensors:
+      res.pop(key)
+  return res
+
+
+def mimic_train_epoch(state, epoch):
+  """`Trainer._train_epoch(epoch)` (trainer/trainer.py:120-249) on `state` = an object with the attributes
+  `real_trainer` sets: same statements in the same order, minus timers and log messages."""
+  if epoch == 0:                                                          # :121-130: no training at epoch 0
+    return {'loss': 0, 'learning_rate': state.lr_scheduler.get_last_lr()[0], 'n_samples': state.n_samples,
+            'n_steps': state.n_steps}
+  state.model.train()                                                     # :132
+  total_loss = 0
+  out = 'embds' if isinstance(state.model, torch.nn.DataParallel) else 'conf'   # :134
+  i = 0
+  while state.data_loaders['train_sets'][i].until_epoch < epoch:          # :137-139
+    i += 1
+  state.batch_size = state.data_loaders['train_sets'][i].batch_size      # :141-143
+  state.n_pairs = state.data_loaders['train_sets'][i].n_pairs
+  for batch_idx, minibatch in enumerate(state.train_loaders[i]):         # :150
+    if (batch_idx + 1) * state.batch_size * state.n_pairs > state.max_samples_per_epoch:   # :152-154
+      break
+    minibatch = move_dict_to_device(minibatch, state.device)             # :167
+    state.n_samples += state.batch_size * state.n_pairs                  # :169-170
+    state.n_steps += 1
+    if state.warmup_scheduler:                                           # :172-173
+      state.warmup_scheduler.dampen()
+    state.optimizer.zero_grad()                                          # :175
+    output = state.model(**minibatch, out=out, device=state.device, debug=False)   # :178
+    assert out == 'conf'
+    loss = state.loss(output['cross_view_conf_matrix'])                  # :182-183
+    loss.backward()                                                      # :203
+    state.optimizer.step()                                               # :204
+    total_loss += loss.item()                                            # :206-207
+  log = {'loss': total_loss / state.batches_per_epoch}                   # :239
+  log['learning_rate'] = state.lr_scheduler.get_last_lr()[0]             # :241-242 (get_lr() in the reference's torch)
+  log['n_samples'], log['n_steps'] = state.n_samples, state.n_steps
+  if state.lr_scheduler is not None:                                     # :246-247
+    state.lr_scheduler.step()
+  return log
+
+
+class MimicState:
+  """Attribute bag for mimic_train_epoch, filled like `real_trainer` fills the reference's Trainer."""
+
+  def __init__(self, model, loss, optimizer, lr_scheduler, loader, device):
+    ts = _TrainSet(dataset=loader.dataset, loader=loader)
+    self.model, self.loss, self.optimizer, self.lr_scheduler, self.device = model, loss, optimizer, lr_scheduler, device
+    self.data_loaders = {'train_sets': [ts]}
+    self.train_loaders = [loader]
+    self.batch_size, self.n_pairs = loader.batch_size, 1
+    self.max_samples_per_epoch = 10 ** 9
+    self.batches_per_epoch = len(loader)
+    self.warmup_scheduler = None
+    self.n_samples = self.n_steps = 0
+
+
+def run_epochs(step_fn, epochs=EPOCHS):
+  """-> list of the per-epoch logs of epochs 1..epochs"""
+  return [step_fn(ep) for ep in range(1, epochs + 1)]
+
+
+PROBE_PARAMS = ['vid_bert.encoder.layer.0.attention.self.query.weight', 'vid_bert.encoder.layer.0.output.dense.bias',
+                'video_dim_reduce.s3d.fc.weight', 'text_GU.vggish.cg.fc.weight', 'moe_fc_txt.s3d.weight',
+                'vid_bert.embeddings.position_embeddings.weight']
