@@ -101,6 +101,7 @@ typedef struct MmtGemmItem {
   const void* A; const void* B; void* C; const float* bias; /* bf16 [M,lda], bf16 [N,ldb], fp32 [M,ldc], fp32 [N] */
   int64_t lda, ldb, ldc;
   int32_t M, N, K, tile_begin;
+  const int32_t* n_rows_dev; /* nullable: live rows of this problem on the device (<= M); tiles past them exit */
 } MmtGemmItem;
 int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue, void* stream);
 
@@ -130,6 +131,7 @@ typedef struct MmtWgradItem {
   float* slab;      /* splits > 1: partial results [splits][N_out, ldo] (summed by the caller, e.g.            */
   float* bias_slab; /*   mmt_col_reduce_multi) and partial bias gradients [splits][N_out]                       */
   int32_t splits, reserved2;
+  const int32_t* n_rows_dev; /* nullable: this item contracts over *n_rows_dev rows (device; overrides the group's) */
 } MmtWgradItem;
 typedef struct MmtWgradGroup {
   MmtWgradItem item[MMT_WGRAD_MAX];
@@ -317,7 +319,7 @@ typedef struct MmtExpertIO {
   const float* maxpool;  /* [B, D] fp32     features_maxpool[mod]                                */
   const float* ind;      /* [B, T] fp32     features_ind[mod]                                    */
   const float* t;        /* [B, T] fp32     features_t[mod]                                      */
-  void* x;               /* bf16 [rows_pad, Dpad] GEMM input (rows: B*T feature rows then B maxpool rows) */
+  void* x;               /* bf16 [rows_pad, Dpad] GEMM input, COMPACT rows (see MmtVideoSrc)              */
   float* y;              /* fp32 [rows_pad, d] ReduceDim.fc output (pre-normalisation)           */
   void* dy;              /* bf16 [rows_pad, d] gradient wrt y (backward)                         */
   int32_t D, Dpad, type_idx, rows_pad;
@@ -325,14 +327,23 @@ typedef struct MmtExpertIO {
 /* Token plan: slot[b*S+s] -> row (or -1), cu_seqlens[B+1], *n_rows_dev, and per-row row_index (b*S+s),
  * type_ids, pos_ids (clamp(features_t,0,max_pos) model.py:516-520), mask_bias, agg_row[b*M+m].
  * pack=0 keeps all S=1+M*(T+1) slots; pack=1 drops padded FEA tokens (exact, see assemble.hip). */
+/* Source-row compaction maps written by mmt_video_plan (device): the ReduceDim projections only see live rows.
+ * Compact source matrix of expert e (x / y / dy of MmtExpertIO): rows [0, B) = the max-pooled vectors, rows B + i = the
+ * valid feature rows in (sample, time) order. */
+typedef struct MmtVideoSrc {
+  int32_t* src_row; /* [token rows] compact source row of every live token inside its expert's matrix (-1: CLS) */
+  int32_t* src_cnt; /* [M] live source rows per expert = B + valid feature rows                                   */
+  int32_t* xsrc;    /* [M, B*T] feature row b*T + t behind compact row B + i                                      */
+} MmtVideoSrc;
 int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos, int32_t* counts,
                    int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot, int32_t* row_index, int32_t* type_ids,
-                   int32_t* pos_ids, float* mask_bias, int32_t* agg_row, uint32_t* seed_bump, void* stream);
-int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, void* stream);
-int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
-                      float* features, void* stream);
-int mmt_video_scatter_bwd(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
-                          const float* dfeatures, void* stream);
+                   int32_t* pos_ids, float* mask_bias, int32_t* agg_row, uint32_t* seed_bump, const MmtVideoSrc* src,
+                   void* stream);
+int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, const MmtVideoSrc* src, void* stream);
+int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* n_rows_dev,
+                      const int32_t* row_index, const MmtVideoSrc* src, float* features, void* stream);
+int mmt_video_scatter_bwd(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* n_rows_dev,
+                          const int32_t* row_index, const MmtVideoSrc* src, const float* dfeatures, void* stream);
 
 /* ---- read-out, similarity, losses (simloss.hip) --------------------------------------------------- */
 /* vid_embds[i] = F.normalize(last_hidden[agg_row[i]]), i < B*M      model.py:583-587,621-625 */

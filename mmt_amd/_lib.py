@@ -31,14 +31,15 @@ class MmtAdamSeg(ctypes.Structure):
 
 class MmtGemmItem(ctypes.Structure):
   _fields_ = [('A', c_vp), ('B', c_vp), ('C', c_vp), ('bias', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldc', c_i64),
-              ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('tile_begin', ctypes.c_int32)]
+              ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('tile_begin', ctypes.c_int32),
+              ('n_rows_dev', c_vp)]
 
 
 class MmtWgradItem(ctypes.Structure):
   _fields_ = [('A', c_vp), ('B', c_vp), ('out', c_vp), ('bias_out', c_vp), ('lda', c_i64), ('ldb', c_i64), ('ldo', c_i64),
               ('N', ctypes.c_int32), ('K2', ctypes.c_int32), ('N_out', ctypes.c_int32), ('K2_out', ctypes.c_int32),
               ('tile_begin', ctypes.c_int32), ('reserved', ctypes.c_int32), ('slab', c_vp), ('bias_slab', c_vp),
-              ('splits', ctypes.c_int32), ('reserved2', ctypes.c_int32)]
+              ('splits', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('n_rows_dev', c_vp)]
 
 
 class MmtWgradGroup(ctypes.Structure):
@@ -48,6 +49,10 @@ class MmtWgradGroup(ctypes.Structure):
 class MmtColReduceJob(ctypes.Structure):
   _fields_ = [('partials', c_vp), ('out', c_vp * 4), ('nblocks', ctypes.c_int32), ('nvec', ctypes.c_int32),
               ('nout', ctypes.c_int32), ('d', ctypes.c_int32)]
+
+
+class MmtVideoSrc(ctypes.Structure):
+  _fields_ = [('src_row', c_vp), ('src_cnt', c_vp), ('xsrc', c_vp)]
 
 
 class MmtExpertIO(ctypes.Structure):
@@ -168,10 +173,12 @@ SIGNATURES = {
     'mmt_adam_step_fused': (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtAdamSeg), c_vp, c_int, c_f32, c_f32, c_f32,
                                     c_f32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
-                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_vp]),
-    'mmt_video_scatter': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
-    'mmt_video_scatter_bwd': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtVideoSrc), c_vp]),
+    'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, ctypes.POINTER(MmtVideoSrc), c_vp]),
+    'mmt_video_scatter': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp,
+                                  ctypes.POINTER(MmtVideoSrc), c_vp, c_vp]),
+    'mmt_video_scatter_bwd': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_vp, c_vp,
+                                      ctypes.POINTER(MmtVideoSrc), c_vp, c_vp]),
     'mmt_readout_fwd': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_readout_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_sims_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

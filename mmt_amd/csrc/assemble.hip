@@ -21,63 +21,49 @@ __device__ __forceinline__ void decode_slot(int s, int T, int& expert, int& j) {
   j = (s - 1) % (T + 1);  // 0 = AGG, 1..T = FEA t = j-1
 }
 
-// grid = B blocks of 256 threads.  Phase 0 (counts) / phase 1 (fill, after cu has been scanned).
-__global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M, int T, int S, int pack, int max_pos,
-                                                   int phase, int32_t* __restrict__ counts, int32_t* __restrict__ cu,
-                                                   int32_t* __restrict__ n_rows, int32_t* __restrict__ slot, int32_t* __restrict__ row_index,
-                                                   int32_t* __restrict__ type_ids, int32_t* __restrict__ pos_ids,
-                                                   float* __restrict__ mask_bias, int32_t* __restrict__ agg_row,
-                                                   uint32_t* __restrict__ seed_bump) {
+// grid = B blocks of 256 threads, ONE launch: block b derives the row offset of its sample (and, per expert, the offset
+// of its valid feature rows inside the expert's COMPACT source matrix) from the validity flags of the samples in front of
+// it (<= B*M*T flags: trivial), then fills the slot map, ids, mask and the source-row maps.
+//
+// Compact source matrix of expert e (X_e / Y_e / dY_e): rows [0, B) = the max-pooled vector of every sample (the AGG
+// token's input, always present: keep_missing_modalities), rows B + i = the VALID feature rows in (sample, time) order.
+// Padded feature rows are never projected: the ReduceDim GEMM, its weight gradient and the cast only see live rows
+// (src_cnt[e] on the device; ~52 % of B*(T+1) at the synthetic MSRVTT fill).  Without token packing every feature row
+// counts as valid (the dense token grid of the reference).
+__global__ __launch_bounds__(256) void video_plan_kernel(ExpertTable tab, int B, int M, int T, int S, int pack, int max_pos,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ cu,
+                                                         int32_t* __restrict__ n_rows, int32_t* __restrict__ slot,
+                                                         int32_t* __restrict__ row_index, int32_t* __restrict__ type_ids,
+                                                         int32_t* __restrict__ pos_ids, float* __restrict__ mask_bias,
+                                                         int32_t* __restrict__ agg_row, uint32_t* __restrict__ seed_bump,
+                                                         MmtVideoSrc src) {
   __shared__ int scan[256];
   __shared__ int carry;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const bool one_launch = phase == 2;
-  int base = 0;
-  if (phase == 2 && b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
-  if (phase == 2) {  // ONE launch: the block counts the live tokens of the samples in front of it itself
-    int part = 0;
-    if (pack) {  // FEA slots of the samples 0..b-1 (CLS + M AGG tokens are always live): ind is [B, T] per expert
-      const int bT = b * T;
+  __shared__ int offs[MMT_MAX_EXPERTS], own[MMT_MAX_EXPERTS];  // valid feature rows of expert e: before sample b / in it
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
+  for (int ex = wave; ex < M; ex += 4) {  // one wave per expert
+    const float* __restrict__ ind_e = tab.e[ex].ind;
+    int before = 0, mine = 0;
+    if (pack) {
+      for (int i = lane; i < b * T; i += 64) before += ind_e[i] != 0.f;
+      for (int t = lane; t < T; t += 64) mine += ind_e[(int64_t)b * T + t] != 0.f;
 #pragma unroll
-      for (int ex = 0; ex < MMT_MAX_EXPERTS; ++ex) {  // uniform, unrolled: every expert's flag loads are in flight together
-        if (ex < M) {
-          const float* __restrict__ ind_e = tab.e[ex].ind;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u;
-            if (i < bT) part += ind_e[i] != 0.f;
-          }
-          for (int i = tid + 1024; i < bT; i += 256) part += ind_e[i] != 0.f;
-        }
-      }
+      for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); mine += __shfl_xor(mine, o, 64); }
+    } else {
+      before = b * T;
+      mine = T;
     }
-    scan[tid] = part;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) scan[tid] += scan[tid + o];
-      __syncthreads();
-    }
-    base = pack ? b * (1 + M) + scan[0] : b * S;
-    __syncthreads();
-    phase = 1;  // fill below; cu / n_rows are written once this sample's own count is known
-  } else if (phase == 1) {  // exclusive prefix of the per-sample counts (phase 0), computed by the block itself: no scan launch
-    int part = 0;
-    for (int i = tid; i < b; i += 256) part += counts[i];
-    scan[tid] = part;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) scan[tid] += scan[tid + o];
-      __syncthreads();
-    }
-    base = scan[0];
-    __syncthreads();
-    if (tid == 0) {
-      cu[b] = base;
-      if (b == B - 1) { cu[B] = base + counts[b]; *n_rows = base + counts[b]; }
-    }
+    if (lane == 0) { offs[ex] = before; own[ex] = mine; }
   }
   if (tid == 0) carry = 0;
   __syncthreads();
+  int base = b * S;
+  if (pack) {
+    base = b * (1 + M);
+    for (int ex = 0; ex < M; ++ex) base += offs[ex];
+  }
+  if (b == B - 1 && tid < M && src.src_cnt) src.src_cnt[tid] = B + offs[tid] + own[tid];
   for (int s0 = 0; s0 < S; s0 += 256) {
     const int s = s0 + tid;
     int live = 0, expert = 0, j = 0;
@@ -99,38 +85,47 @@ __global__ __launch_bounds__(256) void plan_kernel(ExpertTable tab, int B, int M
       __syncthreads();
     }
     const int before = carry + scan[tid] - live;
-    if (phase == 1 && s < S) {
+    if (s < S) {
       const int row = live ? base + before : -1;
       slot[(int64_t)b * S + s] = row;
       if (live) {
         row_index[row] = b * S + s;
-        int type = 0, pos = 0;
+        int type = 0, pos = 0, srow = -1;
         float mask = 1.f;
         if (s > 0) {
           type = tab.e[expert].type_idx;
+          const float* __restrict__ ind_e = tab.e[expert].ind + (int64_t)b * T;
           if (j == 0) {
             float mx = 0.f;  // th.max(features_ind, 1)  model.py:330
-            for (int t = 0; t < T; ++t) mx = fmaxf(mx, tab.e[expert].ind[(int64_t)b * T + t]);
+            for (int t = 0; t < T; ++t) mx = fmaxf(mx, ind_e[t]);
             mask = mx;
             agg_row[b * M + expert] = row;
+            srow = b;  // the max-pooled rows lead the compact source matrix
           } else {
             mask = ind;
             float tv = tab.e[expert].t[(int64_t)b * T + (j - 1)];
             tv = fminf(fmaxf(tv, 0.f), (float)max_pos);  // clamp_ then .long()  model.py:516-520
             pos = (int)tv;
+            int rank = j - 1;
+            if (pack) {
+              rank = 0;
+              for (int t = 0; t < j - 1; ++t) rank += ind_e[t] != 0.f;
+            }
+            srow = B + offs[expert] + rank;
+            if (src.xsrc) src.xsrc[(int64_t)expert * B * T + offs[expert] + rank] = b * T + (j - 1);
           }
         }
         type_ids[row] = type;
         pos_ids[row] = pos;
         mask_bias[row] = (1.0f - mask) * -10000.0f;  // bert.py:395
+        if (src.src_row) src.src_row[row] = srow;
       }
     }
     __syncthreads();
     if (tid == 255) carry += scan[255];
     __syncthreads();
   }
-  if (phase == 0 && tid == 0) counts[b] = carry;
-  if (one_launch && tid == 0) {
+  if (tid == 0) {
     counts[b] = carry;
     cu[b] = base;
     if (b == B - 1) { cu[B] = base + carry; *n_rows = base + carry; }
@@ -147,62 +142,57 @@ __global__ void scan_counts_kernel(const int32_t* __restrict__ counts, int B, in
   }
 }
 
-// X_e[r][c]: r < B*T -> features[b = r/T][t = r%T][c];  B*T <= r < B*(T+1) -> maxpool[r - B*T][c]; zero padding.
-__global__ __launch_bounds__(256) void cast_kernel(ExpertTable tab, int B, int T) {
+// X_e (compact, see video_plan_kernel): row b < B = maxpool[b]; row B + i = features row xsrc[e][i]; bf16, K zero-padded.
+// Only the src_cnt[e] live rows are written: the rows behind them are never read as results (the GEMM's tiles past the
+// live count exit, the weight gradient zeroes the ragged tail of its last 64-row unit).
+__global__ __launch_bounds__(256) void cast_kernel(ExpertTable tab, int B, int T, MmtVideoSrc src) {
   const MmtExpertIO e = tab.e[blockIdx.y];
-  const int rows = B * (T + 1);
-  const int64_t n = (int64_t)e.rows_pad * (e.Dpad / 4);
+  const int rows = src.src_cnt[blockIdx.y];
+  const int32_t* __restrict__ xs = src.xsrc + (int64_t)blockIdx.y * B * T;
+  const int64_t n = (int64_t)rows * (e.Dpad / 4);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / (e.Dpad / 4)), c = (int)(i % (e.Dpad / 4)) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows) {
-      const float* src = r < B * T ? e.feat + (int64_t)r * e.D : e.maxpool + (int64_t)(r - B * T) * e.D;
+    const float* srcp = r < B ? e.maxpool + (int64_t)r * e.D : e.feat + (int64_t)xs[r - B] * e.D;
+    if (c + 3 < e.D && !(e.D & 3)) {
+      const f32x4 q = *(const f32x4*)(srcp + c);
+      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (c + k < e.D) v[k] = src[c + k];
+        if (c + k < e.D) v[k] = srcp[c + k];
     }
     u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     *(u32x2*)((bf16_t*)e.x + (int64_t)r * e.Dpad + c) = o;
   }
 }
 
-// one wave per source row (expert e, r): normalise Y_e[r] into features[slot]
+// One wave per LIVE token row: CLS -> zero feature (model.py:502-503); otherwise normalise the ReduceDim output row
+// Y_e[src_row] (F.normalize, eps 1e-12, model.py:724) into the token's feature row.  BWD: gradient of the token row ->
+// gradient of Y_e[src_row] (bf16).  Every live source row belongs to exactly one live token, so dY needs no zero fill.
 template <bool BWD>
-__global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int B, int M, int T, int S, int d,
-                                                      const int32_t* __restrict__ slot, float* __restrict__ feat,
-                                                      const float* __restrict__ dfeat) {
+__global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int M, int T, int S, int d, int rows,
+                                                      const int32_t* __restrict__ n_rows_dev,
+                                                      const int32_t* __restrict__ row_index, MmtVideoSrc src,
+                                                      float* __restrict__ feat, const float* __restrict__ dfeat) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = B * (T + 1);
-  const int total = M * per + B;  // + CLS rows
+  const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int nch = d >> 8;
-  for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-    if (w >= M * per) {  // CLS token: zero feature (model.py:502-503); no gradient to propagate
-      if constexpr (!BWD) {
-        const int b = w - M * per;
-        const int dst = slot[(int64_t)b * S];
-        for (int c = lane * 4; c < d; c += 256) *(f32x4*)(feat + (int64_t)dst * d + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int s = row_index[row] % S;
+    if (s == 0) {
+      if constexpr (!BWD)
+        for (int c = lane * 4; c < d; c += 256) *(f32x4*)(feat + (int64_t)row * d + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
       continue;
     }
-    const int ex = w / per, r = w % per;
-    const MmtExpertIO e = tab.e[ex];
-    const int b = r < B * T ? r / T : r - B * T;
-    const int s = 1 + ex * (T + 1) + (r < B * T ? 1 + r % T : 0);
-    const int dst = slot[(int64_t)b * S + s];
-    if constexpr (!BWD) {
-      if (dst < 0) continue;
-    } else {
-      if (dst < 0) {
-        for (int c = lane * 4; c < d; c += 256) *(u32x2*)((bf16_t*)e.dy + (int64_t)r * d + c) = (u32x2){0u, 0u};
-        continue;
-      }
-    }
+    const MmtExpertIO e = tab.e[(s - 1) / (T + 1)];
+    const int64_t r = src.src_row[row];
     f32x4 y[4];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < nch) {
-        y[c] = *(const f32x4*)(e.y + (int64_t)r * d + c * 256 + lane * 4);
+        y[c] = *(const f32x4*)(e.y + r * d + c * 256 + lane * 4);
         ss += y[c][0] * y[c][0] + y[c][1] * y[c][1] + y[c][2] * y[c][2] + y[c][3] * y[c][3];
       }
     const float nrm = sqrtf(wave_sum(ss));
@@ -210,14 +200,14 @@ __global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int B, in
     if constexpr (!BWD) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < nch) *(f32x4*)(feat + (int64_t)dst * d + c * 256 + lane * 4) = y[c] * inv;
+        if (c < nch) *(f32x4*)(feat + (int64_t)row * d + c * 256 + lane * 4) = y[c] * inv;
     } else {
       f32x4 g[4];
       float dot = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (c < nch) {
-          g[c] = *(const f32x4*)(dfeat + (int64_t)dst * d + c * 256 + lane * 4);
+          g[c] = *(const f32x4*)(dfeat + (int64_t)row * d + c * 256 + lane * 4);
           dot += g[c][0] * y[c][0] + g[c][1] * y[c][1] + g[c][2] * y[c][2] + g[c][3] * y[c][3];
         }
       // d/dy [y / max(|y|, eps)] : (g - yhat (yhat.g)) / |y| above eps, g / eps below
@@ -227,7 +217,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int B, in
         if (c < nch) {
           f32x4 dyv = (g[c] - y[c] * proj) * inv;
           u32x2 o = {pack_bf2(dyv[0], dyv[1]), pack_bf2(dyv[2], dyv[3])};
-          *(u32x2*)((bf16_t*)e.dy + (int64_t)r * d + c * 256 + lane * 4) = o;
+          *(u32x2*)((bf16_t*)e.dy + r * d + c * 256 + lane * 4) = o;
         }
     }
   }
@@ -309,52 +299,60 @@ extern "C" int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type
   return (int)hipGetLastError();
 }
 
+static int check_src(const MmtVideoSrc* src) {
+  return (src && src->src_row && src->src_cnt && src->xsrc) ? 0 : MMT_ERR_ARG;
+}
+
 extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos,
                               int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot,
                               int32_t* row_index, int32_t* type_ids, int32_t* pos_ids, float* mask_bias,
-                              int32_t* agg_row, uint32_t* seed_bump, void* stream) {
+                              int32_t* agg_row, uint32_t* seed_bump, const MmtVideoSrc* src, void* stream) {
   ExpertTable tab;
   if (int e = make_table(experts, M, tab)) return e;
   if (!counts || !cu_seqlens || !n_rows_dev || !slot || !row_index || !type_ids || !pos_ids || !mask_bias || !agg_row)
     return MMT_ERR_ARG;
+  if (int e = check_src(src)) return e;
   const int S = 1 + M * (T + 1);
-  // one launch: every block counts the live tokens of the samples in front of it itself (<= B*M*T flags, trivial)
-  hipLaunchKernelGGL(plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, 2, counts,
-                     cu_seqlens, n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row, seed_bump);
+  hipLaunchKernelGGL(video_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, counts,
+                     cu_seqlens, n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row, seed_bump, *src);
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, void* stream) {
+extern "C" int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, const MmtVideoSrc* src, void* stream) {
   ExpertTable tab;
   if (int e = make_table(experts, M, tab)) return e;
+  if (int e = check_src(src)) return e;
   for (int i = 0; i < M; ++i)
     if (!experts[i].feat || !experts[i].maxpool || !experts[i].x || (experts[i].Dpad & 3) ||
         experts[i].rows_pad < B * (T + 1))
       return MMT_ERR_ARG;
-  hipLaunchKernelGGL(cast_kernel, dim3(256, M), dim3(256), 0, (hipStream_t)stream, tab, B, T);
+  hipLaunchKernelGGL(cast_kernel, dim3(256, M), dim3(256), 0, (hipStream_t)stream, tab, B, T, *src);
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
-                                 float* features, void* stream) {
+extern "C" int mmt_video_scatter(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* n_rows_dev,
+                                 const int32_t* row_index, const MmtVideoSrc* src, float* features, void* stream) {
   ExpertTable tab;
   if (int e = make_table(experts, M, tab)) return e;
-  if (!slot || !features || d % 256 || d > 1024) return MMT_ERR_ARG;
-  const int total = M * B * (T + 1) + B;
-  hipLaunchKernelGGL(scatter_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab, B, M, T,
-                     1 + M * (T + 1), d, slot, features, nullptr);
+  if (int e = check_src(src)) return e;
+  if (!row_index || !features || d % 256 || d > 1024) return MMT_ERR_ARG;
+  const int S = 1 + M * (T + 1), rows = B * S;
+  hipLaunchKernelGGL(scatter_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab, M, T, S, d, rows,
+                     n_rows_dev, row_index, *src, features, nullptr);
   return (int)hipGetLastError();
 }
 
-extern "C" int mmt_video_scatter_bwd(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* slot,
-                                     const float* dfeatures, void* stream) {
+extern "C" int mmt_video_scatter_bwd(const MmtExpertIO* experts, int M, int B, int T, int d, const int32_t* n_rows_dev,
+                                     const int32_t* row_index, const MmtVideoSrc* src, const float* dfeatures,
+                                     void* stream) {
   ExpertTable tab;
   if (int e = make_table(experts, M, tab)) return e;
-  if (!slot || !dfeatures || d % 256 || d > 1024) return MMT_ERR_ARG;
+  if (int e = check_src(src)) return e;
+  if (!row_index || !dfeatures || d % 256 || d > 1024) return MMT_ERR_ARG;
   for (int i = 0; i < M; ++i)
     if (!experts[i].dy) return MMT_ERR_ARG;
-  const int total = M * B * (T + 1) + B;
-  hipLaunchKernelGGL(scatter_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab, B, M, T,
-                     1 + M * (T + 1), d, slot, nullptr, dfeatures);
+  const int S = 1 + M * (T + 1), rows = B * S;
+  hipLaunchKernelGGL(scatter_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab, M, T, S, d, rows,
+                     n_rows_dev, row_index, *src, nullptr, dfeatures);
   return (int)hipGetLastError();
 }

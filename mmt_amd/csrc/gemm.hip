@@ -325,7 +325,9 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   // item.reserved > 0: this item contracts over exactly that many rows (compact last-layer buffers)
-  const int nrows = it.reserved > 0 ? it.reserved : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
+  const int nrows = it.reserved > 0 ? it.reserved
+                    : it.n_rows_dev ? min(*it.n_rows_dev, g.rows)
+                                    : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
   const int units_all = (nrows + 63) / 64;  // 64-row units of the contraction
   // item.splits > 1: the units are divided among `splits` blocks per tile, each writing its own partial slab
   const int per_split = (units_all + nsplit - 1) / nsplit;

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_grouped_kernel(GemmGroup
   e.bias = it.bias;
   const int nblk = ((it.M + BM - 1) / BM) * (it.N / BN);
   gemm2_body<BM, BN, WGM, WGN, NS, EPI>((const bf16_t*)it.A, it.lda, (const bf16_t*)it.B, it.ldb, it.C, it.ldc, it.M, it.N,
-                                        it.K, e, nullptr, (int)blockIdx.x - it.tile_begin, nblk);
+                                        it.K, e, it.n_rows_dev, (int)blockIdx.x - it.tile_begin, nblk);
 }
 
 extern "C" int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue, void* stream) {

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, ops
-from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, check
+from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, MmtVideoSrc, check
 from .bert import BertModel, EngineBatch
 from .flat import FlatParams
 
@@ -255,6 +255,12 @@ class _VideoPlan:
     self.pos_ids = torch.zeros(self.rows_alloc, **i32)
     self.mask_bias = torch.zeros(self.rows_alloc, device=device, dtype=torch.float32)
     self.agg_row = torch.zeros(bsz * m, **i32)
+    # source-row compaction (MmtVideoSrc): the ReduceDim projections only see live rows
+    self.src_row = torch.zeros(self.rows_alloc, **i32)
+    self.src_cnt = torch.zeros(m, **i32)
+    self.xsrc = torch.zeros(m, bsz * t, **i32)
+    self.src = MmtVideoSrc()
+    self.src.src_row, self.src.src_cnt, self.src.xsrc = (x.data_ptr() for x in (self.src_row, self.src_cnt, self.xsrc))
     self.compact_rows = None
     self.features = None
     self.src_rows = bsz * (t + 1)
@@ -470,20 +476,21 @@ class CENet(nn.Module):
     check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
                            ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
                            ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
-                           ops._p(bump), stream), 'mmt_video_plan')
-    check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, stream), 'mmt_video_cast')
+                           ops._p(bump), ctypes.byref(plan.src), stream), 'mmt_video_plan')
+    check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
     ops.gemm_nt_grouped([(plan.x[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
-                          self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows)
+                          self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows,
+                        n_rows_dev=plan.src_cnt)
     feats = torch.empty(plan.rows_alloc, d, device=plan.slot.device, dtype=torch.float32)
-    check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(feats), stream),
-          'mmt_video_scatter')
+    check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.n_rows), ops._p(plan.row_index),
+                              ctypes.byref(plan.src), ops._p(feats), stream), 'mmt_video_scatter')
     return feats
 
   def _video_tokens_backward(self, plan, dfeat):
     L, m, d = _lib.lib(), len(self.modalities), self.same_dim
     stream = ops._stream()
-    check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.slot), ops._p(dfeat), stream),
-          'mmt_video_scatter_bwd')
+    check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.n_rows), ops._p(plan.row_index),
+                                  ctypes.byref(plan.src), ops._p(dfeat), stream), 'mmt_video_scatter_bwd')
     grad_buf = self._flat.current_grad()
     grads, items = [], []
     for mod in self.modalities:  # every ReduceDim weight + bias gradient in ONE grouped launch
@@ -491,7 +498,7 @@ class CENet(nn.Module):
       gw, gb = self._flat.view(fc.weight, grad_buf), self._flat.view(fc.bias, grad_buf)
       items.append((plan.dy[mod], plan.x[mod], gw, gb))
       grads += [gw if fc.weight.requires_grad else None, gb if fc.bias.requires_grad else None]
-    ops.wgrad_grouped(items, plan.src_rows)
+    ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
     return grads
 
   def video_embeddings(self, features, features_t, features_ind, features_maxpool):

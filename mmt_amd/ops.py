@@ -121,13 +121,15 @@ def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_i
   return out
 
 
-def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32'):
-  """items: list of (a [M,K] bf16, b [N,K] bf16, out [M,N] fp32, bias [N] fp32 or None): all in ONE launch."""
+def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32', n_rows_dev=None):
+  """items: list of (a [M,K] bf16, b [N,K] bf16, out [M,N] fp32, bias [N] fp32 or None): all in ONE launch.
+  n_rows_dev: int32 device tensor [len(items)] of live rows per problem (tiles past them exit), or None."""
   from ._lib import MmtGemmItem
   arr = (MmtGemmItem * len(items))()
   for i, (a, b, out, bias) in enumerate(items):
     _need_cuda(a, b, out)
     it = arr[i]
+    it.n_rows_dev = (n_rows_dev.data_ptr() + 4 * i) if n_rows_dev is not None else None
     it.A, it.B, it.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
     it.bias = bias.data_ptr() if bias is not None else None
     it.lda, it.ldb, it.ldc = a.stride(0), b.stride(0), out.stride(0)
@@ -135,9 +137,10 @@ def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32'):
   check(_lib.lib().mmt_gemm_nt_grouped(arr, len(items), EPI[epilogue], _stream()), 'mmt_gemm_nt_grouped')
 
 
-def wgrad_grouped(items, rows, n_rows_dev=None):
+def wgrad_grouped(items, rows, n_rows_dev=None, item_rows_dev=None):
   """items: list of (a [rows,N] bf16, b [rows,K2] bf16, out fp32 [N_out,K2_out], bias_out fp32 [N_out] or None).
-  One launch: out = a^T @ b (fp32), bias_out = column sums of a."""
+  One launch: out = a^T @ b (fp32), bias_out = column sums of a.  n_rows_dev: one live row count for all items;
+  item_rows_dev: int32 device tensor [len(items)], one per item."""
   from ._lib import MmtWgradGroup
   g = MmtWgradGroup()
   g.count, g.rows = len(items), rows
@@ -145,6 +148,7 @@ def wgrad_grouped(items, rows, n_rows_dev=None):
   for i, (a, b, out, bias) in enumerate(items):
     _need_cuda(a, b, out)
     it = g.item[i]
+    it.n_rows_dev = (item_rows_dev.data_ptr() + 4 * i) if item_rows_dev is not None else None
     it.A, it.B, it.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
     it.bias_out = bias.data_ptr() if bias is not None else None
     it.lda, it.ldb, it.ldo = a.stride(0), b.stride(0), out.stride(0)
