@@ -26,6 +26,7 @@ from mmt_amd import dist as mdist  # noqa: E402
 from mmt_amd import ops, synthetic  # noqa: E402
 from mmt_amd.loss import MaxMarginRankingLoss  # noqa: E402
 from mmt_amd.model import CENet, cross_view_similarity  # noqa: E402
+from mmt_amd.feature_store import RaggedFeatures  # noqa: E402
 from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
@@ -188,6 +189,9 @@ def main():
   ap.add_argument('--host-inputs', action='store_true',
                   help='minibatches live in pinned host memory: every step uploads one over PCIe (the PCIe-inclusive rate; '
                        'the headline value keeps the inputs resident in HBM)')
+  ap.add_argument('--ragged-inputs', action='store_true',
+                  help='video features in the ragged bf16 wire format (mmt_amd.feature_store.RaggedFeatures: live rows only, '
+                       'no cast kernel) instead of the reference\'s dict of dense fp32 tensors')
   ap.add_argument('--force-collectives', action='store_true',
                   help='N=1 only: run the all-gather / all-reduce plumbing on a 1-rank RCCL group (measures its overhead)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
@@ -197,6 +201,10 @@ def main():
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
+  if args.ragged_inputs:
+    if args.dense:
+      ap.error('--ragged-inputs carries live rows only: it cannot feed the dense (unpacked) step')
+    args.no_dense = True
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -231,10 +239,19 @@ def main():
   # NBATCH different synthetic minibatches resident in HBM; each step copies one (device-to-device) into
   # the static input buffers of the captured graphs.
   NBATCH = 16
-  batches = []
+  batches, input_bytes = [], []
   for i in range(NBATCH):
     mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
     mb['text'] = text.view(-1, 768)
+    if args.ragged_inputs:
+      rag = RaggedFeatures.from_dense(mb['features'], mb['features_t'], mb['features_ind'], mb['features_maxpool'],
+                                      experts=synthetic.MSRVTT_MODALITIES, pin_memory=args.host_inputs)
+      input_bytes.append(rag.live_bytes())
+      mb = {k: v for k, v in mb.items() if not k.startswith('features')}
+      mb['features'] = rag
+    else:
+      input_bytes.append(sum(v.numel() * 4 for k in ('features', 'features_t', 'features_ind', 'features_maxpool')
+                             for v in mb[k].values()))
     # one contiguous buffer per minibatch (HBM, or pinned host memory with --host-inputs): load = ONE copy
     batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
 
@@ -251,8 +268,20 @@ def main():
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype)
     it, first = 0, None
+    if args.host_inputs:
+      # double-buffered upload: minibatch i+1 crosses PCIe on a copy stream while step i computes
+      def feed():
+        nonlocal it
+        runner.load_prefetched()
+        it += 1
+        runner.prefetch(batches[it % NBATCH])
+      runner.prefetch(batches[0])
+    else:
+      def feed():
+        nonlocal it
+        runner.load(batches[it % NBATCH]); it += 1
     for _ in range(warmup):
-      runner.load(batches[it % NBATCH]); it += 1
+      feed()
       l = runner.step()
       if first is None:
         first = float(l.item())  # loss of the FIRST optimisation step (the runner's warm-up does not train)
@@ -261,7 +290,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-      runner.load(batches[it % NBATCH]); it += 1
+      feed()
       loss = runner.step()
     torch.cuda.synchronize()
     if world > 1:
@@ -322,7 +351,9 @@ def main():
                                 'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
                    'global_batch': world * BATCH, 'seq_len': seq,
                    'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager,
-                   'inputs': 'pinned host, uploaded every step' if args.host_inputs else 'resident in HBM',
+                   'inputs': 'pinned host, uploaded every step (double-buffered on a copy stream)' if args.host_inputs else 'resident in HBM',
+                   'input_format': 'ragged bf16 wire buffer (live rows)' if args.ragged_inputs else 'dense fp32 dict',
+                   'video_input_bytes_per_step': int(sum(input_bytes) / len(input_bytes)),
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
                    'grad_wire_dtype': args.grad_dtype,
                    'live_rows_rank0': live, 'dense_rows': dense_rows},

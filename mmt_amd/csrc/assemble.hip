@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void video_plan_kernel(ExpertTable tab, int B,
   __shared__ int scan[256];
   __shared__ int carry;
   __shared__ int offs[MMT_MAX_EXPERTS], own[MMT_MAX_EXPERTS];  // valid feature rows of expert e: before sample b / in it
+  extern __shared__ float ind_s[];  // [M][T] validity flags of THIS sample (the per-slot loops below read them from LDS)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
+  for (int i = tid; i < M * T; i += 256) ind_s[i] = tab.e[i / T].ind[(int64_t)b * T + i % T];
   for (int ex = wave; ex < M; ex += 4) {  // one wave per expert
     const float* __restrict__ ind_e = tab.e[ex].ind;
     int before = 0, mine = 0;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void video_plan_kernel(ExpertTable tab, int B,
       else {
         decode_slot(s, T, expert, j);
         if (j == 0) live = 1;
-        else { ind = tab.e[expert].ind[(int64_t)b * T + (j - 1)]; live = pack ? (ind != 0.f) : 1; }
+        else { ind = ind_s[expert * T + (j - 1)]; live = pack ? (ind != 0.f) : 1; }
       }
     }
     scan[tid] = live;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void video_plan_kernel(ExpertTable tab, int B,
         float mask = 1.f;
         if (s > 0) {
           type = tab.e[expert].type_idx;
-          const float* __restrict__ ind_e = tab.e[expert].ind + (int64_t)b * T;
+          const float* ind_e = ind_s + expert * T;
           if (j == 0) {
             float mx = 0.f;  // th.max(features_ind, 1)  model.py:330
             for (int t = 0; t < T; ++t) mx = fmaxf(mx, ind_e[t]);
@@ -312,8 +314,11 @@ extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, i
   if (!counts || !cu_seqlens || !n_rows_dev || !slot || !row_index || !type_ids || !pos_ids || !mask_bias || !agg_row)
     return MMT_ERR_ARG;
   if (int e = check_src(src)) return e;
+  if (B <= 0 || T <= 0 || max_pos < 0) return MMT_ERR_ARG;
+  for (int i = 0; i < M; ++i)
+    if (!experts[i].ind || !experts[i].t || experts[i].type_idx < 0) return MMT_ERR_ARG;
   const int S = 1 + M * (T + 1);
-  hipLaunchKernelGGL(video_plan_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, counts,
+  hipLaunchKernelGGL(video_plan_kernel, dim3(B), dim3(256), (size_t)M * T * sizeof(float), (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, counts,
                      cu_seqlens, n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row, seed_bump, *src);
   return (int)hipGetLastError();
 }

@@ -31,6 +31,7 @@ from torch import nn
 from . import _lib, ops
 from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, MmtVideoSrc, check
 from .bert import BertModel, EngineBatch
+from .feature_store import RaggedFeatures
 from .flat import FlatParams
 
 
@@ -267,6 +268,8 @@ class _VideoPlan:
     self.src_rows_pad = _round_up(self.src_rows, 128)
     d = net.same_dim
     self.x, self.y, self.dy = {}, {}, {}
+    self.xin = {}        # X_e actually read this step: self.x (filled by the cast kernel) or the RaggedFeatures' own
+    self.precast = False
     for mod in mods:
       dpad = _round_up(dims[mod]['dim'], 128)
       self.x[mod] = torch.zeros(self.src_rows_pad, dpad, device=device, dtype=torch.bfloat16)
@@ -471,14 +474,15 @@ class CENet(nn.Module):
     # a training forward draws a fresh dropout seed: the plan kernel bumps the encoder's seed word itself (and the
     # encoder is told not to), one launch less per step
     vb = self.vid_bert
-    bump = vb._seed_dev if (vb.training and torch.is_grad_enabled() and vb._seed_dev is not None) else None
+    bump = vb._seed_dev if (plan.bump_seed and vb._seed_dev is not None) else None
     vb._seed_bumped = bump is not None
     check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
                            ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
                            ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
                            ops._p(bump), ctypes.byref(plan.src), stream), 'mmt_video_plan')
-    check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
-    ops.gemm_nt_grouped([(plan.x[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
+    if not plan.precast:
+      check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
+    ops.gemm_nt_grouped([(plan.xin[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
                           self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows,
                         n_rows_dev=plan.src_cnt)
     feats = torch.empty(plan.rows_alloc, d, device=plan.slot.device, dtype=torch.float32)
@@ -496,7 +500,7 @@ class CENet(nn.Module):
     for mod in self.modalities:  # every ReduceDim weight + bias gradient in ONE grouped launch
       fc = self.video_dim_reduce[mod].fc
       gw, gb = self._flat.view(fc.weight, grad_buf), self._flat.view(fc.bias, grad_buf)
-      items.append((plan.dy[mod], plan.x[mod], gw, gb))
+      items.append((plan.dy[mod], plan.xin[mod], gw, gb))
       grads += [gw if fc.weight.requires_grad else None, gb if fc.bias.requires_grad else None]
     ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
     return grads
@@ -504,14 +508,27 @@ class CENet(nn.Module):
   def video_embeddings(self, features, features_t, features_ind, features_maxpool):
     """(B, M, d) L2-normalised expert embeddings of the video side (model.py:426-437, 485-587, 621-625)."""
     mods = self.modalities
-    f0 = features[mods[0]]
-    if not f0.is_cuda:
-      raise RuntimeError('mmt_amd.CENet runs on the GPU only (no CPU fallback)')
-    dev = f0.device
-    bsz, t = f0.shape[0], f0.shape[1]
-    for mod in mods:
-      if features[mod].shape[1] != t:
-        raise NotImplementedError('all experts must share max_expert_tokens (as in every published config)')
+    ragged = features if isinstance(features, RaggedFeatures) else None
+    if ragged is not None:
+      # wire format of feature_store.py: X_e arrives compact and in bf16, the cast kernel has nothing to do
+      if not self.pack_tokens:
+        raise NotImplementedError('RaggedFeatures carry no padded rows: they need pack_tokens=True')
+      if [n for n, _ in ragged.layout.experts] != mods or any(
+          d != self.expert_dims[n]['dim'] for n, d in ragged.layout.experts):
+        raise ValueError('RaggedFeatures experts %r do not match the model\'s %r' % (ragged.layout.experts, mods))
+      dev, bsz, t = ragged.device, ragged.batch, ragged.tokens
+      if dev.type != 'cuda':
+        raise RuntimeError('mmt_amd.CENet runs on the GPU only (no CPU fallback)')
+      features_ind, features_t = ragged.ind, ragged.t
+    else:
+      f0 = features[mods[0]]
+      if not f0.is_cuda:
+        raise RuntimeError('mmt_amd.CENet runs on the GPU only (no CPU fallback)')
+      dev = f0.device
+      bsz, t = f0.shape[0], f0.shape[1]
+      for mod in mods:
+        if features[mod].shape[1] != t:
+          raise NotImplementedError('all experts must share max_expert_tokens (as in every published config)')
     self._prepare(dev)
     key = (bsz, t, dev)
     plan = self._plans.get(key)
@@ -520,15 +537,29 @@ class CENet(nn.Module):
     plan.generation += 1
     keep = []
     for i, mod in enumerate(mods):
-      tensors = [features[mod], features_maxpool[mod], features_ind[mod], features_t[mod]]
-      tensors = [x.detach().to(device=dev, dtype=torch.float32).contiguous() for x in tensors]
-      keep.append(tensors)
       io = plan.io[i]
-      io.feat, io.maxpool, io.ind, io.t = (x.data_ptr() for x in tensors)
-      io.x, io.y, io.dy = plan.x[mod].data_ptr(), plan.y[mod].data_ptr(), plan.dy[mod].data_ptr()
-      io.D, io.Dpad = self.expert_dims[mod]['dim'], plan.x[mod].shape[1]
+      if ragged is not None:
+        tensors = [x.detach().to(device=dev, dtype=torch.float32).contiguous() for x in (features_ind[mod], features_t[mod])]
+        x = ragged.x[mod]
+        if x.shape != plan.x[mod].shape:
+          raise ValueError('RaggedFeatures layout does not match the model (rows/K padding)')
+        keep.append(tensors + [x])
+        io.feat = io.maxpool = None
+        io.ind, io.t = (v.data_ptr() for v in tensors)
+      else:
+        tensors = [features[mod], features_maxpool[mod], features_ind[mod], features_t[mod]]
+        tensors = [x.detach().to(device=dev, dtype=torch.float32).contiguous() for x in tensors]
+        keep.append(tensors)
+        x = plan.x[mod]
+        io.feat, io.maxpool, io.ind, io.t = (v.data_ptr() for v in tensors)
+      plan.xin[mod] = x
+      io.x, io.y, io.dy = x.data_ptr(), plan.y[mod].data_ptr(), plan.dy[mod].data_ptr()
+      io.D, io.Dpad = self.expert_dims[mod]['dim'], x.shape[1]
       io.type_idx, io.rows_pad = self.expert_dims[mod]['idx'], plan.src_rows_pad
     plan.inputs = keep
+    plan.precast = ragged is not None
+    # (grad mode is off inside autograd.Function.forward: decide here whether this forward draws a fresh dropout seed)
+    plan.bump_seed = self.vid_bert.training and torch.is_grad_enabled()
     feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
     batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
                         plan.rows, bsz, plan.seq, cu_seqlens=plan.cu,
@@ -694,7 +725,10 @@ class CENet(nn.Module):
 
   def forward(self, token_ids, features, features_t, features_ind, features_avgpool, features_maxpool,
               query_masks, out='conf', device=None, debug=None):
-    dev = features[self.modalities[0]].device if device is None else torch.device(device)
+    dev = (features.device if isinstance(features, RaggedFeatures) else features[self.modalities[0]].device) \
+        if device is None else torch.device(device)
+    if dev.type != 'cuda':
+      raise RuntimeError('mmt_amd.CENet runs on the GPU only (no CPU fallback)')
     b, c = token_ids.size(0), token_ids.size(1)
     m = len(self.modalities)
     text = self.text_features(token_ids, dev)                                   # (B*C, text_dim)

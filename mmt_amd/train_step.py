@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist as mdist
+from .feature_store import RaggedFeatures
 from .model import cross_view_similarity
 from .optim import FlatAdam
 
@@ -47,6 +48,7 @@ class FlatMinibatch(dict):
     the same layout is one asynchronous H2D copy."""
     super().__init__()
     leaves = []
+    self.ragged = []  # top-level keys holding RaggedFeatures
 
     def walk(d, out):
       for k, v in d.items():
@@ -55,6 +57,9 @@ class FlatMinibatch(dict):
           walk(v, out[k])
         elif torch.is_tensor(v):
           leaves.append((out, k, v))
+        elif isinstance(v, RaggedFeatures):  # video features in the wire format: their own buffer, same idea
+          out[k] = RaggedFeatures(v.layout, device, pin_memory).copy_from(v, non_blocking=False)
+          self.ragged.append(k)
         else:
           out[k] = v
 
@@ -80,6 +85,8 @@ def _copy_tree(dst, src):
       _copy_tree(dst[k], v)
     elif torch.is_tensor(v):
       dst[k].copy_(v, non_blocking=True)
+    elif isinstance(v, RaggedFeatures):
+      dst[k].copy_from(v)
 
 
 class GraphedTrainStep:
@@ -103,6 +110,7 @@ class GraphedTrainStep:
     self._want_stages = self._multi if overlap_grad_sync is None else bool(overlap_grad_sync)
     self.staged = False
     self.static = minibatch
+    self._staging = None  # device-side landing buffer of prefetch()
     flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
     flat_ids = {id(p) for f in flats for p in f.params}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
@@ -187,8 +195,8 @@ class GraphedTrainStep:
   # ---- pieces ------------------------------------------------------------------------------------
   def _forward(self):
     mb = self.static
-    e = self.model(mb['token_ids'], mb['features'], mb['features_t'], mb['features_ind'], mb['features_avgpool'],
-                   mb['features_maxpool'], mb['query_masks'], out='embds')
+    e = self.model(mb['token_ids'], mb['features'], mb.get('features_t'), mb.get('features_ind'),
+                   mb.get('features_avgpool'), mb.get('features_maxpool'), mb['query_masks'], out='embds')
     self._pack_local(e)
     return e
 
@@ -489,8 +497,43 @@ class GraphedTrainStep:
     if isinstance(minibatch, FlatMinibatch) and isinstance(self.static, FlatMinibatch) \
         and minibatch.flat.numel() == self.static.flat.numel():
       self.static.flat.copy_(minibatch.flat, non_blocking=True)
+      for k in minibatch.ragged:
+        self.static[k].copy_from(minibatch[k])
     else:
       _copy_tree(self.static, minibatch)
+
+  def prefetch(self, minibatch):
+    """Start uploading a HOST (pinned) FlatMinibatch into a device staging buffer on a copy stream: the PCIe transfer
+    of step i+1 runs under the kernels of step i.  `load_prefetched()` then moves it into the static inputs with a
+    device-to-device copy on the compute stream."""
+    if not isinstance(minibatch, FlatMinibatch) or not isinstance(self.static, FlatMinibatch):
+      raise TypeError('prefetch needs FlatMinibatch inputs (one buffer per minibatch)')
+    if self._staging is None:
+      # two landing buffers: the upload of minibatch i+1 never waits for the device-side read of minibatch i
+      self._staging = [dict(buf=FlatMinibatch(self.static, self.static.flat.device), ready=torch.cuda.Event(),
+                            free=torch.cuda.Event()) for _ in range(2)]
+      self._copy_stream = torch.cuda.Stream()
+      for st in self._staging:
+        st['free'].record(torch.cuda.current_stream())
+      self._staged, self._uploads = [], 0
+    st = self._staging[self._uploads % 2]
+    self._uploads += 1
+    self._copy_stream.wait_event(st['free'])  # the load_prefetched() two steps back has read this landing buffer
+    with torch.cuda.stream(self._copy_stream):
+      st['buf'].flat.copy_(minibatch.flat, non_blocking=True)
+      for k in minibatch.ragged:
+        st['buf'][k].copy_from(minibatch[k])
+      st['ready'].record(self._copy_stream)
+    self._staged.append(st)
+
+  def load_prefetched(self):
+    if not self._staged:
+      raise RuntimeError('load_prefetched() without a prefetch()')
+    st = self._staged.pop(0)
+    cur = torch.cuda.current_stream()
+    cur.wait_event(st['ready'])
+    self.load(st['buf'])
+    st['free'].record(cur)
 
   def eager_step(self):
     """One un-captured optimisation step on the runner's own stream (the stream the autograd graph's AccumulateGrad nodes

@@ -1,0 +1,121 @@
+"""Input pipeline: memory-mapped store + ragged wire format against what the REAL reference
+pipeline produced on the same synthetic videos (tests/golden/dataset_items.npz, oracle/gen_dataset_golden.py:
+base/base_dataset.py get_sample_data / __getitem__ + mix_dataset.py collate_data)."""
+import numpy as np
+import pytest
+import torch
+
+from mmt_amd import feature_store as FS
+from tests import dataset_fixture as DF
+from tests.fixtures import load_npz
+
+
+def build_store(path, dtype):
+  with FS.FeatureStoreWriter(str(path), DF.DIMS, dtype=dtype) as w:
+    for vid, h5 in DF.make_videos():
+      feats, times = DF.h5_features(h5)
+      w.add(vid, feats, times)
+  return FS.FeatureStore(str(path))
+
+
+def bf16_round(a):
+  return FS.from_bf16(FS.to_bf16(a)).reshape(np.shape(a))
+
+
+def test_to_bf16_is_torch_round_to_nearest_even():
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn(100_000, generator=g) * torch.logspace(-20, 20, 100_000)
+  x[:6] = torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3895e38])  # ties to even both ways, near-overflow
+  want = x.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+  assert np.array_equal(FS.to_bf16(x.numpy()), want)
+  assert np.array_equal(FS.from_bf16(want), x.to(torch.bfloat16).float().numpy())
+
+
+def test_feature_timings_match_reference():
+  g = load_npz('dataset_items')
+  assert np.array_equal(FS.feature_timings(7, FS.FEAT_WIDTH.get('rgb')), g['timings/rgb7'])
+  assert np.array_equal(FS.feature_timings(4, FS.FEAT_WIDTH.get('face')), g['timings/face4'])
+  assert np.array_equal(FS.feature_timings(6, 1.0, stride=2.0, group=2), g['timings/group'])
+
+
+def test_training_row_choice_matches_reference_function():
+  """choose_or_pad_to_len under np.random.seed(s) (base_dataset.py:96-113) == choose_rows with RandomState(s)."""
+  for row in load_npz('dataset_items')['train_choice']:
+    n, seed = int(row[0]), int(row[1])
+    T = DF.MAX_TOKENS
+    feat, t, ind = row[2:2 + T], row[2 + T:2 + 2 * T], row[2 + 2 * T:]
+    pick = FS.choose_rows(n, T, True, np.random.RandomState(seed))
+    keep = min(n, T)
+    assert np.array_equal(pick, feat[:keep].astype(np.int64))       # the fixture's feature value IS the row index
+    assert np.array_equal(pick * 0.5, t[:keep]) and np.all(t[keep:] == 1) and ind.sum() == keep
+    np.random.seed(seed)
+    assert np.array_equal(FS.choose_rows(n, T, True), pick)           # default generator = the reference's global one
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('tag', ['full', 'clip'])
+def test_collated_minibatch_equals_reference_pipeline(tmp_path, dtype, tag):
+  g = load_npz('dataset_items')
+  store = build_store(tmp_path / 's', dtype)
+  videos = dict(DF.make_videos())
+  coll = FS.RaggedCollator(store, list(DF.DIMS), len(store), DF.MAX_TOKENS, training=False,
+                           temporal_encoding_window=DF.WINDOW)
+  window = None if tag == 'full' else (lambda i: DF.clip_window(videos[store.videos[i]]))
+  rag = coll.collate(list(range(len(store))), window=window)
+  feats, ft, fi, fm = rag.to_dense()
+  for e in DF.DIMS:
+    assert np.array_equal(fi[e].numpy(), g['%s/features_ind/%s' % (tag, e)]), e
+    assert np.array_equal(ft[e].numpy(), g['%s/features_t/%s' % (tag, e)]), e            # fp32, bit for bit
+    assert np.array_equal(feats[e].numpy(), bf16_round(g['%s/features/%s' % (tag, e)])), e
+    assert np.array_equal(fm[e].numpy(), bf16_round(g['%s/features_maxpool/%s' % (tag, e)])), e
+    assert rag.live[e] == len(store) + int(g['%s/features_ind/%s' % (tag, e)].sum())
+  # the same minibatch through the dense door (a reference loader's output handed over as is)
+  dense = {k: {e: g['%s/%s/%s' % (tag, k, e)] for e in DF.DIMS} for k in
+           ('features', 'features_t', 'features_ind', 'features_maxpool')}
+  rag2 = FS.RaggedFeatures.from_dense(dense['features'], dense['features_t'], dense['features_ind'],
+                                      dense['features_maxpool'], experts=list(DF.DIMS))
+  assert rag2.live == rag.live
+  L = rag.layout
+  assert torch.equal(rag2.flat[:L.header_bytes], rag.flat[:L.header_bytes])
+  for e in DF.DIMS:
+    assert torch.equal(rag2.x[e][:rag.live[e]].view(torch.int16), rag.x[e][:rag.live[e]].view(torch.int16)), e
+
+
+def test_store_edge_cases_and_views(tmp_path):
+  store = build_store(tmp_path / 's', 'bf16')
+  assert store.videos == ['video%d' % i for i in range(8)] and len(store) == 8
+  assert store.rows('s3d', 3)[0].shape == (0, 64)          # key absent
+  assert store.rows('rgb', 5)[0].shape == (0, 48)          # NaN first value
+  assert store.rows('rgb', 4)[0].shape == (0, 48)          # empty array
+  assert store.rows('vggish', 'video1')[0].shape == (5, 32) and store.rows('vggish', 1)[1].shape == (5,)
+  assert store.rows('rgb', 2)[1][1] == pytest.approx(0.3)  # stored rgb timings are ignored: 0.2 s per row, mean of [0.2, 0.4]
+  assert np.all(store.rows('face', 2)[1] == -1.0)
+  rows, _ = store.rows('s3d', 0)
+  assert isinstance(rows, np.memmap) or isinstance(rows.base, np.memmap)   # a view, nothing parsed or copied
+  with pytest.raises(ValueError):
+    FS.FeatureStoreWriter(str(tmp_path / 'bad'), {'s3d': 64}).add('v', {'s3d': np.zeros((3, 5), np.float32)})
+  with pytest.raises(KeyError):
+    FS.RaggedCollator(store, ['s3d', 'scene'], 2, 8, False)
+  with pytest.raises(NotImplementedError):
+    FS.RaggedCollator(store, ['s3d'], 2, 8, True, shuffle_feats_t=True)
+
+
+def test_collator_reuses_a_buffer_and_training_is_a_valid_draw(tmp_path):
+  store = build_store(tmp_path / 's', 'bf16')
+  coll = FS.RaggedCollator(store, ['s3d', 'rgb'], 4, DF.MAX_TOKENS, training=True, rng=np.random.RandomState(1))
+  buf = coll.new_buffer()
+  a = coll.collate([0, 4, 0, 4], out=buf)
+  assert a is buf
+  feats, ft, fi, fm = a.to_dense()
+  full, sec = store.rows('s3d', 0)
+  full = FS.from_bf16(full)
+  for s in (0, 2):   # 12 rows -> 8 kept, in increasing time, each an actual row of the video
+    idx = [int(np.nonzero((full == feats['s3d'][s, k].numpy()).all(1))[0][0]) for k in range(8)]
+    assert idx == sorted(idx) and len(set(idx)) == 8
+    assert np.allclose(ft['s3d'][s].numpy(), (sec[idx] / 1.0 + 2).astype(np.float32))
+    assert np.array_equal(fm['s3d'][s].numpy(), full.max(0))     # pooled over ALL rows, not just the kept ones
+  assert not torch.equal(feats['s3d'][0], feats['s3d'][2])        # two independent draws
+  assert fi['rgb'][1].sum() == 0 and fm['rgb'][1].abs().sum() == 0 and torch.all(ft['rgb'][1] == 1)
+  b = coll.collate([1, 1, 1, 1], out=buf)                         # a smaller batch leaves nothing of the old one visible
+  feats2, _, fi2, _ = b.to_dense()
+  assert fi2['s3d'].sum() == 20 and b.live['s3d'] == 4 + 20 and b.live_bytes() < a.layout.nbytes
