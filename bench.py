@@ -149,29 +149,49 @@ def executed_flops_per_step(batch, live_rows, seq_lens_sq_sum, m_experts):
 
 
 def cpu_baseline(steps=6):
-  """The CPU oracle ('port' of the reference path, pinned to it by tests/golden) on this box's host cores:
-  fwd+bwd of config B, train mode semantics without dropout RNG (cheaper than the reference), fp32."""
+  """The CPU oracle ('port' of the reference path, pinned to it by tests/golden) on this box's host cores: one training
+  step of config B as the reference runs it -- dense tokens, fp32, train mode with the dropout masks drawn inside the
+  timed region (bernoulli, as ATen's dropout does: ~20 % of the reference's forward), backward,
+  torch.optim.Adam step.  The reference itself (Python/torch) cannot travel to the GPU box; BASELINE.md section 4 holds
+  its timing from the build container next to this port's timing on the same cores."""
   import copy
 
   from oracle import mmt_oracle as O
   torch.set_num_threads(min(32, os.cpu_count()))  # more threads thrash on these small ops (256-thread run: 0.28 pairs/s)
+  p_drop = 0.1
   model = build_model(False, dropout=0.0)
   sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
   mods = list(synthetic.compute_dims(synthetic.MSRVTT_MODALITIES))
   cfg = dict(modalities=mods, expert_dims=synthetic.compute_dims(synthetic.MSRVTT_MODALITIES),
-             vid_bert_params=synthetic.vid_bert_params(hidden=HIDDEN, layers=LAYERS, heads=HEADS, inter=INTER, dropout=0.0),
+             vid_bert_params=synthetic.vid_bert_params(hidden=HIDDEN, layers=LAYERS, heads=HEADS, inter=INTER, dropout=p_drop),
              same_dim=HIDDEN)
   mb, text = synthetic.make_batch(0, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
+  seq = 1 + len(mods) * (TOKENS + 1)
+  shapes = {'emb': (BATCH, seq, HIDDEN)}
+  for l in range(LAYERS):
+    shapes['l%d.probs' % l] = (BATCH, HEADS, seq, seq)
+    shapes['l%d.attn_out' % l] = shapes['l%d.ffn_out' % l] = (BATCH, seq, HIDDEN)
+  P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+  opt = torch.optim.Adam([v for v in P.values() if torch.is_tensor(v) and v.requires_grad], lr=5e-5)
   times = []
   for it in range(steps + 1):
-    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
     t0 = time.time()
-    sims = O.cenet_forward(P, cfg, copy.deepcopy(mb), text, training=True)['cross_view_conf_matrix']
+    masks = {k: torch.bernoulli(torch.full(shp, 1.0 - p_drop)) for k, shp in shapes.items()}
+    opt.zero_grad()
+    sims = O.cenet_forward(P, cfg, copy.deepcopy(mb), text, training=True, masks=masks)['cross_view_conf_matrix']
     O.max_margin_ranking_loss(sims, 0.05, True).backward()
+    opt.step()
     times.append(time.time() - t0)
   sec = sum(times[1:]) / steps
-  return dict(value=BATCH / sec, unit='pairs/s', cores=torch.get_num_threads(), kind='port',
-              sample='%d fwd+bwd steps of config B (batch 32, dense, fp32, torch CPU ops, 1 warm-up)' % steps)
+  cpu = ''
+  try:
+    with open('/proc/cpuinfo') as f:
+      cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+  except (OSError, StopIteration):
+    pass
+  return dict(value=BATCH / sec, unit='pairs/s', cores=torch.get_num_threads(), kind='port', cpu=cpu,
+              sample='%d training steps of config B (batch 32, dense, fp32, dropout 0.1 masks drawn per step, backward, '
+                     'Adam; torch CPU ops; 1 warm-up step)' % steps)
 
 
 def main():

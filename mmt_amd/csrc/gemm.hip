@@ -526,7 +526,7 @@ static int wide192_tile(int M, int N, bool packed) {
     forced3072 = a ? atoi(a) : 0;
     forced1536 = b ? atoi(b) : 0;
     if (f && atof(f) > 0.0) live_fraction = atof(f);
-    enabled = en ? atoi(en) : 0;
+    enabled = en ? atoi(en) : 0;  // whole-step A/B on one box (r02): 1.473 ms off vs 1.485 ms on -- the per-kernel lab win does not carry
   }
   if (N == 3072 && forced3072) return forced3072;
   if (N == 1536 && forced1536) return forced1536;

@@ -11,7 +11,7 @@ from mmt_amd import _lib, ops  # noqa: E402
 
 dev = torch.device('cuda:0')
 L = ctypes.CDLL(_lib.LIB_PATH)
-for rows in (3596, 6976):
+for rows in (1750, 3596, 6976):
   R = ops.pad_rows(rows)
   d, I = 512, 3072
   bf = torch.bfloat16
