@@ -323,6 +323,10 @@ typedef struct MmtExpertIO {
   float* y;              /* fp32 [rows_pad, d] ReduceDim.fc output (pre-normalisation)           */
   void* dy;              /* bf16 [rows_pad, d] gradient wrt y (backward)                         */
   int32_t D, Dpad, type_idx, rows_pad;
+  /* K-split of a wide expert's projection (rgb 2048, scene 2208 ...): y holds the first K chunk's product + bias,
+   * y_part[i] the other chunks' partial products (same shape as y); the scatter kernels add them up. */
+  const float* y_part[2];
+  int32_t n_part, reserved;
 } MmtExpertIO;
 /* Token plan: slot[b*S+s] -> row (or -1), cu_seqlens[B+1], *n_rows_dev, and per-row row_index (b*S+s),
  * type_ids, pos_ids (clamp(features_t,0,max_pos) model.py:516-520), mask_bias, agg_row[b*M+m].

@@ -58,7 +58,8 @@ class MmtVideoSrc(ctypes.Structure):
 class MmtExpertIO(ctypes.Structure):
   _fields_ = [('feat', c_vp), ('maxpool', c_vp), ('ind', c_vp), ('t', c_vp), ('x', c_vp), ('y', c_vp), ('dy', c_vp),
               ('D', ctypes.c_int32), ('Dpad', ctypes.c_int32), ('type_idx', ctypes.c_int32),
-              ('rows_pad', ctypes.c_int32)]
+              ('rows_pad', ctypes.c_int32), ('y_part', c_vp * 2), ('n_part', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
 
 
 _LAYER_PTRS = ['wqkv', 'wqkv_t', 'wo', 'wo_t', 'w1', 'w1_t', 'w2', 'w2_t',

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int M, in
     for (int c = 0; c < 4; ++c)
       if (c < nch) {
         y[c] = *(const f32x4*)(e.y + r * d + c * 256 + lane * 4);
+        if (e.n_part > 0) y[c] += *(const f32x4*)(e.y_part[0] + r * d + c * 256 + lane * 4);
+        if (e.n_part > 1) y[c] += *(const f32x4*)(e.y_part[1] + r * d + c * 256 + lane * 4);
         ss += y[c][0] * y[c][0] + y[c][1] * y[c][1] + y[c][2] * y[c][2] + y[c][3] * y[c][3];
       }
     const float nrm = sqrtf(wave_sum(ss));
@@ -228,7 +230,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int M, in
 // ------------------------------------------------------------------------------------------------
 static int make_table(const MmtExpertIO* experts, int M, ExpertTable& tab) {
   if (!experts || M <= 0 || M > MMT_MAX_EXPERTS) return MMT_ERR_ARG;
-  for (int i = 0; i < M; ++i) tab.e[i] = experts[i];
+  for (int i = 0; i < M; ++i) {
+    tab.e[i] = experts[i];
+    if (experts[i].n_part < 0 || experts[i].n_part > 2) return MMT_ERR_ARG;
+    for (int k = 0; k < experts[i].n_part; ++k)
+      if (!experts[i].y_part[k]) return MMT_ERR_ARG;
+  }
   return 0;
 }
 

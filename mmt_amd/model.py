@@ -238,6 +238,7 @@ def sharded_cross_view_inner_product(vid_embds, text_embds, vid_weights, text_we
 
 class _VideoPlan:
   """Per-(B,T) device buffers of the token pipeline."""
+  KSPLIT = 768  # input channels per ReduceDim GEMM problem
 
   def __init__(self, net, bsz, t, device):
     mods, dims = net.modalities, net.expert_dims
@@ -267,7 +268,11 @@ class _VideoPlan:
     self.src_rows = bsz * (t + 1)
     self.src_rows_pad = _round_up(self.src_rows, 128)
     d = net.same_dim
-    self.x, self.y, self.dy = {}, {}, {}
+    self.x, self.y, self.dy, self.y_part = {}, {}, {}, {}
+    self.zero_bias = torch.zeros(d, device=device, dtype=torch.float32)
+    chunks = {mod: min(3, -(-_round_up(dims[mod]['dim'], 128) // self.KSPLIT)) for mod in mods}
+    if sum(chunks.values()) > 16:  # MMT_GEMM_GROUP_MAX problems per grouped launch
+      chunks = {mod: 1 for mod in mods}
     self.xin = {}        # X_e actually read this step: self.x (filled by the cast kernel) or the RaggedFeatures' own
     self.precast = False
     for mod in mods:
@@ -275,6 +280,8 @@ class _VideoPlan:
       self.x[mod] = torch.zeros(self.src_rows_pad, dpad, device=device, dtype=torch.bfloat16)
       self.y[mod] = torch.zeros(self.src_rows_pad, d, device=device, dtype=torch.float32)
       self.dy[mod] = torch.zeros(self.src_rows_pad, d, device=device, dtype=torch.bfloat16)
+      self.y_part[mod] = [torch.zeros(self.src_rows_pad, d, device=device, dtype=torch.float32)
+                          for _ in range(chunks[mod] - 1)]
     self.io = (MmtExpertIO * m)()
     self.inputs = None  # keeps the input tensors of the current batch alive
 
@@ -482,9 +489,19 @@ class CENet(nn.Module):
                            ops._p(bump), ctypes.byref(plan.src), stream), 'mmt_video_plan')
     if not plan.precast:
       check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
-    ops.gemm_nt_grouped([(plan.xin[mod], self._flat.shadow(('reduce', mod))[0], plan.y[mod],
-                          self.video_dim_reduce[mod].fc.bias) for mod in self.modalities], m=plan.src_rows,
-                        n_rows_dev=plan.src_cnt)
+    # wide experts are cut along K into chunks of <= KSPLIT columns (own tiles, partial products summed by the scatter
+    # kernel): the launch lasts as long as its longest K loop, and rgb / scene have 2048 / 2208 input channels
+    items, index = [], []
+    for i, mod in enumerate(self.modalities):
+      x, w = plan.xin[mod], self._flat.shadow(('reduce', mod))[0]
+      outs = [plan.y[mod]] + plan.y_part[mod]
+      step = _round_up(-(-x.shape[1] // len(outs)), 64)  # even chunks, whole K steps of the GEMM
+      for c, out in enumerate(outs):
+        k0 = c * step
+        k1 = x.shape[1] if c == len(outs) - 1 else k0 + step
+        items.append((x[:, k0:k1], w[:, k0:k1], out, self.video_dim_reduce[mod].fc.bias if c == 0 else plan.zero_bias))
+        index.append(i)
+    ops.gemm_nt_grouped(items, m=plan.src_rows, n_rows_dev=plan.src_cnt, n_rows_index=index)
     feats = torch.empty(plan.rows_alloc, d, device=plan.slot.device, dtype=torch.float32)
     check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.n_rows), ops._p(plan.row_index),
                               ctypes.byref(plan.src), ops._p(feats), stream), 'mmt_video_scatter')
@@ -555,6 +572,9 @@ class CENet(nn.Module):
       plan.xin[mod] = x
       io.x, io.y, io.dy = x.data_ptr(), plan.y[mod].data_ptr(), plan.dy[mod].data_ptr()
       io.D, io.Dpad = self.expert_dims[mod]['dim'], x.shape[1]
+      io.n_part = len(plan.y_part[mod])
+      for c, part in enumerate(plan.y_part[mod]):
+        io.y_part[c] = part.data_ptr()
       io.type_idx, io.rows_pad = self.expert_dims[mod]['idx'], plan.src_rows_pad
     plan.inputs = keep
     plan.precast = ragged is not None

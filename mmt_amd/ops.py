@@ -121,15 +121,17 @@ def gemm_nt_splitk(a, b, out, epilogue='F32', m=None, bias=None, res=None, row_i
   return out
 
 
-def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32', n_rows_dev=None):
+def gemm_nt_grouped(items, m=None, epilogue='BIAS_F32', n_rows_dev=None, n_rows_index=None):
   """items: list of (a [M,K] bf16, b [N,K] bf16, out [M,N] fp32, bias [N] fp32 or None): all in ONE launch.
-  n_rows_dev: int32 device tensor [len(items)] of live rows per problem (tiles past them exit), or None."""
+  n_rows_dev: int32 device tensor of live rows per problem (tiles past them exit), or None; item i reads entry
+  n_rows_index[i] (default i)."""
   from ._lib import MmtGemmItem
   arr = (MmtGemmItem * len(items))()
   for i, (a, b, out, bias) in enumerate(items):
     _need_cuda(a, b, out)
     it = arr[i]
-    it.n_rows_dev = (n_rows_dev.data_ptr() + 4 * i) if n_rows_dev is not None else None
+    j = i if n_rows_index is None else n_rows_index[i]
+    it.n_rows_dev = (n_rows_dev.data_ptr() + 4 * j) if n_rows_dev is not None else None
     it.A, it.B, it.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
     it.bias = bias.data_ptr() if bias is not None else None
     it.lda, it.ldb, it.ldc = a.stride(0), b.stride(0), out.stride(0)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
   # struct layouts agree with the C side (sizes are what the kernels are compiled against)
   assert ctypes.sizeof(_lib.MmtEpilogue) == 96
   assert ctypes.sizeof(_lib.MmtPackItem) == 48
-  assert ctypes.sizeof(_lib.MmtExpertIO) == 72
+  assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
   assert ctypes.sizeof(_lib.MmtBertBatch) == 96
 
