@@ -339,7 +339,9 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   const int kg = wave8 >> 2, wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  const bool want_bias = it.bias_out != nullptr && tk == 0 && wn == 0;
+  // bias gradient (column sums of the A operand) in the first tile column: the two waves that hold the same A fragments
+  // (wn = 0 / 1) take two of the four each, so no wave of the tile carries 25 % more MFMAs than its neighbours
+  const bool want_bias = it.bias_out != nullptr && tk == 0;
   f32x4 acc[4][4], accb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -403,7 +405,10 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         if (want_bias) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) {  // (two static branches: a dynamic index would send af[] to scratch)
+            if (wn == 0) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            else accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2 + i], accb[i], 0, 0, 0);
+          }
         }
       }
     }
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
           if (k2 + e < it.K2_out) out[(int64_t)n * it.ldo + k2 + e] = acc[i][j][e];
       }
     }
-    if (want_bias && lg == 0) bias_out[n] = accb[i][0];
+    if (want_bias && lg == 0 && (i >> 1) == wn) bias_out[n] = accb[i & 1][0];
   }
 }
 
