@@ -388,6 +388,14 @@ class BertModel(nn.Module):
     if token_type_ids is None:
       token_type_ids = torch.zeros(bsz, seq, dtype=torch.long, device=dev)
 
+    # the reference's nn.Embedding lookups raise IndexError on ids outside their tables (bert.py:96-99); the fused
+    # embedding kernel would read out of bounds, so this (host-synchronising) check guards the standalone entry point --
+    # CENet's own path builds its ids on the device and clamps them (assemble.hip)
+    for name, ids, size in (('token_type_ids', token_type_ids, self.config.type_vocab_size),
+                            ('position_ids', position_ids, self.config.max_position_embeddings)):
+      if ids is not None and ids.numel() and not (0 <= int(ids.min()) and int(ids.max()) < size):
+        raise IndexError('%s out of range [0, %d)' % (name, size))
+
     def rows_i32(x):
       buf = torch.zeros(R, dtype=torch.int32, device=dev)
       buf[:rows] = x.reshape(-1).to(device=dev, dtype=torch.int32)

@@ -244,12 +244,14 @@ static int make_table(const MmtExpertIO* experts, int M, ExpertTable& tab) {
 // Only the [CLS] row of the last layer is read (post_agg 'cls', :378-379) and padded tokens are masked as keys in every
 // layer, so -- exactly as on the video side -- dropping them changes nothing: keep the tokens with attention_mask != 0,
 // in order, sample after sample.  row_index keeps the dense coordinate b*W + t (dropout RNG), cls_rows[b] = first kept
-// row of sample b (the caller guarantees attention_mask[:, 0] == 1).
+// row of sample b.  Token 0 ([CLS]) of every sample is ALWAYS kept, whatever its mask says (the reference's tokenisation
+// always marks it valid, base_dataset.py:63-68 after :336-344): a caption with an all-zero mask then still owns its CLS row
+// instead of reading the next sample's.
 __global__ __launch_bounds__(256) void text_count_kernel(const int64_t* __restrict__ mask, int W, int32_t* __restrict__ counts) {
   __shared__ int red[4];
   const int b = blockIdx.x;
   int c = 0;
-  for (int t = threadIdx.x; t < W; t += 256) c += mask[(int64_t)b * W + t] != 0;
+  for (int t = threadIdx.x; t < W; t += 256) c += (mask[(int64_t)b * W + t] != 0) || t == 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void text_pack_kernel(const int64_t* __restric
   for (int t0 = 0; t0 < W; t0 += 256) {
     const int t = t0 + threadIdx.x;
     const int64_t src = (int64_t)b * W + t;
-    const bool keep = t < W && mask[src] != 0;
+    const bool keep = t < W && (mask[src] != 0 || t == 0);
     const unsigned long long bal = __ballot(keep);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wave_cnt[wave] = __popcll(bal);

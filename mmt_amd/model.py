@@ -312,6 +312,13 @@ class CENet(nn.Module):
     self._vid_weights = {}
     self.overlap_text_heads = False  # measured: no gain on MI355X (1.76 vs 1.74 ms/step), kept as an option
     self._side_streams = {}
+    # the reference indexes nn.Embedding tables with these and raises IndexError when they do not fit; the kernels would
+    # read out of bounds silently, so the check happens here
+    type_vocab = (vid_bert_params or {}).get('type_vocab_size')
+    if type_vocab is not None:
+      bad = [m for m, e in expert_dims.items() if not 0 <= e['idx'] < type_vocab]
+      if bad:
+        raise IndexError('expert type ids of %r do not fit vid_bert_params.type_vocab_size = %d' % (bad, type_vocab))
     unsupported = []
     if vid_cont != 'bert': unsupported.append('vid_cont=%r' % vid_cont)
     if vid_inp != 'both': unsupported.append('vid_inp=%r' % vid_inp)

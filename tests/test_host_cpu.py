@@ -98,6 +98,22 @@ def test_unsupported_modes_fail_loudly():
           txt_bert=_fake_txt_bert())
 
 
+def test_expert_type_ids_must_fit_the_type_table():
+  """The reference's nn.Embedding raises IndexError for a type id outside the table (model/bert.py:96-99); the fused
+  embedding kernel would read out of bounds, so the constructor checks."""
+  meta = json.loads(str(load_npz('cenet_tiny')['meta']))
+  from mmt_amd import synthetic
+  from mmt_amd.model import CENet
+  fx = meta['fixture']
+  dims = synthetic.compute_dims(fx['modalities'])
+  vb = dict(synthetic.vid_bert_params(**fx['vb']), type_vocab_size=max(e['idx'] for e in dims.values()))
+  with pytest.raises(IndexError):
+    CENet(l2renorm=False, expert_dims=dims, tokenizer=None, keep_missing_modalities=True, test_caption_mode='indep',
+          txt_inp='bertftn', txt_agg='bertftn', txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both',
+          pos_enc='tint', out_tok='mxp', vid_bert_params=vb, txt_pro='gbn', same_dim=fx['vb']['hidden'],
+          txt_bert=_fake_txt_bert())
+
+
 def test_flat_params_survive_load_and_move():
   from mmt_amd import synthetic
   meta = json.loads(str(load_npz('cenet_tiny')['meta']))

@@ -2,6 +2,8 @@
 gradients stored in tests/golden/text_bert.npz and (b) the oracle at the bert-base-cased shape the reference fine-tunes
 (12 layers x 768, 12 heads x 64, 28 996 tokens; model/model.py:152-162).  bf16 MFMA operands / fp32 everything else:
 hidden states atol 0.03, gradients 3 % of their norm (SURVEY 8c tolerances)."""
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -169,3 +171,34 @@ def test_text_token_packing_is_exact_including_dropout():
   assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-3
   g0, g1 = outs[0][1], outs[1][1]
   assert (g0 - g1).norm().item() < 2e-3 * g0.norm().item()
+
+
+def test_text_plan_keeps_the_cls_token_of_a_fully_masked_caption():
+  """A caption whose attention mask is all zero still owns its [CLS] row (cls_rows must never point into the next sample
+  or past the live rows); other captions are unaffected."""
+  gold, cfg, sd, ids, mask, probe = load_text_bert_fixture()
+  model = _native(cfg, sd).eval()
+  model.cls_only, model.pack_tokens = True, True
+  with torch.no_grad():
+    ref = model(ids.to(DEV), attention_mask=mask.to(DEV))[0][:, 0].clone()
+    m2 = mask.clone()
+    m2[1] = 0
+    out = model(ids.to(DEV), attention_mask=m2.to(DEV))[0][:, 0]
+  keep = [i for i in range(ids.shape[0]) if i != 1]
+  assert torch.isfinite(out).all()
+  assert (out[keep] - ref[keep]).abs().max().item() < 1e-5
+  assert (out[1] - ref[1]).abs().max().item() > 1e-3      # its own row: [CLS] attending to itself only
+
+
+def test_standalone_bert_rejects_ids_outside_the_tables():
+  from mmt_amd import synthetic
+  from mmt_amd.bert import BertModel
+  cfg = types.SimpleNamespace(**synthetic.vid_bert_params(hidden=256, layers=1, heads=2, inter=512, max_pos=16))
+  model = BertModel(cfg).to(DEV).eval()
+  feats = torch.randn(2, 5, 256, device=DEV)
+  pos = torch.full((2, 5), 16, device=DEV, dtype=torch.long)   # table has rows 0..15
+  with pytest.raises(IndexError):
+    model(None, features=feats, position_ids=pos)
+  typ = torch.full((2, 5), cfg.type_vocab_size, device=DEV, dtype=torch.long)
+  with pytest.raises(IndexError):
+    model(None, features=feats, token_type_ids=typ)
