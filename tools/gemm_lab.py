@@ -83,6 +83,8 @@ def main():
   ap.add_argument('--tiles', default='1,2,3,4,5,6')
   ap.add_argument('--ablate', action='store_true', help='(needs a lab build with debug flags)')
   ap.add_argument('--nocheck', action='store_true')
+  ap.add_argument('--instep', action='store_true',
+                  help='launch as the training step does: M = the dense row count, live rows in a DEVICE scalar, row_index + device seed')
   ap.add_argument('--text', action='store_true', help='the text tower shapes (d = 768) instead of the video ones (d = 512)')
   args = ap.parse_args()
   tiles = [int(t) for t in args.tiles.split(',')]
@@ -111,9 +113,13 @@ def main():
           print('ablate %5dx%4dx%4d %-10s tile=%d ' % (rows, N, K, epi, tile) +
                 '  '.join('f%d %5.1f' % (fl, us) for fl, us in zip(flags, ts)))
     return
+  DENSE = 6976
   for rows in [int(r) for r in args.rows.split(',')]:
-    R = ops.pad_rows(rows)
-    print('rows', rows)
+    R = ops.pad_rows(DENSE if args.instep else rows)
+    print('rows', rows, '(launched as the step does: M = %d, live rows on the device)' % DENSE if args.instep else '')
+    nrd = torch.tensor([rows], device=dev, dtype=torch.int32)
+    ridx = (torch.arange(R, device=dev, dtype=torch.int32) * 2) % (DENSE)
+    seed = torch.tensor([7], device=dev, dtype=torch.int32)
     video = [(3072, 512, 'BIAS_GELU'), (3072, 512, 'DGELU'), (3072, 512, 'BIAS_BF16'), (1536, 512, 'BIAS_BF16'),
              (512, 512, 'BIAS_DROP_RES'), (512, 3072, 'BIAS_DROP_RES'), (512, 3072, 'ADD_F32'), (512, 1536, 'ADD_F32'),
              (512, 512, 'BF16')]
@@ -135,6 +141,13 @@ def main():
           kw.update(drop_key=1, drop_p=0.1)
         if epi == 'DGELU' and tile != 12:
           kw.update(colsum=cs)
+        if args.instep:
+          kw.update(n_rows_dev=nrd)
+          if epi == 'BIAS_DROP_RES':
+            kw.update(row_index=ridx, seed_dev=seed)
+          fns.append(lambda kw=kw: ops.gemm_nt(a, b, out, epi, m=DENSE, **kw))
+          used.append(tile)
+          continue
         fns.append(lambda kw=kw: ops.gemm_nt(a, b, out, epi, m=rows, **kw))
         used.append(tile)
       ts = timeit(fns)
