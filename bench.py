@@ -353,6 +353,15 @@ def main():
     dense_ms = dense_run['elapsed'] / max(10, args.steps // 2) * 1e3
     dense_run = dict(ms_per_step=dense_ms, pairs_per_s=BATCH / dense_ms * 1e3)
 
+  # every rank empties its C stdio buffer (RCCL's banner) BEFORE rank 0 prints, so the JSON line ends the job's stdout
+  try:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+  except OSError:
+    pass
+  sys.stdout.flush()
+  if world > 1:
+    dist.barrier()
   if rank == 0:
     live = int(round(sum(live_rows) / len(live_rows)))  # mean live token rows per launch over the probe steps
     dense_rows = BATCH * seq
@@ -400,7 +409,14 @@ def main():
       out['roofline_top3'] = tops
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
+    # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise come out at
+    # exit, AFTER the result: flush it first so that the JSON line is the last line of stdout
+    try:
+      import ctypes
+      ctypes.CDLL(None).fflush(None)
+    except OSError:
+      pass
+    print(json.dumps(out), flush=True)
   if dist.is_initialized():
     dist.destroy_process_group()
 

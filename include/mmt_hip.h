@@ -113,6 +113,9 @@ int mmt_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
                      int rows, int N, int K2, int splits, const int32_t* n_rows_dev, void* stream);
 int mmt_reduce_slabs(const float* ws, int splits, int64_t count, float* out, int accumulate,
                      void* stream);
+/* the same for a weight-gradient slab set and its bias-gradient slab set in ONE launch (out = sum of `splits` slabs) */
+int mmt_reduce_slabs_pair(const float* ws_a, int64_t count_a, float* out_a, const float* ws_b, int64_t count_b,
+                          float* out_b, int splits, void* stream);
 
 /* Grouped weight gradients: for every item, out[N_out, K2_out] = sum_rows A[rows,N]^T . B[rows,K2] written
  * directly as fp32 (no split-K slabs), and bias_out[n] = sum_rows A[rows, n] (nullable) -- all items in ONE
@@ -306,8 +309,10 @@ typedef struct MmtAdamSeg {
 int mmt_adam_fused_blocks(const MmtAdamSeg* seg);
 int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                         const MmtAdamSeg* segs_host, const MmtAdamSeg* segs_dev, int n_segs, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, const int32_t* step_dev, const float* lr_dev,
-                        void* stream);
+                        float beta2, float eps, float weight_decay, int32_t* step_dev, const float* lr_dev,
+                        int bump_step, void* stream);
+/* bump_step = 0: step_dev[0] is this launch's step number t (bias correction), as mmt_adam_step.
+ * bump_step = 1: step_dev is int32[2] = {steps taken so far, 0}; the launch is step step_dev[0] + 1 and stores it. */
 
 /* ---- video tokens (assemble.hip) -------------------------------------------------------------------
  * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip.

@@ -131,6 +131,7 @@ SIGNATURES = {
     'mmt_gemm_nt_grouped': (c_int, [ctypes.POINTER(MmtGemmItem), c_int, c_int, c_vp]),
     'mmt_wgrad_grouped': (c_int, [ctypes.POINTER(MmtWgradGroup), c_vp]),
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
+    'mmt_reduce_slabs_pair': (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                  c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
@@ -172,7 +173,7 @@ SIGNATURES = {
     'mmt_adam_step': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_adam_fused_blocks': (c_int, [ctypes.POINTER(MmtAdamSeg)]),
     'mmt_adam_step_fused': (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtAdamSeg), c_vp, c_int, c_f32, c_f32, c_f32,
-                                    c_f32, c_f32, c_vp, c_vp, c_vp]),
+                                    c_f32, c_f32, c_vp, c_vp, c_int, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtVideoSrc), c_vp]),
     'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, ctypes.POINTER(MmtVideoSrc), c_vp]),

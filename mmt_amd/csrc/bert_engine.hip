@@ -315,8 +315,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         g.item[3].A = t.dy;    g.item[3].lda = d;     g.item[3].B = t.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
         g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo; g.item[3].reserved = nc;
         TRY(mmt_wgrad_grouped(&g, stream));
-        TRY(mmt_reduce_slabs(t.wslab, TAIL_WSPLIT, (int64_t)3 * d * d, P.g_wqkv, 0, stream));
-        TRY(mmt_reduce_slabs(t.bslab, TAIL_WSPLIT, (int64_t)3 * d, P.g_bqkv, 0, stream));
+        TRY(mmt_reduce_slabs_pair(t.wslab, (int64_t)3 * d * d, P.g_wqkv, t.bslab, (int64_t)3 * d, P.g_bqkv, TAIL_WSPLIT, stream));
       }
       dcur = dnext;
       continue;

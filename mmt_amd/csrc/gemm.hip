@@ -623,6 +623,30 @@ extern "C" int mmt_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
   return (int)hipGetLastError();
 }
 
+// two slab sets (a weight gradient and its bias gradient) in one launch
+__global__ void reduce_slabs_pair_kernel(const float* __restrict__ wa, int64_t ca4, float* __restrict__ oa,
+                                         const float* __restrict__ wb, int64_t cb4, float* __restrict__ ob, int splits) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ca4 + cb4; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool first = i < ca4;
+    const f32x4* ws = (const f32x4*)(first ? wa : wb);
+    const int64_t j = first ? i : i - ca4, c4 = first ? ca4 : cb4;
+    f32x4 s = ws[j];
+    for (int k = 1; k < splits; ++k) s += ws[k * c4 + j];
+    ((f32x4*)(first ? oa : ob))[j] = s;
+  }
+}
+
+extern "C" int mmt_reduce_slabs_pair(const float* ws_a, int64_t count_a, float* out_a, const float* ws_b, int64_t count_b,
+                                     float* out_b, int splits, void* stream) {
+  if (!ws_a || !out_a || !ws_b || !out_b || splits <= 0 || count_a <= 0 || count_b <= 0 || ((count_a | count_b) & 3))
+    return MMT_ERR_ARG;
+  const int64_t c4 = (count_a + count_b) / 4;
+  const int grid = (int)((c4 + 255) / 256 < 2048 ? (c4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(reduce_slabs_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws_a, count_a / 4, out_a, ws_b,
+                     count_b / 4, out_b, splits);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mmt_reduce_slabs(const float* ws, int splits, int64_t count, float* out, int accumulate,
                                 void* stream) {
   if (!ws || !out || splits <= 0 || count <= 0 || (count & 3)) return MMT_ERR_ARG;

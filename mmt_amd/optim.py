@@ -80,7 +80,9 @@ class FlatAdam:
     if self.exp_avg is None or self.exp_avg.device != f.master.device:
       self.exp_avg = torch.zeros_like(f.master)
       self.exp_avg_sq = torch.zeros_like(f.master)
-      self.step_dev = torch.zeros(1, dtype=torch.int32, device=f.master.device)
+      # [steps taken, ticket]: the fused kernel increments the count itself (mmt_adam_step_fused, bump_step)
+      self._step_store = torch.zeros(2, dtype=torch.int32, device=f.master.device)
+      self.step_dev = self._step_store[:1]
     if self.lr_dev is None or self.lr_dev.device != f.master.device:
       self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=f.master.device)
       self._lr_on_dev = float(self.lr)
@@ -142,17 +144,18 @@ class FlatAdam:
     self._ensure_state()
     self.sync_lr()
     g = self._grad()
-    self.step_dev.add_(1)
     table = self._segment_table() if self.fuse_shadows else None
     if table is not None:
-      # ONE launch: Adam over every segment of the flat buffer + the bf16 W / W^T shadows of the GEMM weights
+      # ONE launch: Adam over every segment of the flat buffer + the bf16 W / W^T shadows of the GEMM weights + the step
+      # counter (the last block to finish stores steps + 1)
       host, dev, n = table
       check(_lib.lib().mmt_adam_step_fused(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
                                            host, ops._p(dev), n, float(self.lr), self.betas[0], self.betas[1], self.eps,
-                                           self.weight_decay, ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()),
-            'mmt_adam_step_fused')
+                                           self.weight_decay, ops._p(self._step_store), ops._p(self.lr_dev), 1,
+                                           ops._stream()), 'mmt_adam_step_fused')
       f.shadows_fresh()
       return
+    self.step_dev.add_(1)
     check(_lib.lib().mmt_adam_step(ops._p(f.master), ops._p(g), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
                                    f.count, float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                    ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()), 'mmt_adam_step')
