@@ -17,15 +17,16 @@ bytes at the synthetic-MSRVTT fill: bf16 x ~52 % live rows), no cast kernel.  bf
 device path rounds the fp32 features to bf16 (round-to-nearest-even) before the first GEMM anyway, `to_bf16` below is the
 same rounding, and max pooling commutes with a monotone rounding.
 
-Not carried: features_avgpool (only read for out_tok='avg', which the drop-in rejects) and the raw caption strings
-(tokenisation is the HuggingFace tokenizer's, upstream of the hot path; token ids are plain int tensors)."""
+Not carried: features_avgpool (only read for out_tok='avg', which the drop-in rejects).  Captions are stored as the token
+ids the (HuggingFace, upstream) tokenizer produced for `caption_text(words)`; `collate_tokens` applies the cut to
+max_text_words / forced [SEP] / padding rules of the reference (base_dataset.py:320-346, 63-68)."""
 import json
 import os
 
 import numpy as np
 import torch
 
-__all__ = ['FEAT_WIDTH', 'feature_timings', 'choose_rows', 'to_bf16', 'from_bf16', 'FeatureStoreWriter', 'FeatureStore',
+__all__ = ['FEAT_WIDTH', 'feature_timings', 'choose_rows', 'caption_text', 'crop_or_pad_tokens', 'to_bf16', 'from_bf16', 'FeatureStoreWriter', 'FeatureStore',
            'RaggedLayout', 'RaggedFeatures', 'RaggedCollator']
 
 # utils/expert_timings.py: seconds covered by one feature row (stride = width); every other expert has no timing (-1)
@@ -63,6 +64,27 @@ def choose_rows(n, max_tokens, training, rng=None):
   return np.sort(pick)
 
 
+def caption_text(words):
+  """The string `tokenize_caption` hands to the tokenizer (base_dataset.py:328-334): words joined by blanks, stripped,
+  a period appended unless it already ends a sentence, capitalised."""
+  txt = ' '.join(words).strip()
+  if txt[-1] not in ['.', '?', '!']:
+    txt += '.'
+  return txt.capitalize()
+
+
+def crop_or_pad_tokens(ids, max_text_words, sep_id=None):
+  """[max_text_words, 2] (id, valid) rows of one caption: the token list is cut to max_text_words and, when special
+  tokens are in use, its last kept token forced to [SEP] (base_dataset.py:340-344), then `crop_or_pad_to_len` (:63-68)."""
+  ids = np.array(ids[:max_text_words], dtype=np.int64)
+  if sep_id is not None and ids.shape[0]:
+    ids[-1] = sep_id
+  out = np.zeros((max_text_words, 2))
+  out[:ids.shape[0], 0] = ids
+  out[:ids.shape[0], 1] = 1
+  return out
+
+
 def to_bf16(a):
   """fp32 array -> uint16 bf16 bit patterns, round-to-nearest-even (what csrc pack_bf2 does on the device)."""
   u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
@@ -89,10 +111,19 @@ class FeatureStoreWriter:
     self._rows = {e: open(os.path.join(path, e + '.rows'), 'wb') for e in self.experts}
     self._t = {e: open(os.path.join(path, e + '.t'), 'wb') for e in self.experts}
     self._off = {e: [0] for e in self.experts}
+    self._tok = open(os.path.join(path, 'captions.tok'), 'wb')
+    self._cap_off, self._vid_cap = [0], [0]   # token offset of every caption, caption offset of every video
 
-  def add(self, vid, features, features_t=None):
-    """features: {expert: [n, D] float array}; features_t: {expert: [n, 2] start/end seconds} (optional per expert)."""
+  def add(self, vid, features, features_t=None, captions=None):
+    """features: {expert: [n, D] float array}; features_t: {expert: [n, 2] start/end seconds} (optional per expert);
+    captions: list of token-id sequences, one per caption of the video, tokenised as `tokenize_caption` does
+    (base_dataset.py:320-346: `caption_text(words)` through the tokenizer, [CLS] ... [SEP], NOT yet cut to max_text_words)."""
     features_t = features_t or {}
+    for ids in (captions or []):
+      ids = np.asarray(ids, dtype=np.int32).reshape(-1)
+      self._tok.write(ids.tobytes())
+      self._cap_off.append(self._cap_off[-1] + ids.shape[0])
+    self._vid_cap.append(len(self._cap_off) - 1)
     for e, dim in self.experts.items():
       x = features.get(e)
       n = 0
@@ -118,6 +149,9 @@ class FeatureStoreWriter:
       self._rows[e].close()
       self._t[e].close()
       np.asarray(self._off[e], dtype=np.int64).tofile(os.path.join(self.path, e + '.off'))
+    self._tok.close()
+    np.asarray(self._cap_off, dtype=np.int64).tofile(os.path.join(self.path, 'captions.off'))
+    np.asarray(self._vid_cap, dtype=np.int64).tofile(os.path.join(self.path, 'captions.vid'))
     with open(os.path.join(self.path, 'meta.json'), 'w') as f:
       json.dump({'version': 1, 'dtype': self.dtype, 'experts': self.experts, 'videos': self.videos}, f)
 
@@ -153,8 +187,20 @@ class FeatureStore:
         self._rows[e] = np.zeros((0, dim), np.uint16 if self.dtype == 'bf16' else np.float32)
         self._t[e] = np.zeros((0,), np.float64)
 
+    self._cap_off = np.fromfile(os.path.join(path, 'captions.off'), dtype=np.int64)
+    self._vid_cap = np.fromfile(os.path.join(path, 'captions.vid'), dtype=np.int64)
+    ntok = int(self._cap_off[-1])
+    self._tok = (np.memmap(os.path.join(path, 'captions.tok'), mode='r', dtype=np.int32, shape=(ntok,)) if ntok
+                 else np.zeros((0,), np.int32))
+
   def __len__(self):
     return len(self.videos)
+
+  def captions(self, i):
+    """-> list of int32 token-id views, one per stored caption of video i"""
+    i = self.index[i] if isinstance(i, str) else i
+    a, b = int(self._vid_cap[i]), int(self._vid_cap[i + 1])
+    return [self._tok[self._cap_off[c]:self._cap_off[c + 1]] for c in range(a, b)]
 
   def rows(self, expert, i):
     """-> ([n, D] rows as stored, [n] mean second of each row) of video i (index or id)"""
@@ -303,6 +349,21 @@ class RaggedCollator:
 
   def new_buffer(self):
     return RaggedFeatures(self.layout, 'cpu', self.pin_memory)
+
+  def collate_tokens(self, indices, captions_per_video, max_text_words, pad_caption, sep_id=None):
+    """token_ids [B, C, W, 2] int32 and query_masks [B, C] int32 as `__getitem__` + `collate_data` build them for
+    query_shuffling='indiv', caption_length=inf, n_pairs=1 (base_dataset.py:594-600, 647-668, 741-757, 852-858;
+    mix_dataset.py:134-136): the first C stored captions of every video, missing ones replaced by `pad_caption` (the
+    token ids of the reference's filler caption "0", :661-664) with query mask 0."""
+    tok = np.zeros((len(indices), captions_per_video, max_text_words, 2))
+    qm = np.zeros((len(indices), captions_per_video))
+    for s, i in enumerate(indices):
+      caps = self.store.captions(i)
+      for c in range(captions_per_video):
+        have = c < len(caps)
+        tok[s, c] = crop_or_pad_tokens(caps[c] if have else pad_caption, max_text_words, sep_id)
+        qm[s, c] = 1.0 if have else 0.0
+    return torch.from_numpy(tok.astype(np.int32)), torch.from_numpy(qm.astype(np.int32))
 
   def collate(self, indices, out=None, window=None):
     L = self.layout

@@ -10,11 +10,22 @@ from tests import dataset_fixture as DF
 from tests.fixtures import load_npz
 
 
+class FixtureTokenizer:
+  """the stand-in tokenizer oracle/gen_dataset_golden.py gave the reference dataset (any tokenizer would do: the store
+  keeps what it returns)"""
+  CLS, SEP = 101, 102
+
+  def ids(self, words):
+    toks = FS.caption_text(words).replace('.', ' .').split()
+    return [self.CLS] + [1000 + sum(map(ord, t)) % 997 for t in toks] + [self.SEP]
+
+
 def build_store(path, dtype):
+  tok = FixtureTokenizer()
   with FS.FeatureStoreWriter(str(path), DF.DIMS, dtype=dtype) as w:
     for vid, h5 in DF.make_videos():
       feats, times = DF.h5_features(h5)
-      w.add(vid, feats, times)
+      w.add(vid, feats, times, captions=[tok.ids(list(h5['raw_captions.0']))])
   return FS.FeatureStore(str(path))
 
 
@@ -119,3 +130,21 @@ def test_collator_reuses_a_buffer_and_training_is_a_valid_draw(tmp_path):
   b = coll.collate([1, 1, 1, 1], out=buf)                         # a smaller batch leaves nothing of the old one visible
   feats2, _, fi2, _ = b.to_dense()
   assert fi2['s3d'].sum() == 20 and b.live['s3d'] == 4 + 20 and b.live_bytes() < a.layout.nbytes
+
+
+def test_collated_token_ids_equal_reference_pipeline(tmp_path):
+  """token_ids (B, C, W, 2) as the real `__getitem__` + `collate_data` built them: captions of 3..10 words against
+  max_text_words = 10 (the longest is cut and its last kept token forced to [SEP])."""
+  g = load_npz('dataset_items')
+  store = build_store(tmp_path / 's', 'bf16')
+  coll = FS.RaggedCollator(store, list(DF.DIMS), len(store), DF.MAX_TOKENS, training=False)
+  tok = FixtureTokenizer()
+  ids, qm = coll.collate_tokens(list(range(len(store))), 1, DF.MAX_WORDS, pad_caption=tok.ids(['0']), sep_id=tok.SEP)
+  assert ids.dtype == torch.int32 and np.array_equal(ids.numpy(), g['full/token_ids'])
+  assert np.array_equal(ids.numpy(), g['clip/token_ids']) and int(qm.sum()) == len(store)
+  assert int(ids[7, 0, :, 1].sum()) == DF.MAX_WORDS and int(ids[7, 0, -1, 0]) == tok.SEP   # 10 words: cut, [SEP] forced
+  assert int(ids[0, 0, :, 1].sum()) == 6                                                    # [CLS] w0 w1 w2 . [SEP]
+  # more captions requested than stored: the filler caption with query mask 0 (base_dataset.py:661-664)
+  ids2, qm2 = coll.collate_tokens([0, 1], 2, DF.MAX_WORDS, pad_caption=tok.ids(['0']), sep_id=tok.SEP)
+  assert qm2.tolist() == [[1, 0], [1, 0]] and ids2[0, 1, :, 1].sum() == 4 and torch.equal(ids2[:, 0], ids[:2, 0])
+  assert [len(c) for c in store.captions('video3')] == [3 + 3 + 3]
