@@ -214,6 +214,8 @@ def main():
                        'no cast kernel) instead of the reference\'s dict of dense fp32 tensors')
   ap.add_argument('--force-collectives', action='store_true',
                   help='N=1 only: run the all-gather / all-reduce plumbing on a 1-rank RCCL group (measures its overhead)')
+  ap.add_argument('--capture-collectives', action='store_true',
+                  help='EXPERIMENTAL: capture the RCCL collectives into the step graph (one graph launch per multi-rank step)')
   ap.add_argument('--eager', action='store_true', help='no HIP-graph capture (host-bound; for debugging)')
   ap.add_argument('--no-dense', action='store_true', help='skip the second (unpacked) timing of the same step')
   ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default='fp32',
@@ -286,7 +288,8 @@ def main():
       model.txt_bert.text = static['text']
     runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
-                              force_collectives=args.force_collectives, grad_dtype=grad_dtype)
+                              force_collectives=args.force_collectives, grad_dtype=grad_dtype,
+                              capture_collectives=args.capture_collectives)
     it, first = 0, None
     if args.host_inputs:
       # double-buffered upload: minibatch i+1 crosses PCIe on a copy stream while step i computes
@@ -384,7 +387,7 @@ def main():
                    'input_format': 'ragged bf16 wire buffer (live rows)' if args.ragged_inputs else 'dense fp32 dict',
                    'video_input_bytes_per_step': int(sum(input_bytes) / len(input_bytes)),
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
-                   'grad_wire_dtype': args.grad_dtype,
+                   'grad_wire_dtype': args.grad_dtype, 'collectives_captured': bool(args.capture_collectives and (world > 1 or args.force_collectives)),
                    'live_rows_rank0': live, 'dense_rows': dense_rows},
         # fraction of the (B, S) token grid that holds a real token in the synthetic batches (valid length ~ U{0..30}
         # per expert); the packed step computes only those, the dense step all of them.  The fill of real

@@ -92,7 +92,7 @@ def _copy_tree(dst, src):
 class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
-               overlap_grad_sync=None, force_collectives=False, grad_dtype=None):
+               overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -110,6 +110,8 @@ class GraphedTrainStep:
     self._want_stages = self._multi if overlap_grad_sync is None else bool(overlap_grad_sync)
     self.staged = False
     self.static = minibatch
+    self.capture_collectives = bool(capture_collectives)
+    self._one_graph = False
     self._staging = None  # device-side landing buffer of prefetch()
     flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
     flat_ids = {id(p) for f in flats for p in f.params}
@@ -462,6 +464,29 @@ class GraphedTrainStep:
       pool = ga.pool()
       with torch.cuda.stream(self._stream):
         g = self._gather(e)
+    if self._multi and self.capture_collectives:
+      # EXPERIMENTAL (opt-in): the collectives are captured too, so a multi-rank step is ONE graph launch like the
+      # single-rank one -- RCCL's stream joins the capture through the events torch.distributed records, the cross-stream
+      # waits become graph edges.  Verified on a 1-rank RCCL group only (no multi-GPU box this round), hence not default.
+      ga = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(ga, stream=self._stream):
+        e = self._forward()
+        g = self._gather(e)
+        if self.staged:
+          self._regions = self._region_table()
+          handles = []
+          for fn, names in self._stage_list(e, g):
+            fn()
+            handles += self._reduce_async(names)
+          self._finish(handles)
+        else:
+          self.loss = self._loss_backward(e, g)
+          self._sync_all()
+        self._opt()
+      self._graphs, self._e = (ga, None, None), e
+      self._one_graph = True
+      torch.cuda.synchronize()
+      return
     if not self._multi and not self.staged:
       # nothing happens between forward and backward on one rank: one graph for both (one launch gap less per step)
       ga = torch.cuda.CUDAGraph()
@@ -553,7 +578,7 @@ class GraphedTrainStep:
       o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     ga, gb, gc = self._graphs
     ga.replay()
-    if self._multi:
+    if self._multi and not self._one_graph:
       self._gather(self._e)
     if gb is None:
       pass  # forward + backward were captured as one graph

@@ -52,7 +52,8 @@ def _slice_batch(mb, text, sl):
   return out
 
 
-def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, **build_kw):
+def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, force_collectives=False,
+         capture_collectives=False, **build_kw):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
@@ -64,8 +65,9 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
   static = FlatMinibatch(_slice_batch(mb, text, slice(rank * b, (rank + 1) * b)), dev)
   model.txt_bert.text = static['text']
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
-                            overlap_grad_sync=overlap, grad_dtype=grad_dtype)
-  assert runner.staged == (world > 1 if overlap is None else overlap)
+                            overlap_grad_sync=overlap, grad_dtype=grad_dtype, force_collectives=force_collectives,
+                            capture_collectives=capture_collectives)
+  assert runner.staged == ((world > 1 or force_collectives) if overlap is None else overlap)
   # the warm-up inside the constructor must not have trained: weights, BatchNorm statistics, Adam state as loaded
   now = model.state_dict()
   for k, v in init.items():
@@ -87,7 +89,11 @@ def _worker(rank, world, port, out, kw):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   torch.cuda.set_device(0)
-  dist.init_process_group('gloo', rank=rank, world_size=world)
+  backend = kw.pop('backend', 'gloo')
+  if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+  else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
   torch.save(_run(rank, world, torch.device('cuda', 0), **kw), '%s.%d' % (out, rank))
   dist.barrier()
   dist.destroy_process_group()
@@ -156,6 +162,21 @@ def test_bf16_gradient_wire_format_tracks_fp32_reduction(tmp_path):
   g = (a['grad'] - b['grad']).norm() / a['grad'].norm()
   assert g < 1e-2, g.item()
   assert max(abs(x - y) for x, y in zip(a['losses'], b['losses'])) < 1e-3
+
+
+def test_collectives_captured_into_the_step_graph_change_nothing(tmp_path):
+  """GraphedTrainStep(capture_collectives=True): all-gather + staged all-reduces captured into ONE graph with the rest of
+  the step.  On the real backend (RCCL; a 1-rank group is what one GPU allows) the trajectory is bit-identical to the
+  step that issues the collectives between graph launches."""
+  outs = {}
+  for name, cap in (('plain', False), ('captured', True)):
+    out = str(tmp_path / name)
+    kw = dict(backend='nccl', force_collectives=True, capture_collectives=cap, steps=4, txt_pro='gbn', dropout=0.1, layers=4)
+    mp.spawn(_worker, args=(1, _free_port(), out, kw), nprocs=1, join=True)
+    outs[name] = torch.load(out + '.0')
+  a, b = outs['plain'], outs['captured']
+  assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
+  assert torch.equal(a['master'], b['master'])
 
 
 def _sharded_worker(rank, world, port, out):
