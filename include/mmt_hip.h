@@ -133,7 +133,7 @@ typedef struct MmtWgradItem {
   int32_t reserved; /* > 0: this item contracts over exactly `reserved` rows (overrides rows / n_rows_dev)     */
   float* slab;      /* splits > 1: partial results [splits][N_out, ldo] (summed by the caller, e.g.            */
   float* bias_slab; /*   mmt_col_reduce_multi) and partial bias gradients [splits][N_out]                       */
-  int32_t splits, reserved2;
+  int32_t splits, reserved2; /* reserved2: set by mmt_wgrad_grouped (tile patch shape), callers leave it 0 */
   const int32_t* n_rows_dev; /* nullable: this item contracts over *n_rows_dev rows (device; overrides the group's) */
 } MmtWgradItem;
 typedef struct MmtWgradGroup {

@@ -322,7 +322,22 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   const int nsplit = it.splits > 1 ? it.splits : 1;
   const int tile = (id - it.tile_begin) / nsplit, split = (id - it.tile_begin) % nsplit;
   const int tiles_k = it.K2 / 128;
-  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  // Tile order inside an item: patches of PN x PK tiles (reserved2 = PN << 16 | PK, chosen by the host so that PN * PK is
+  // about the 32 consecutive ids one XCD receives): the tiles that share an L2 then share as few distinct operand panels
+  // as possible (8 x 4 or 4 x 8 tiles = 12 panels; a row-major run over a 4 x 24 grid = 34).
+  int tn, tk;
+  {
+    const int PN = it.reserved2 >> 16, PK = it.reserved2 & 0xffff;
+    if (PN > 0 && PK > 0) {
+      const int per = PN * PK, patches_k = tiles_k / PK;
+      const int patch = tile / per, within = tile % per;
+      tn = (patch / patches_k) * PN + within / PK;
+      tk = (patch % patches_k) * PK + within % PK;
+    } else {
+      tn = tile / tiles_k;
+      tk = tile % tiles_k;
+    }
+  }
   const int n0 = tn * 128, k0 = tk * 128;
   // item.reserved > 0: this item contracts over exactly that many rows (compact last-layer buffers)
   const int nrows = it.reserved > 0 ? it.reserved
@@ -479,6 +494,16 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
     if (it.splits > 1 && (!it.slab || (it.bias_out && !it.bias_slab))) return MMT_ERR_ARG;
     it.tile_begin = tiles;
     tiles += (it.N / 128) * (it.K2 / 128) * (it.splits > 1 ? it.splits : 1);
+    // patch shape: PN = largest divisor of the tile rows <= 8, PK = largest divisor of the tile columns <= 32 / PN
+    {
+      const int tn_all = it.N / 128, tk_all = it.K2 / 128;
+      int pn = 1, pk = 1;
+      for (int c = 1; c <= 8; ++c)
+        if (tn_all % c == 0) pn = c;
+      for (int c = 1; c <= 32 / pn; ++c)
+        if (tk_all % c == 0) pk = c;
+      it.reserved2 = (pn << 16) | pk;
+    }
   }
   constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;  // 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
   static bool configured = false;
