@@ -139,7 +139,22 @@ __device__ __forceinline__ void gemm2_body(
     return;
   }
   const int id = xcd_remap(bid, live_tiles);
-  const int tm = id / tiles_n, tn = id % tiles_n;
+  // Wide outputs (N >= 1024: QKV, FFN-up, dGELU) walk the tile grid in bands of GROUP tile rows, column by column inside a
+  // band: the ~live_tiles / 8 consecutive ids an XCD owns then touch GROUP A panels + a third of the B panels instead of
+  // every B panel (the whole weight matrix) + 4 A panels.  Narrow outputs (<= 8 tile columns) stay row-major.
+  int tm, tn;
+  if (tiles_n * BN >= 1024) {
+    constexpr int GROUP = 8;
+    const int tile_rows = live_tiles / tiles_n;           // live tile rows (live_tiles is a multiple of tiles_n)
+    const int band = id / (GROUP * tiles_n), first = band * GROUP;
+    const int rows_here = min(GROUP, tile_rows - first);  // the last band may be shorter
+    const int within = id - band * GROUP * tiles_n;
+    tm = first + within % rows_here;
+    tn = within / rows_here;
+  } else {
+    tm = id / tiles_n;
+    tn = id % tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
