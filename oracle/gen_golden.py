@@ -69,6 +69,10 @@ FIXTURES = {
     # BASELINE.json configs[4] encoder shape (HowTo100M-scale): d1024, 6 layers, 8 heads, I = 6144; small batch
     'config5': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=4, max_tokens=10,
                     vb=dict(hidden=1024, layers=6, heads=8, inter=6144, max_pos=32), seed=15),
+    # ... and the same encoder at the MSRVTT token count and a batch that fills whole GEMM tiles (16 x 218 = 3 488 token
+    # rows; d1024 / 8 heads / I = 6144 / 6 layers: every GEMM shape, head count and split-K path of configs[4])
+    'config5b16': dict(modalities=synthetic.MSRVTT_MODALITIES, batch=16, max_tokens=30,
+                       vb=dict(hidden=1024, layers=6, heads=8, inter=6144, max_pos=32), seed=17),
 }
 
 

@@ -37,7 +37,7 @@ def _cos(a, b):
   return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize('name', ['tiny', 'configA', 'configB', 'config4', 'config4b32', 'config5'])
+@pytest.mark.parametrize('name', ['tiny', 'configA', 'configB', 'config4', 'config4b32', 'config5', 'config5b16'])
 @pytest.mark.parametrize('pack', [False, True])
 def test_cenet_matches_reference(name, pack):
   from mmt_amd.loss import MaxMarginRankingLoss
