@@ -220,6 +220,10 @@ def main():
   ap.add_argument('--no-dense', action='store_true', help='skip the second (unpacked) timing of the same step')
   ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default='fp32',
                   help='wire format of the gradient all-reduces at N > 1 (bf16: half the bytes over xGMI)')
+  ap.add_argument('--fork', type=int, default=None,
+                  help='bit mask of the work that leaves the main stream for a parallel branch of the step graph '
+                       '(mmt_amd.train_step.FORK_*: 1 weight gradients, 2 ... in two early launches, 4 LN/table reductions, '
+                       '16 per-region Adam, 32 text heads, 64 ReduceDim weight gradients); 0 = one serial chain; default: all but 2')
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
@@ -289,7 +293,7 @@ def main():
     runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
-                              capture_collectives=args.capture_collectives)
+                              capture_collectives=args.capture_collectives, fork=args.fork)
     it, first = 0, None
     if args.host_inputs:
       # double-buffered upload: minibatch i+1 crosses PCIe on a copy stream while step i computes

@@ -312,7 +312,9 @@ int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float
                         float beta2, float eps, float weight_decay, int32_t* step_dev, const float* lr_dev,
                         int bump_step, void* stream);
 /* bump_step = 0: step_dev[0] is this launch's step number t (bias correction), as mmt_adam_step.
- * bump_step = 1: step_dev is int32[2] = {steps taken so far, 0}; the launch is step step_dev[0] + 1 and stores it. */
+ * bump_step = 1: step_dev is int32[2] = {steps taken so far, 0}; the launch is step step_dev[0] + 1 and stores it.
+ * bump_step = 2: the launch is step step_dev[0] + 1 as well but leaves the count alone: one optimizer step issued as
+ *   several launches over sub-ranges of the segment table (each as soon as its gradients are final), the last with 1. */
 
 /* ---- video tokens (assemble.hip) -------------------------------------------------------------------
  * model.py:426-437 (ReduceDim per expert) + :485-567 (token assembly), see assemble.hip.
@@ -510,8 +512,29 @@ typedef struct MmtBertBatch {
    * out_last[i] = sequence_output[out_rows[i]] for i < batch * n_out_per_sample; `dlast` is read the same way.  The
    * compact mode is taken iff batch * n_out_per_sample <= mmt_bert_tail_capacity(rows_alloc).  NULL = every row. */
   const int32_t* out_rows;
-  int32_t n_out_per_sample, reserved;
+  int32_t n_out_per_sample;
+  /* MMT_FORK_* bits: which launches of the BACKWARD leave `stream` for `side_stream` (they are off the critical
+   * path of the step: nothing on `stream` reads what they write until the optimizer does).  0 = everything on `stream`. */
+  int32_t fork;
+  /* second hipStream_t of the caller (nullable = no forking).  The engine orders the two streams with events
+   * (mmt_stream_fork), which become graph edges under stream capture: the forked kernels then sit on a parallel branch
+   * of the captured step.  Without MMT_FORK_JOIN the work on `side_stream` is still pending when the call returns: the
+   * caller joins (mmt_stream_fork(side_stream, stream)) before anything on `stream` consumes a parameter gradient. */
+  void* side_stream;
 } MmtBertBatch;
+
+enum {
+  MMT_FORK_WGRAD = 1,   /* the grouped weight-gradient launch of every layer (trainer/trainer.py:203: autograd's
+                         * mm-backward nodes for the weights, which nothing in the remaining backward depends on)  */
+  MMT_FORK_EARLY = 2,   /* ... cut in two launches issued as soon as their operands exist (FFN pair after the
+                         * dGELU GEMM, attention pair after the attention backward)                               */
+  MMT_FORK_REDUCE = 4,  /* LayerNorm gamma/beta and embedding-table reductions                                    */
+  MMT_FORK_JOIN = 8     /* `stream` waits for `side_stream` before mmt_bert_backward_range returns                */
+};
+
+/* `to` waits for everything enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent on an event of an internal
+ * ring).  Under stream capture this is the fork (main -> side) resp. join (side -> main) edge of the captured graph. */
+int mmt_stream_fork(void* from, void* to);
 
 int64_t mmt_bert_workspace_bytes(const MmtBertModel* m, int rows_alloc);
 int mmt_bert_tail_capacity(int rows_alloc);

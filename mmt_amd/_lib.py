@@ -84,7 +84,11 @@ class MmtBertBatch(ctypes.Structure):
   _fields_ = ([(n, c_vp) for n in ('features', 'type_ids', 'pos_ids', 'mask_bias', 'cu_seqlens', 'row_index',
                                    'n_rows_dev', 'seed_dev')] +
               [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')] +
-              [('out_rows', c_vp), ('n_out_per_sample', ctypes.c_int32), ('reserved', ctypes.c_int32)])
+              [('out_rows', c_vp), ('n_out_per_sample', ctypes.c_int32), ('fork', ctypes.c_int32),
+               ('side_stream', c_vp)])
+
+
+FORK_WGRAD, FORK_EARLY, FORK_REDUCE, FORK_JOIN = 1, 2, 4, 8
 
 
 _PTR16 = c_vp * 16
@@ -207,6 +211,7 @@ SIGNATURES = {
                                   c_vp]),
     'mmt_bert_backward_range': (c_int, [ctypes.POINTER(MmtBertModel), ctypes.POINTER(MmtBertBatch), c_vp, c_vp, c_vp,
                                         c_int, c_int, c_int, c_vp]),
+    'mmt_stream_fork': (c_int, [c_vp, c_vp]),
     'mmt_sgemm_batched': (c_int, [ctypes.POINTER(MmtSgemm), c_vp]),
     'mmt_text_heads_workspace_floats': (c_i64, [c_int, c_int, c_int]),
     'mmt_text_heads_fast': (c_int, [c_int, c_int, c_int, c_int]),

@@ -122,6 +122,9 @@ class EngineBatch:
     # is then evaluated on those rows only and the other rows of the returned tensor are undefined
     self.out_rows, self.n_out_per_sample = out_rows, n_out_per_sample
     self.save = False
+    # backward only (MmtBertBatch.fork / side_stream): a second stream (torch.cuda.Stream) for the launches that are
+    # off the critical path of the step, and the _lib.FORK_* bits that say which
+    self.side_stream, self.fork = None, 0
 
 
 class _BertFn(torch.autograd.Function):
@@ -295,6 +298,8 @@ class BertModel(nn.Module):
     b.rows, b.rows_alloc, b.batch, b.seq = batch.rows, rows_alloc, batch.batch, batch.seq
     if batch.out_rows is not None and batch.n_out_per_sample > 0:
       b.out_rows, b.n_out_per_sample = batch.out_rows.data_ptr(), batch.n_out_per_sample
+    if batch.side_stream is not None and batch.fork:
+      b.side_stream, b.fork = batch.side_stream.cuda_stream, int(batch.fork)
     return b
 
   def _workspace(self, rows_alloc, save, model_struct):
@@ -354,15 +359,15 @@ class BertModel(nn.Module):
     else:
       dlast = dout.contiguous().clone()  # the engine uses it as scratch
     dfeat = torch.empty_like(dlast)
-    b = self._batch_struct(batch, rows_alloc)
     L = _lib.lib()
 
     def run(l_hi, l_lo):
+      b = self._batch_struct(batch, rows_alloc)  # (per call: the caller may change batch.fork between ranges)
       check(L.mmt_bert_backward_range(ctypes.byref(m), ctypes.byref(b), ws.data_ptr(), dlast.data_ptr(),
                                       dfeat.data_ptr(), int(training), int(l_hi), int(l_lo), ops._stream()),
             'mmt_bert_backward_range')
 
-    run.dfeat, run.keep = dfeat, (dlast, ws, m, b)
+    run.dfeat, run.keep = dfeat, (dlast, ws, m)
     return run
 
   def run_engine(self, batch, features):

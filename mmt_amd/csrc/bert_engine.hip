@@ -2,6 +2,7 @@
 // No device code here; everything is asynchronous launches on the caller's stream (graph-capturable).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/mmt_hip.h"
 
 namespace {
@@ -33,7 +34,9 @@ struct Ws {
   char* h16_in;
   LayerWs layer[64];
   float *dz, *dA, *delta, *ln_partials[2 * 64 + 1], *table_scratch[2];
-  char *dy, *dy2, *dhpre, *dctx, *dqkv;
+  // dy / dy2 / dhpre / dqkv are what the weight gradients of a layer read: two sets, used by even / odd layers, so that
+  // the weight gradients of layer l may still be running (MMT_FORK_WGRAD) while layer l-1 produces its own
+  char *dy_[2], *dy2_[2], *dhpre_[2], *dqkv_[2], *dctx;
   size_t bytes;
 };
 
@@ -55,7 +58,10 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     L.h32 = (float*)take(R * d * 4); L.h16 = take(R * d * 2);
   }
   w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
-  w->dy = take(R * d * 2); w->dy2 = take(R * d * 2); w->dhpre = take(R * I * 2); w->dctx = take(R * d * 2); w->dqkv = take(R * 3 * d * 2);
+  for (int p = 0; p < 2; ++p) {
+    w->dy_[p] = take(R * d * 2); w->dy2_[p] = take(R * d * 2); w->dhpre_[p] = take(R * I * 2); w->dqkv_[p] = take(R * 3 * d * 2);
+  }
+  w->dctx = take(R * d * 2);
   w->delta = (float*)take(R * H * 4);
   size_t ln_nb = ((size_t)R + 15) / 16;  // blocks of mmt_ln_bwd: rows/16, or rows/4 when rows <= 2048
   const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
@@ -118,6 +124,24 @@ int tail_rows(const MmtBertBatch* b, const Ws& w) {
   if (!b->out_rows || b->n_out_per_sample <= 0) return 0;
   const long n = (long)b->batch * b->n_out_per_sample;
   return (n > 0 && n <= w.t.cap) ? (int)n : 0;
+}
+
+// ---- forked launches (MmtBertBatch.fork) ----
+// "weight gradients of layer l have been issued" events, one per layer parity and workspace: layer l-2 overwrites the
+// buffers layer l's weight gradients read, so `stream` waits for that event first.
+struct DoneEvents { const void* ws; hipEvent_t ev[2]; };
+DoneEvents g_done[16];
+int g_done_n = 0;
+std::mutex g_done_mu;
+hipEvent_t* done_events(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_done_mu);
+  for (int i = 0; i < g_done_n; ++i)
+    if (g_done[i].ws == ws) return g_done[i].ev;
+  DoneEvents& e = g_done[g_done_n < 16 ? g_done_n++ : 15];  // (more than 16 live workspaces: the last slot is recycled)
+  e.ws = ws;
+  for (int p = 0; p < 2; ++p)
+    if (!e.ev[p] && hipEventCreateWithFlags(&e.ev[p], hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e.ev;
 }
 
 }  // namespace
@@ -239,6 +263,10 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
 // Layers l_hi .. l_lo (descending); the embedding stage runs with layer 0.  A full backward is (layers-1, 0); a caller
 // that wants to start reducing a layer's gradients over ranks while the next layers still run calls it range by range
 // (the buffers that carry the running gradient between calls are determined by the layer index alone).
+//
+// b->fork / b->side_stream: the launches nothing in the remaining backward depends on -- weight gradients, LayerNorm /
+// table reductions -- go to the caller's second stream, ordered by events (graph edges under capture), and run under the
+// input-gradient chain of the layers below.
 extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
                                        float* dfeatures, int training, int l_hi, int l_lo, void* stream) {
   TRY(check_model(m, b));
@@ -253,6 +281,15 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   const int ln_blocks = (rows + rpb - 1) / rpb;
   const int32_t* nr = b->n_rows_dev;
 
+  void* side = (b->side_stream && b->side_stream != stream) ? b->side_stream : nullptr;
+  const int fork = side ? b->fork : 0;
+  const bool fork_w = fork & MMT_FORK_WGRAD, fork_early = fork_w && (fork & MMT_FORK_EARLY);
+  const bool fork_r = fork & MMT_FORK_REDUCE, join = fork & MMT_FORK_JOIN;
+  void* wstream = fork_w ? side : stream;   // weight gradients
+  void* rstream = fork_r ? side : stream;   // LayerNorm / table reductions
+  hipEvent_t* done = fork_w ? done_events(ws) : nullptr;
+  if (fork_w && !done) return MMT_ERR_ARG;
+
   // LayerNorm gamma/beta and embedding-table partial sums stay in per-site buffers; ONE batched reduction at the end
   MmtColReduceJob jobs[2 * 64 + 5];
   int njobs = 0;
@@ -261,6 +298,14 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     j = {};
     j.partials = partials; j.nblocks = nblocks; j.nvec = nvec; j.nout = nout; j.d = dd; j.out[0] = o0; j.out[1] = o1;
   };
+  auto finish = [&]() -> int {  // batched reduction (+ join) at the end of the range
+    if (njobs) {
+      if (fork_r) TRY(mmt_stream_fork(stream, side));
+      TRY(mmt_col_reduce_multi(jobs, njobs, rstream));
+    }
+    if (join) TRY(mmt_stream_fork(side, stream));
+    return 0;
+  };
   const int nc = tail_rows(b, w);
   // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
   float* dcur = ((m->layers - 1 - l_hi) & 1) ? w.dA : dlast;
@@ -268,6 +313,13 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
+    const int par = l & 1;
+    char *dy = w.dy_[par], *dy2 = w.dy2_[par], *dhpre = w.dhpre_[par], *dqkv = w.dqkv_[par];
+    // the weight gradients of layer l + 2 read the buffers this layer is about to overwrite (only an issue when they
+    // were forked and not joined since: with MMT_FORK_JOIN every range call ends with the side stream drained)
+    if (fork_w && !join && l + 2 <= m->layers - 1) {
+      if (hipStreamWaitEvent((hipStream_t)stream, done[par], 0) != hipSuccess) return MMT_ERR_ARG;
+    }
     if (nc && l == m->layers - 1) {
       // ---- last layer on the nc read-out rows only (mirror of the forward tail) ----
       TailWs& t = w.t;
@@ -296,16 +348,13 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       // dQ exists for the read-out rows only (the dq kernel zero-fills the rest of the Q section); the residual
       // gradient t.dz likewise: the input-gradient GEMM runs without residual and t.dz is scatter-added afterwards
       TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
-                            w.dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
+                            dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
                             b->seed_dev, b->row_index, stream));
-      e = {};
-      float* dnext = w.dA;
-      TRY(gemm_hidden(w, rows, d, w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
-      TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, dnext, 1, stream));
+      if (fork_w) TRY(mmt_stream_fork(stream, side));  // every operand of the layer's weight gradients exists now
       {
         MmtWgradGroup g = {};
         g.count = 4; g.rows = rows; g.n_rows_dev = nr;
-        g.item[0].A = w.dqkv;  g.item[0].lda = 3 * d; g.item[0].B = hin16; g.item[0].ldb = d; g.item[0].N = 3 * d; g.item[0].K2 = d;
+        g.item[0].A = dqkv;    g.item[0].lda = 3 * d; g.item[0].B = hin16; g.item[0].ldb = d; g.item[0].N = 3 * d; g.item[0].K2 = d;
         g.item[0].out = P.g_wqkv; g.item[0].bias_out = P.g_bqkv;
         g.item[0].splits = TAIL_WSPLIT; g.item[0].slab = t.wslab; g.item[0].bias_slab = t.bslab;
         g.item[1].A = t.dhpre; g.item[1].lda = I;     g.item[1].B = t.a16; g.item[1].ldb = d; g.item[1].N = I;     g.item[1].K2 = d;
@@ -314,74 +363,103 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         g.item[2].out = P.g_w2;   g.item[2].bias_out = P.g_b2; g.item[2].reserved = nc;
         g.item[3].A = t.dy;    g.item[3].lda = d;     g.item[3].B = t.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
         g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo; g.item[3].reserved = nc;
-        TRY(mmt_wgrad_grouped(&g, stream));
-        TRY(mmt_reduce_slabs_pair(t.wslab, (int64_t)3 * d * d, P.g_wqkv, t.bslab, (int64_t)3 * d, P.g_bqkv, TAIL_WSPLIT, stream));
+        TRY(mmt_wgrad_grouped(&g, wstream));
+        TRY(mmt_reduce_slabs_pair(t.wslab, (int64_t)3 * d * d, P.g_wqkv, t.bslab, (int64_t)3 * d, P.g_bqkv, TAIL_WSPLIT, wstream));
+        if (fork_w && hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG;
       }
+      e = {};
+      float* dnext = w.dA;
+      TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
+      TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, dnext, 1, stream));
       dcur = dnext;
       continue;
     }
+    MmtWgradGroup gffn = {}, gatt = {};  // FFN pair (dW1, dW2) and attention pair (dWqkv, dWo) of the layer
+    gffn.count = 2; gffn.rows = rows; gffn.n_rows_dev = nr;
+    gffn.item[0].A = dhpre; gffn.item[0].lda = I;     gffn.item[0].B = L.a16; gffn.item[0].ldb = d; gffn.item[0].N = I;     gffn.item[0].K2 = d;
+    gffn.item[0].out = P.g_w1;   gffn.item[0].bias_out = P.g_b1;
+    gffn.item[1].A = dy2;   gffn.item[1].lda = d;     gffn.item[1].B = L.g;   gffn.item[1].ldb = I; gffn.item[1].N = d;     gffn.item[1].K2 = I;
+    gffn.item[1].out = P.g_w2;   gffn.item[1].bias_out = P.g_b2;
+    gatt.count = 2; gatt.rows = rows; gatt.n_rows_dev = nr;
+    gatt.item[0].A = dqkv;  gatt.item[0].lda = 3 * d; gatt.item[0].B = hin16; gatt.item[0].ldb = d; gatt.item[0].N = 3 * d; gatt.item[0].K2 = d;
+    gatt.item[0].out = P.g_wqkv; gatt.item[0].bias_out = P.g_bqkv;
+    gatt.item[1].A = dy;    gatt.item[1].lda = d;     gatt.item[1].B = L.ctx; gatt.item[1].ldb = d; gatt.item[1].N = d;     gatt.item[1].K2 = d;
+    gatt.item[1].out = P.g_wo;   gatt.item[1].bias_out = P.g_bo;
     // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
-    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, w.dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
+    TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
     add_job(w.ln_partials[2 * l + 2], ln_blocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
     MmtEpilogue e = {};
     e.aux = L.hpre; e.ldaux = I;
-    TRY(mmt_gemm_nt_bf16(w.dy2, d, P.w2_t, d, w.dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
+    TRY(mmt_gemm_nt_bf16(dy2, d, P.w2_t, d, dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
+    if (fork_early) {  // dW1 / dW2 need nothing else: they start under the rest of this layer's input-gradient chain
+      TRY(mmt_stream_fork(stream, side));
+      TRY(mmt_wgrad_grouped(&gffn, side));
+    }
     // --- BertIntermediate: dense(d->I) ---
     e = {};
     e.res = w.dz; e.ldres = d;
-    TRY(gemm_hidden(w, rows, d, w.dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
+    TRY(gemm_hidden(w, rows, d, dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
-    TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, w.dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
+    TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
     add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
     e = {};
-    TRY(mmt_gemm_nt_bf16(w.dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
+    TRY(mmt_gemm_nt_bf16(dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
-    TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, w.dqkv, w.delta, b->batch, b->seq,
+    TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, b->batch, b->seq,
                      m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    if (fork_w) {
+      // --- weight + bias gradients on the side stream, under the input-gradient GEMM below and the layers that follow ---
+      TRY(mmt_stream_fork(stream, side));
+      if (fork_early) {
+        TRY(mmt_wgrad_grouped(&gatt, side));
+      } else {
+        MmtWgradGroup g = gffn;
+        g.count = 4; g.item[2] = gatt.item[0]; g.item[3] = gatt.item[1];
+        ProbeScope probe(2, l == 0, side);
+        TRY(mmt_wgrad_grouped(&g, side));
+      }
+      if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG;
+    }
     e = {};
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.
-    TRY(gemm_hidden(w, rows, d, w.dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
+    TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- all four weight gradients + bias gradients of the layer: ONE grouped launch (256 tiles at d=512, I=3072) ---
-    {
-      MmtWgradGroup g = {};
-      g.count = 4; g.rows = rows; g.n_rows_dev = nr;
-      g.item[0].A = w.dhpre; g.item[0].lda = I;     g.item[0].B = L.a16; g.item[0].ldb = d; g.item[0].N = I;     g.item[0].K2 = d;
-      g.item[0].out = P.g_w1;   g.item[0].bias_out = P.g_b1;
-      g.item[1].A = w.dy2;   g.item[1].lda = d;     g.item[1].B = L.g;   g.item[1].ldb = I; g.item[1].N = d;     g.item[1].K2 = I;
-      g.item[1].out = P.g_w2;   g.item[1].bias_out = P.g_b2;
-      g.item[2].A = w.dqkv;  g.item[2].lda = 3 * d; g.item[2].B = hin16; g.item[2].ldb = d; g.item[2].N = 3 * d; g.item[2].K2 = d;
-      g.item[2].out = P.g_wqkv; g.item[2].bias_out = P.g_bqkv;
-      g.item[3].A = w.dy;    g.item[3].lda = d;     g.item[3].B = L.ctx; g.item[3].ldb = d; g.item[3].N = d;     g.item[3].K2 = d;
-      g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo;
+    if (!fork_w) {
+      MmtWgradGroup g = gffn;
+      g.count = 4; g.item[2] = gatt.item[0]; g.item[3] = gatt.item[1];
       ProbeScope probe(2, l == 0, stream);
       TRY(mmt_wgrad_grouped(&g, stream));
     }
     dcur = dnext;
   }
-  if (l_lo > 0) return njobs ? mmt_col_reduce_multi(jobs, njobs, stream) : 0;
+  if (l_lo > 0) return finish();
   // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---
   TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials[0], rows, d, 2, nr,
                  b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
   add_job(w.ln_partials[0], ln_blocks, 3, 2, d, m->g_emb_ln_g, m->g_emb_ln_b);
+  if (fork_r) TRY(mmt_stream_fork(stream, side));
   const int chunks = mmt_table_grad_chunks();
   const bool pos_partials = b->pos_ids && m->max_pos <= 64;
   // token-type table (+ the temporal-position table when it is small) as one-hot MFMA products, ONE launch for both
   if (m->type_vocab <= 64) {
     TRY(mmt_table_grad_partials_pair(dfeatures, b->type_ids, m->type_vocab, w.table_scratch[0],
-                                     pos_partials ? b->pos_ids : nullptr, m->max_pos, w.table_scratch[1], rows, d, nr, stream));
+                                     pos_partials ? b->pos_ids : nullptr, m->max_pos, w.table_scratch[1], rows, d, nr, rstream));
   } else {  // large token-type vocabularies: the scan kernel
-    TRY(mmt_table_grad_partials(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch[0], stream));
-    if (pos_partials) TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], stream));
+    TRY(mmt_table_grad_partials(dfeatures, b->type_ids, rows, d, m->type_vocab, nr, w.table_scratch[0], rstream));
+    if (pos_partials) TRY(mmt_table_grad_partials(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, w.table_scratch[1], rstream));
   }
   add_job(w.table_scratch[0], chunks, 1, 1, m->type_vocab * d, m->g_type_emb, nullptr);
   if (pos_partials) add_job(w.table_scratch[1], chunks, 1, 1, m->max_pos * d, m->g_pos_emb, nullptr);
   else if (b->pos_ids)  // BERT-base position table (512 rows, a few dozen in use): no vocab-sized partial sums
-    TRY(mmt_table_grad_direct(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, m->g_pos_emb, stream));
-  return mmt_col_reduce_multi(jobs, njobs, stream);
+    TRY(mmt_table_grad_direct(dfeatures, b->pos_ids, rows, d, m->max_pos, nr, m->g_pos_emb, rstream));
+  // (the fork for the reductions happened above: `rstream` already sees the LayerNorm partials of this range)
+  TRY(mmt_col_reduce_multi(jobs, njobs, rstream));
+  if (join) TRY(mmt_stream_fork(side, stream));
+  return 0;
 }
 
 extern "C" int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,

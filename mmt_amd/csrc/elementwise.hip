@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
         s[0] = t;
       }
     }
-  } bump{step_dev, t_int, bump_step};
+  } bump{step_dev, t_int, bump_step == 1};  // bump_step == 2: this launch is step count + 1 too, but a later launch of
+                                           // the same step stores the new count (per-region launches, FlatAdam.step_span)
   const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   int s = 0;

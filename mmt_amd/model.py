@@ -193,6 +193,7 @@ class _TextHeadsFn(torch.autograd.Function):
     ctx.net, ctx.caps, ctx.generation, ctx.training = net, caps, net._th_generation, net.training
     ctx.need_dtext = text.requires_grad
     ctx.need_dmoe = text_moe is not None and text_moe.requires_grad
+    net._th_needs_input_grad = ctx.need_dtext or ctx.need_dmoe  # (train_step: may the backward bypass autograd?)
     return out
 
   @staticmethod
@@ -514,7 +515,9 @@ class CENet(nn.Module):
                               ctypes.byref(plan.src), ops._p(feats), stream), 'mmt_video_scatter')
     return feats
 
-  def _video_tokens_backward(self, plan, dfeat):
+  def _video_tokens_backward(self, plan, dfeat, side_stream=None):
+    """side_stream: the ReduceDim weight gradients (the last kernel of the backward; only the optimizer reads them) go
+    there, ordered after the scatter; the caller joins."""
     L, m, d = _lib.lib(), len(self.modalities), self.same_dim
     stream = ops._stream()
     check(L.mmt_video_scatter_bwd(plan.io, m, plan.batch, plan.tokens, d, ops._p(plan.n_rows), ops._p(plan.row_index),
@@ -526,7 +529,12 @@ class CENet(nn.Module):
       gw, gb = self._flat.view(fc.weight, grad_buf), self._flat.view(fc.bias, grad_buf)
       items.append((plan.dy[mod], plan.xin[mod], gw, gb))
       grads += [gw if fc.weight.requires_grad else None, gb if fc.bias.requires_grad else None]
-    ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
+    if side_stream is not None:
+      side_stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side_stream):
+        ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
+    else:
+      ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
     return grads
 
   def video_embeddings(self, features, features_t, features_ind, features_maxpool):

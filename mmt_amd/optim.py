@@ -161,6 +161,35 @@ class FlatAdam:
                                    ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()), 'mmt_adam_step')
     f._dirty = True  # the bf16 shadows are stale now (the kernel wrote through raw pointers)
 
+  @torch.no_grad()
+  def step_span(self, offset, count, bump):
+    """The fused step over ONE contiguous span of the flat buffer (a `CENet.grad_regions` entry) on the current stream:
+    a data-dependence-ordered optimizer -- the span's update runs as soon as its gradients are final, on a side stream
+    under the rest of the backward (train_step.GraphedTrainStep, fork mode).  Every span of a step reads the same step
+    count; `bump` (the LAST span's launch) advances it.  The spans of one step must tile [0, flat.count)."""
+    import ctypes
+
+    from ._lib import MmtAdamSeg
+    f = self.flat
+    self._ensure_state()
+    table = self._segment_table() if self.fuse_shadows else None
+    if table is None:
+      raise RuntimeError('FlatAdam.step_span needs the fused kernel (bf16 shadows allocated: run a forward first)')
+    host, dev, n = table
+    idx = [i for i in range(n) if offset <= host[i].offset < offset + count]
+    if not idx or idx != list(range(idx[0], idx[-1] + 1)) or host[idx[0]].offset != offset or \
+        host[idx[-1]].offset + host[idx[-1]].count != offset + count:
+      raise ValueError('FlatAdam.step_span: [%d, %d) does not start and end on segment boundaries' % (offset, offset + count))
+    size = ctypes.sizeof(MmtAdamSeg)
+    sub = ctypes.cast(ctypes.byref(host, idx[0] * size), ctypes.POINTER(MmtAdamSeg))
+    check(_lib.lib().mmt_adam_step_fused(ops._p(f.master), ops._p(f.current_grad()), ops._p(self.exp_avg),
+                                         ops._p(self.exp_avg_sq), sub, ctypes.c_void_p(dev.data_ptr() + idx[0] * size),
+                                         len(idx), float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                         ops._p(self._step_store), ops._p(self.lr_dev), 1 if bump else 2, ops._stream()),
+          'mmt_adam_step_fused')
+    if bump:
+      f.shadows_fresh()
+
   fuse_shadows = True
   _seg_key = _seg_table = None
 

@@ -26,13 +26,26 @@ RCCL's stream while the next stage's graph runs:
 The stages call the engine's range backward (mmt_bert_backward_range) directly instead of through autograd, so each
 stage is a plain kernel sequence that captures into its own graph; the collectives stay eager.
 
+Fork mode (`fork`, default on): the captured step is not one serial chain of kernels.  Work that nothing on the critical
+path waits for leaves the main stream for a second one, ordered by events that become EDGES of the captured graph:
+
+    main: forward ............ loss | layer L-1 dgrad chain | layer L-2 dgrad chain | ... | layer 0 | embeddings, tokens |
+    side: text heads fwd |            text heads bwd, dW(L-1), Adam(top) | dW(L-2), Adam(L-2) | ... | dW(0), dW(ReduceDim), Adam(bottom)
+
+The weight gradients of a layer only feed the optimizer, so they run under the input-gradient chain of the layers below
+(mmt_bert_backward_range, MmtBertBatch.fork); the optimizer runs region by region (`FlatAdam.step_span`) as soon as a
+region's gradients are final -- HBM-bound work under MFMA-bound work; the text heads run beside the video tower.
+
 Everything data-dependent lives in device memory (live row count of the token packing, dropout seed,
 Adam step counter), so replays are correct for new minibatches copied into the static input buffers.
 """
 import torch
 import torch.distributed as dist
 
+import os
+
 from . import dist as mdist
+from . import _lib
 from .feature_store import RaggedFeatures
 from .model import cross_view_similarity
 from .optim import FlatAdam
@@ -89,10 +102,18 @@ def _copy_tree(dst, src):
       dst[k].copy_from(v)
 
 
+# GraphedTrainStep(fork=...) bits: 1 | 2 | 4 are the engine's _lib.FORK_WGRAD / FORK_EARLY / FORK_REDUCE
+FORK_WGRAD, FORK_EARLY, FORK_REDUCE = _lib.FORK_WGRAD, _lib.FORK_EARLY, _lib.FORK_REDUCE
+FORK_ADAM = 16    # optimizer region by region on the side stream
+FORK_TEXT = 32    # text heads (forward and backward) on the side stream
+FORK_TOKENS = 64  # ReduceDim weight gradients on the side stream
+FORK_DEFAULT = FORK_WGRAD | FORK_REDUCE | FORK_ADAM | FORK_TEXT | FORK_TOKENS
+
+
 class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
-               overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False):
+               overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -101,6 +122,12 @@ class GraphedTrainStep:
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
+    if fork is None:
+      fork = int(os.environ.get('MMT_FORK', FORK_DEFAULT))
+    self.fork = int(fork)
+    self._side = None
+    self._fork_on = False  # decided after the first warm-up step (needs the model's stage handles)
+    self._keep = []
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
     # measurement hook: issue the collectives even at world size 1 (a 1-rank RCCL group) to see what their stream
@@ -145,8 +172,17 @@ class GraphedTrainStep:
       snap = self._snapshot() if warmup_steps > 0 else None
       for i in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
         self._eager_step()
-        if i == 0 and self._want_stages:
-          self.staged = self._stageable([p for p in rest if p.grad is not None])  # e.g. the unused pooler: no grad
+        if i == 0 and (self._want_stages or self.fork):
+          ok = self._stageable([p for p in rest if p.grad is not None])  # e.g. the unused pooler: no grad
+          self.staged = ok and self._want_stages
+          if not ok or len(flats) > 1 or not hasattr(model, '_text_heads_backward'):
+            self.fork = 0  # fork mode drives the backward stage by stage, like the staged reduction
+          if self.fork:
+            self._side = torch.cuda.Stream()
+            if self.fork & FORK_TEXT:
+              model.overlap_text_heads = True
+              model._side_streams[next(model.parameters()).device] = self._side
+            self._fork_on = True
       if snap is not None:
         self._restore(snap)
     torch.cuda.current_stream().wait_stream(self._stream)
@@ -357,17 +393,25 @@ class GraphedTrainStep:
       pairs = list(zip(outs, grads))
       h = model._stages
       txt = [(o, gr) for o, gr in pairs if o is not e['vid_embds'] and o is not h['last']]
-      if txt:
+      if txt and not self._text_heads_backward_forked(e, txt):
         torch.autograd.backward([o for o, _ in txt], [gr for _, gr in txt])  # text heads
       dlast = next((gr for o, gr in pairs if o is h['last']), None)  # the fused kernel already ran the read-out backward
       if dlast is None:
         gvid = next(gr for o, gr in pairs if o is e['vid_embds'])
         dlast, = torch.autograd.grad([e['vid_embds']], [h['last']], [gvid])  # read-out backward only
+      if self._fork_on:
+        # weight gradients / reductions of the encoder leave the main stream (MmtBertBatch.fork); between separately
+        # captured stage graphs (multi-rank) every range call joins before it returns
+        h['batch'].side_stream = self._side
+        h['batch'].fork = (self.fork & (FORK_WGRAD | FORK_EARLY | FORK_REDUCE)) | (_lib.FORK_JOIN if self._multi else 0)
       st['run'] = vb.backward_ranges(h['batch'], dlast, vb.training)
 
     def bottom():
       st['run'](0, 0)
-      model._video_tokens_backward(model._stages['plan'], st['run'].dfeat)
+      side = self._side if (self._fork_on and self.fork & FORK_TOKENS) else None
+      model._video_tokens_backward(model._stages['plan'], st['run'].dfeat, side_stream=side)
+      if side is not None and self._multi:
+        self._join()
 
     n_layers = vb.config.num_hidden_layers
 
@@ -382,6 +426,45 @@ class GraphedTrainStep:
       stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
     stages.append((bottom, ['bottom']))
     return stages
+
+  def _text_heads_backward_forked(self, e, txt):
+    """Fork mode: the text heads' backward (3 launches, latency-bound) on the side stream, called directly -- autograd
+    would run it on the stream of its forward too, but joins that stream into the caller's right after.  Only when
+    nothing upstream of the heads needs a gradient (a trainable text tower takes the autograd path).  -> done?"""
+    m = self.model
+    if not (self._fork_on and self.fork & FORK_TEXT) or self._multi:
+      return False
+    text = getattr(m, '_th_text', None)
+    fn = getattr(e['text_embds'], 'grad_fn', None)
+    if text is None or fn is None or any(t is not None and t.requires_grad for t in (text, m._th_text_moe)):
+      return False
+    if getattr(m, '_th_needs_input_grad', True):
+      return False
+    grads = {id(o): gr for o, gr in txt}
+    de, dtw = grads.get(id(e['text_embds'])), grads.get(id(e['text_weights']))
+    if de is None:
+      return False
+    cur = torch.cuda.current_stream()
+    self._side.wait_stream(cur)
+    self._keep += [de, dtw]  # allocated on `cur`, read on the side stream: alive until the step has joined
+    with torch.cuda.stream(self._side):
+      m._text_heads_backward(e['text_embds'].shape[2], de, dtw, False, False, m.training)
+    return True
+
+  def _join(self):
+    """main stream waits for the side stream (graph edge under capture)."""
+    if self._side is not None:
+      torch.cuda.current_stream().wait_stream(self._side)
+
+  def _adam_regions(self, names, last):
+    """Fork mode, one rank: the optimizer over the regions a stage has just finished, on the side stream -- after that
+    stage's forked weight gradients (same stream) and everything the main stream has issued so far."""
+    cur = torch.cuda.current_stream()
+    self._side.wait_stream(cur)
+    with torch.cuda.stream(self._side):
+      for i, n in enumerate(names):
+        flat, off, cnt = self._regions[n]
+        self.opt_flat.step_span(off, cnt, bump=last and i == len(names) - 1)
 
   def _region_table(self):
     """name -> (flat, offset, count): the video flat's spans in backward order + every other flat as one span (the
@@ -436,7 +519,30 @@ class GraphedTrainStep:
           g['lr'] = lr
 
 
+  def _fork_step(self):
+    """One rank, fork mode: forward, then the backward stage by stage with the off-critical-path work on the side stream
+    and the optimizer region by region behind it (module docstring).  Captured as ONE graph with parallel branches."""
+    self._keep = []
+    self._zero()
+    e = self._forward()
+    g = self._gather(e)
+    self._regions = self._region_table()
+    stages = self._stage_list(e, g)
+    opt = self.opt_flat
+    if self.fork & FORK_ADAM:
+      opt._ensure_state()
+      opt.sync_lr()
+    for i, (fn, names) in enumerate(stages):
+      fn()
+      if self.fork & FORK_ADAM:
+        self._adam_regions(names, last=i == len(stages) - 1)
+    self._join()
+    if not self.fork & FORK_ADAM:
+      self._opt()
+
   def _eager_step(self):
+    if self._fork_on and not self._multi:
+      return self._fork_step()
     self._zero()
     e = self._forward()
     g = self._gather(e)
@@ -456,6 +562,13 @@ class GraphedTrainStep:
   def _capture(self):
     torch.cuda.synchronize()
     self._zero()
+    if not self._multi and self._fork_on:
+      ga = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(ga, stream=self._stream):
+        self._fork_step()  # ONE graph whose branches are the main and the side stream
+      self._graphs, self._e = (ga, None, None), None
+      torch.cuda.synchronize()
+      return
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     e = g = pool = None
     if self._multi or self.staged:

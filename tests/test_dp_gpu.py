@@ -53,7 +53,7 @@ def _slice_batch(mb, text, sl):
 
 
 def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, force_collectives=False,
-         capture_collectives=False, **build_kw):
+         capture_collectives=False, fork=None, **build_kw):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
@@ -66,7 +66,9 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
   model.txt_bert.text = static['text']
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
                             overlap_grad_sync=overlap, grad_dtype=grad_dtype, force_collectives=force_collectives,
-                            capture_collectives=capture_collectives)
+                            capture_collectives=capture_collectives, fork=fork)
+  if fork is not None:
+    assert runner._fork_on == bool(fork)
   assert runner.staged == ((world > 1 or force_collectives) if overlap is None else overlap)
   # the warm-up inside the constructor must not have trained: weights, BatchNorm statistics, Adam state as loaded
   now = model.state_dict()
@@ -124,6 +126,22 @@ def test_staged_backward_equals_single_graph_backward():
   assert a['losses'] == b['losses']
   assert torch.equal(a['grad'], b['grad'])
   assert torch.equal(a['master'], b['master'])
+
+
+@pytest.mark.parametrize('fork', [1, 1 | 4 | 16, 1 | 4 | 16 | 32 | 64, 1 | 2 | 4 | 16 | 32 | 64])
+def test_forked_step_graph_equals_the_serial_chain(fork):
+  """GraphedTrainStep(fork=...): weight gradients, reductions, text heads and the per-region optimizer on a parallel
+  branch of the captured step (events = graph edges) launch the same kernels on the same data as the one-stream step:
+  losses, the eager step's gradient buffer and the weights after the captured steps are bit-identical -- with BatchNorm
+  text heads, every dropout site on, 4 layers (the bench configuration's structure)."""
+  dev = torch.device('cuda', 0)
+  kw = dict(txt_pro='gbn', dropout=0.1, layers=4, steps=4)
+  a, b = _run(0, 1, dev, fork=0, **kw), _run(0, 1, dev, fork=fork, **kw)
+  assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
+  assert torch.equal(a['grad'], b['grad'])
+  assert torch.equal(a['master'], b['master'])
+  for k in a['buffers']:
+    assert torch.equal(a['buffers'][k], b['buffers'][k]), k
 
 
 def test_two_ranks_bench_configuration_stays_in_lock_step(tmp_path):

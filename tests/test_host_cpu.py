@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
   assert ctypes.sizeof(_lib.MmtPackItem) == 48
   assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
-  assert ctypes.sizeof(_lib.MmtBertBatch) == 96
+  assert ctypes.sizeof(_lib.MmtBertBatch) == 104  # + side_stream (r03)
 
 
 def test_product_path_refuses_cpu_tensors():
