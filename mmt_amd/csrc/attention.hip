@@ -264,19 +264,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, part 1: dQ (+ delta).  Same tiling as forward: grid (q tiles, H, B).
+// backward, dQ role (+ delta output).  Same tiling as forward: one block per (q tile, H, B).
 //   dA^T[key][q] = V . dO^T ; dS = P o (keep*dA*sc - delta) ; dQ^T[d][q] += K^T . dS^T
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2 + 2 * 64 * 2];
+__device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* smem, int bx) {
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);
   int* kpos_s = (int*)(bias_s + 2 * 64);
   const bool dense_keys = a.row_index == nullptr;
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = bx * 64;
   const int nqs = a.qsel ? a.nq : Sb;
   if (q0 >= nqs || Sb <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int qrow = a.qsel ? a.qsel[b * a.nq + qic] : off + qic;
   const int crow = a.qsel ? b * a.nq + qic : qrow;  // row in ctx / dctx / lse / delta
   const int q_local = orig_pos(a, b, off, qrow);
-  if (a.qsel && blockIdx.x == 0) {
+  if (a.qsel && bx == 0) {
     // query-subset mode: dQ of the non-selected rows is zero -- this block (sample b, head h) clears its 128 columns
     // of every row of the sample; the selected rows are overwritten at the end (after the K-loop's barriers)
     for (int e = tid; e < Sb * (DH / 8); e += 256) {
@@ -378,18 +377,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, part 2: dK, dV.  grid (key tiles of 64, H, B); each wave owns 16 keys, loops over q tiles.
+// backward, dK / dV role.  One block per (key tile of 64, H, B); each wave owns 16 keys, loops over q tiles.
 //   S[q][key] = Q . K^T (a = Q frag from LDS, b = K frag in registers) ; dA = dO . V^T
 //   dV^T[d][key] += dO^T . A ; dK^T[d][key] += Q^T . dS     (a = transpose reads of the dO / Q tiles)
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 3 * 64 * 2];
+__device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* smem, int bx) {
   float* aux_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][3][64]: lse2, delta, rowkey(bits)
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
-  const int k0 = blockIdx.x * 64;
+  const int k0 = bx * 64;
   if (k0 >= Sb) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int row_last = off + Sb - 1;
@@ -425,15 +423,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       stage64<DH>(Qg, a.ld, off + qt * 64, row_last, base, wave, lane);
       stage64<DH>(dOg, a.ldc, off + qt * 64, row_last, base + 64 * DH, wave, lane);
     }
-    if (tid < 64) {
-      const int q = qt * 64 + tid;
+    {
+      // delta = rowsum(dO * O) of this head is formed here (the dQ blocks of the same launch produce it too, but nothing
+      // orders the two roles): four neighbouring lanes per query row, each one 8-column group of every 32 (the dQ role's
+      // split), combined in its order ((g0 + g1) + (g2 + g3))
+      const int ql = tid >> 2, g = tid & 3;
+      const int q = qt * 64 + ql;
       const int qc = min(q, nqs - 1);
-      const int row = a.qsel ? b * a.nq + qc : off + qc;               // row in lse / delta
-      const int qpos = orig_pos(a, b, off, a.qsel ? a.qsel[b * a.nq + qc] : off + qc);  // original position (RNG coordinate)
+      const int row = a.qsel ? b * a.nq + qc : off + qc;               // row in lse / ctx / dctx
       float* ax = aux_s + st * 192;
-      ax[tid] = q < nqs ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
-      ax[64 + tid] = a.delta[(int64_t)row * a.H + h];
-      ax[128 + tid] = __uint_as_float(attn_rowkey(dkey, bh, (unsigned)a.S4, (unsigned)qpos));
+      const bf16_t* dop = a.dctx + (int64_t)row * a.ldc + h * DH + g * 8;
+      const bf16_t* op = a.ctx + (int64_t)row * a.ldc + h * DH + g * 8;
+      float part = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < DH / 32; ++kk) {
+        const u16x8 dv = *(const u16x8*)(dop + kk * 32);
+        const u16x8 ov = *(const u16x8*)(op + kk * 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += bf2f(dv[e]) * bf2f(ov[e]);
+      }
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      if (g == 0) {
+        const int qpos = orig_pos(a, b, off, a.qsel ? a.qsel[b * a.nq + qc] : off + qc);  // original position (RNG coordinate)
+        ax[ql] = q < nqs ? a.lse[(int64_t)row * a.H + h] * LOG2E : INFINITY;  // +inf => P = 0 for dead rows
+        ax[64 + ql] = part;
+        ax[128 + ql] = __uint_as_float(attn_rowkey(dkey, bh, (unsigned)a.S4, (unsigned)qpos));
+      }
     }
   };
   stage(0, 0);
@@ -492,6 +508,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   store_block16<DH>(smem + wave * 16 * (DH + 8), dv, 1.0f, lane, [&](int r) { return krow_ptr(r, 2); });
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, ONE launch: blocks [0, q_tiles) of grid.x take the dQ role, blocks [q_tiles, q_tiles + key_tiles) the dK/dV
+// role.  The two roles are independent (the dK/dV blocks form delta themselves), so the whole backward of a layer's
+// attention is one node of the step graph and its two halves share the CUs instead of running back to back.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, int q_tiles) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 3 * 64 * 2];
+  if ((int)blockIdx.x < q_tiles) attn_bwd_dq_block<DH>(a, smem, (int)blockIdx.x);
+  else attn_bwd_dkv_block<DH>(a, smem, (int)blockIdx.x - q_tiles);
+}
+
 // test helper: materialise the attention dropout keep-mask, uint8 [B,H,S,S] (dense layout only)
 __global__ void attn_mask_export_kernel(uint8_t* out, int B, int H, int S, int S4, uint32_t key_in, uint32_t thr16,
                                         const uint32_t* seed_dev) {
@@ -538,14 +566,10 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.delta = delta; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
-  const dim3 grid((S + 63) / 64, H, B);
-  if (d == H * 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  }
+  const int tiles = (S + 63) / 64;
+  const dim3 grid(2 * tiles, H, B);
+  if (d == H * 128) hipLaunchKernelGGL(attn_bwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a, tiles);
+  else hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a, tiles);
   return (int)hipGetLastError();
 }
 
@@ -581,13 +605,9 @@ extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
-  if (d == H * 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  }
+  const int tq = (nq + 63) / 64, tk = (S + 63) / 64;
+  if (d == H * 128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(tq + tk, H, B), dim3(256), 0, (hipStream_t)stream, a, tq);
+  else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(tq + tk, H, B), dim3(256), 0, (hipStream_t)stream, a, tq);
   return (int)hipGetLastError();
 }
 

@@ -26,7 +26,8 @@ RCCL's stream while the next stage's graph runs:
 The stages call the engine's range backward (mmt_bert_backward_range) directly instead of through autograd, so each
 stage is a plain kernel sequence that captures into its own graph; the collectives stay eager.
 
-Fork mode (`fork`, default on): the captured step is not one serial chain of kernels.  Work that nothing on the critical
+Fork mode (`fork` bits, opt-in -- measured slower on this runtime, see FORK_DEFAULT): the captured step is not one serial
+chain of kernels.  Work that nothing on the critical
 path waits for leaves the main stream for a second one, ordered by events that become EDGES of the captured graph:
 
     main: forward ............ loss | layer L-1 dgrad chain | layer L-2 dgrad chain | ... | layer 0 | embeddings, tokens |
@@ -107,7 +108,12 @@ FORK_WGRAD, FORK_EARLY, FORK_REDUCE = _lib.FORK_WGRAD, _lib.FORK_EARLY, _lib.FOR
 FORK_ADAM = 16    # optimizer region by region on the side stream
 FORK_TEXT = 32    # text heads (forward and backward) on the side stream
 FORK_TOKENS = 64  # ReduceDim weight gradients on the side stream
-FORK_DEFAULT = FORK_WGRAD | FORK_REDUCE | FORK_ADAM | FORK_TEXT | FORK_TOKENS
+FORK_ALL = FORK_WGRAD | FORK_REDUCE | FORK_ADAM | FORK_TEXT | FORK_TOKENS
+# Measured on MI355X / ROCm 7.2 (profiles/r03_fork_lab.txt): every variant is SLOWER than the serial chain (1.465 ms ->
+# 1.51-1.59 ms).  The graph executor maps the branches to separate hardware queues; each cross-queue edge costs 5-15 us,
+# and kernels that do overlap slow each other down by as much as they overlap (a 16 us input-gradient GEMM takes 65-73 us
+# next to the 256-tile weight-gradient launch, which itself goes from 57 to 72-103 us).  So the default is one chain.
+FORK_DEFAULT = 0
 
 
 class GraphedTrainStep:
