@@ -194,6 +194,36 @@ def cpu_baseline(steps=6):
                      'Adam; torch CPU ops; 1 warm-up step)' % steps)
 
 
+def spawn_ranks(n):
+  """Launcher for `python bench.py --gpus N` without torch.distributed.run: N child processes of this same command line
+  with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment.  -> worst exit code."""
+  import socket
+  import subprocess
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC (RCCL across processes), see the task environment
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+  rc = 0
+  try:
+    while any(p.poll() is None for p in procs):
+      time.sleep(0.2)
+      if any(p.poll() not in (None, 0) for p in procs):
+        break  # a rank that died takes the others down instead of leaving them in a collective forever
+    rc = max(abs(p.poll() or 0) for p in procs)
+  finally:
+    for p in procs:
+      if p.poll() is None:
+        p.terminate()
+        rc = rc or 1
+  return rc
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -220,6 +250,9 @@ def main():
   ap.add_argument('--no-dense', action='store_true', help='skip the second (unpacked) timing of the same step')
   ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default='fp32',
                   help='wire format of the gradient all-reduces at N > 1 (bf16: half the bytes over xGMI)')
+  ap.add_argument('--grad-algo', choices=['allreduce', 'rs_ag'], default='allreduce',
+                  help='N > 1: every gradient span as one all-reduce (RCCL picks ring / tree) or as reduce-scatter + '
+                       'all-gather (the decomposition a direct full-mesh exchange over all xGMI links maps to)')
   ap.add_argument('--fork', type=int, default=None,
                   help='bit mask of the work that leaves the main stream for a parallel branch of the step graph '
                        '(mmt_amd.train_step.FORK_*: 1 weight gradients, 2 ... in two early launches, 4 LN/table reductions, '
@@ -232,11 +265,16 @@ def main():
       ap.error('--ragged-inputs carries live rows only: it cannot feed the dense (unpacked) step')
     args.no_dense = True
 
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    # bare `python bench.py --gpus N`: this process becomes the launcher -- N ranks of this same command, one per GPU,
+    # rendezvous on 127.0.0.1 (what `python -m torch.distributed.run --nproc-per-node N` would set up); rank 0 prints
+    # the ONE JSON line, the launcher only waits and forwards the worst exit code
+    raise SystemExit(spawn_ranks(args.gpus))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
   # Test hook (1-GPU boxes): MMT_BENCH_BACKEND=gloo runs every rank on cuda:0 with gloo moving the tensors, to exercise
   # the N > 1 control flow end to end where no second GPU exists.  The default is one GPU per rank over RCCL.
   backend = os.environ.get('MMT_BENCH_BACKEND', 'nccl')
@@ -293,7 +331,8 @@ def main():
     runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
-                              capture_collectives=args.capture_collectives, fork=args.fork)
+                              capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo)
+    runner.measure_exposed = world > 1 or args.force_collectives
     it, first = 0, None
     if args.host_inputs:
       # double-buffered upload: minibatch i+1 crosses PCIe on a copy stream while step i computes
@@ -327,11 +366,14 @@ def main():
       t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       elapsed = t.item()
-    return dict(model=model, runner=runner, elapsed=elapsed, first_loss=first, final_loss=float(loss.item()), it=it)
+    exposed = runner.exposed_collective_ms()
+    runner._exposed = []
+    return dict(model=model, runner=runner, elapsed=elapsed, first_loss=first, final_loss=float(loss.item()), it=it,
+                exposed_ms=exposed)
 
   main_run = timed_run(not args.dense, args.steps, args.warmup)
   model, runner, elapsed, it = main_run['model'], main_run['runner'], main_run['elapsed'], main_run['it']
-  main_first, main_final = main_run['first_loss'], main_run['final_loss']
+  main_first, main_final, exposed_ms = main_run['first_loss'], main_run['final_loss'], main_run['exposed_ms']
 
   # Kernel-family durations: HIP events around one launch per step of the three kernel families that lead the rocprof
   # time table, recorded by the engine on the launch stream in eager steps of the same workload right after the timed
@@ -391,7 +433,12 @@ def main():
                    'input_format': 'ragged bf16 wire buffer (live rows)' if args.ragged_inputs else 'dense fp32 dict',
                    'video_input_bytes_per_step': int(sum(input_bytes) / len(input_bytes)),
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
-                   'grad_wire_dtype': args.grad_dtype, 'collectives_captured': bool(args.capture_collectives and (world > 1 or args.force_collectives)),
+                   'grad_wire_dtype': args.grad_dtype, 'grad_algo': args.grad_algo,
+                   # mean ms per step between the end of the last backward stage and the last gradient reduction having
+                   # landed (HIP events on the compute stream): what the staged overlap did not hide; null at N = 1
+                   'exposed_collective_ms_rank0': exposed_ms,
+                   'comm_backend': (backend if world > 1 else None), 'comm_log': bool(args.comm_log),
+                   'collectives_captured': bool(args.capture_collectives and (world > 1 or args.force_collectives)),
                    'live_rows_rank0': live, 'dense_rows': dense_rows},
         # fraction of the (B, S) token grid that holds a real token in the synthetic batches (valid length ~ U{0..30}
         # per expert); the packed step computes only those, the dense step all of them.  The fill of real

@@ -529,7 +529,11 @@ enum {
   MMT_FORK_EARLY = 2,   /* ... cut in two launches issued as soon as their operands exist (FFN pair after the
                          * dGELU GEMM, attention pair after the attention backward)                               */
   MMT_FORK_REDUCE = 4,  /* LayerNorm gamma/beta and embedding-table reductions                                    */
-  MMT_FORK_JOIN = 8     /* `stream` waits for `side_stream` before mmt_bert_backward_range returns                */
+  MMT_FORK_JOIN = 8,    /* `stream` waits for `side_stream` before mmt_bert_backward_range returns                */
+  /* not a fork bit, same field: a range that ends at layer 0 stops BEFORE the embedding stage (layer 0's parameter
+   * gradients are final then: a data-parallel caller starts their reduction); the embedding stage follows as its own
+   * call with l_hi = l_lo = -1 */
+  MMT_RANGE_LAYERS_ONLY = 16
 };
 
 /* `to` waits for everything enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent on an event of an internal
@@ -550,7 +554,8 @@ int mmt_bert_backward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, fl
 /* The same backward, layers l_hi .. l_lo only (descending; the embedding stage runs with layer 0), so that a
  * data-parallel caller can start the all-reduce of a finished layer's gradients while the layers below still run
  * (the reference's DataParallel reduces after the whole backward, trainer/trainer.py:185-199).  Calls must cover
- * layers-1 .. 0 in descending order with the same dlast / dfeatures / ws. */
+ * layers-1 .. 0 in descending order with the same dlast / dfeatures / ws.  l_hi = l_lo = -1: the embedding stage alone
+ * (see MMT_RANGE_LAYERS_ONLY). */
 int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast, float* dfeatures,
                             int training, int l_hi, int l_lo, void* stream);
 

@@ -88,7 +88,7 @@ class MmtBertBatch(ctypes.Structure):
                ('side_stream', c_vp)])
 
 
-FORK_WGRAD, FORK_EARLY, FORK_REDUCE, FORK_JOIN = 1, 2, 4, 8
+FORK_WGRAD, FORK_EARLY, FORK_REDUCE, FORK_JOIN, RANGE_LAYERS_ONLY = 1, 2, 4, 8, 16
 
 
 _PTR16 = c_vp * 16

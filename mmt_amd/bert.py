@@ -361,8 +361,11 @@ class BertModel(nn.Module):
     dfeat = torch.empty_like(dlast)
     L = _lib.lib()
 
-    def run(l_hi, l_lo):
+    def run(l_hi, l_lo, embed=True):
+      """embed=False with l_lo == 0: stop before the embedding stage; run(-1, -1) then runs that stage alone."""
       b = self._batch_struct(batch, rows_alloc)  # (per call: the caller may change batch.fork between ranges)
+      if not embed:
+        b.fork |= _lib.RANGE_LAYERS_ONLY
       check(L.mmt_bert_backward_range(ctypes.byref(m), ctypes.byref(b), ws.data_ptr(), dlast.data_ptr(),
                                       dfeat.data_ptr(), int(training), int(l_hi), int(l_lo), ops._stream()),
             'mmt_bert_backward_range')

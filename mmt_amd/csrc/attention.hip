@@ -18,6 +18,7 @@
 // Dropout mask of element (b,h,q,k): hash of (key, (b*H+h)*S4+q) then of (k>>1); q,k are the ORIGINAL positions of the
 // tokens inside the sample (row_index[row] - b*S when the rows are packed), so a packed run draws exactly the mask of
 // the dense run.  Backward regenerates it.
+#include <stdlib.h>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -539,6 +540,27 @@ static int check_args(const void* qkv, int B, int S, int H, int d) {
   return 0;
 }
 
+// tq query tiles (dQ role) + tk key tiles (dK/dV role) in one launch.  MMT_ATTN_BWD_SPLIT=1 (lab: same-box A/B) issues
+// the two roles as two launches of the same kernel, the r02 structure.
+static int launch_bwd(const AttnArgs& a, int tq, int tk, int H, int B, bool dh128, hipStream_t s) {
+  static int split = -1;
+  if (split < 0) {
+    const char* e = getenv("MMT_ATTN_BWD_SPLIT");
+    split = e ? atoi(e) : 0;
+  }
+  auto go = [&](int gx, int q_tiles) {
+    if (dh128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(gx, H, B), dim3(256), 0, s, a, q_tiles);
+    else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(gx, H, B), dim3(256), 0, s, a, q_tiles);
+  };
+  if (split) {
+    go(tq, tq);
+    go(tk, 0);
+  } else {
+    go(tq + tk, tq);
+  }
+  return (int)hipGetLastError();
+}
+
 extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, void* ctx,
                             float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key,
                             uint32_t thr16, float drop_scale, const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
@@ -567,10 +589,7 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   const int tiles = (S + 63) / 64;
-  const dim3 grid(2 * tiles, H, B);
-  if (d == H * 128) hipLaunchKernelGGL(attn_bwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a, tiles);
-  else hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a, tiles);
-  return (int)hipGetLastError();
+  return launch_bwd(a, tiles, tiles, H, B, d == H * 128, (hipStream_t)stream);
 }
 
 // Query-subset variants: only the rows qsel[b*nq + i] act as queries (all rows of a sample remain keys/values).
@@ -605,10 +624,7 @@ extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
-  const int tq = (nq + 63) / 64, tk = (S + 63) / 64;
-  if (d == H * 128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(tq + tk, H, B), dim3(256), 0, (hipStream_t)stream, a, tq);
-  else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(tq + tk, H, B), dim3(256), 0, (hipStream_t)stream, a, tq);
-  return (int)hipGetLastError();
+  return launch_bwd(a, (nq + 63) / 64, (S + 63) / 64, H, B, d == H * 128, (hipStream_t)stream);
 }
 
 extern "C" int mmt_attn_dropout_mask(uint8_t* out, int B, int H, int S, uint32_t drop_key, uint32_t thr16,

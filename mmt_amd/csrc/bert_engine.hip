@@ -270,7 +270,8 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
 extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* dlast,
                                        float* dfeatures, int training, int l_hi, int l_lo, void* stream) {
   TRY(check_model(m, b));
-  if (!ws || !dlast || !dfeatures || l_hi >= m->layers || l_lo < 0 || l_lo > l_hi) return MMT_ERR_ARG;
+  const bool embed_only = l_hi == -1 && l_lo == -1;  // just the embedding stage (after a MMT_RANGE_LAYERS_ONLY call)
+  if (!ws || !dlast || !dfeatures || l_hi >= m->layers || (!embed_only && (l_lo < 0 || l_lo > l_hi))) return MMT_ERR_ARG;
   Ws w;
   layout(m, b->rows_alloc, (char*)ws, &w);
   const int d = m->hidden, I = m->inter, rows = b->rows;
@@ -308,8 +309,9 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   };
   const int nc = tail_rows(b, w);
   // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
+  // (the buffer that holds the gradient wrt layer l's OUTPUT depends on l alone; "layer -1" = the embedding stage)
   float* dcur = ((m->layers - 1 - l_hi) & 1) ? w.dA : dlast;
-  for (int l = l_hi; l >= l_lo; --l) {
+  for (int l = l_hi; l >= l_lo && !embed_only; --l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
@@ -436,7 +438,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     }
     dcur = dnext;
   }
-  if (l_lo > 0) return finish();
+  if (!embed_only && (l_lo > 0 || (b->fork & MMT_RANGE_LAYERS_ONLY))) return finish();
   // --- BertEmbeddings: dropout <- LN <- (features + type_emb + pos_emb) ---
   TRY(mmt_ln_bwd(dcur, w.z0, w.mean0, w.rstd0, m->emb_ln_g, dfeatures, nullptr, w.ln_partials[0], rows, d, 2, nr,
                  b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));

@@ -436,10 +436,12 @@ class CENet(nn.Module):
     n = sum(p.numel() for p in self.parameters() if p.requires_grad)
     return super().__str__() + '\nTrainable parameters: {}'.format(n)
 
-  def grad_regions(self):
+  def grad_regions(self, split_bottom=False):
     """Contiguous (offset, count) spans of the flat gradient buffer in the order the backward finishes them:
     [('top', text heads + last layer), ('layer<L-2>', ...), ..., ('layer1', ...),
-     ('bottom', expert projections + embeddings + layer 0)]  (one layer: 'top' = text heads only)."""
+     ('bottom', expert projections + embeddings + layer 0)]  (one layer: 'top' = text heads only).
+    split_bottom: 'bottom' as ('layer0', layer 0) + ('bottom', expert projections + embeddings) -- layer 0's weight
+    gradients are final before the embedding / token stage runs, so a data-parallel step can already reduce them."""
     f, vb = self._flat, self.vid_bert
     n_layers = vb.config.num_hidden_layers
     named = vb.engine_named_params()
@@ -451,7 +453,11 @@ class CENet(nn.Module):
     out = [('top', f.span(top))] if top else []
     for l in range(n_layers - 2, 0, -1):
       out.append(('layer%d' % l, f.span(per_layer[l])))
-    out.append(('bottom', f.span(self._reduce_params() + emb + per_layer[0])))
+    if split_bottom and n_layers >= 2:
+      out.append(('layer0', f.span(per_layer[0])))
+      out.append(('bottom', f.span(self._reduce_params() + emb)))
+    else:
+      out.append(('bottom', f.span(self._reduce_params() + emb + per_layer[0])))
     return out
 
   def engine_params(self):

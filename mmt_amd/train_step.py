@@ -119,12 +119,16 @@ FORK_DEFAULT = 0
 class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
-               overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None):
+               overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
+               grad_algo='allreduce', split_bottom=True):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
     grad_dtype: torch.bfloat16 sends the gradient all-reduces in bf16 (half the bytes over xGMI, `dist.WireBuffer`);
     None / torch.float32 reduces the fp32 buffer in place.
+    grad_algo: 'allreduce' | 'rs_ag' (reduce-scatter + all-gather per span, `dist.WireBuffer`).
+    split_bottom: staged mode reduces layer 0's gradients before the embedding / token stage runs, so that only the
+    expert projections + embedding tables (about half of the last span) are reduced after the backward has ended.
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
@@ -163,8 +167,11 @@ class GraphedTrainStep:
     else:
       self.opt_rest = None
     self.grad_dtype = grad_dtype
-    self._wire = mdist.WireBuffer(grad_dtype)
-    self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group, grad_dtype=grad_dtype) for i, f in enumerate(flats)]
+    self.grad_algo, self._split_bottom = grad_algo, bool(split_bottom)
+    self._wire = mdist.WireBuffer(grad_dtype, grad_algo)
+    self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group, grad_dtype=grad_dtype, algo=grad_algo)
+                  for i, f in enumerate(flats)]
+    self._exposed = []  # (event before, event after) around the final wait for the staged reductions, last steps
     self.sync = self.syncs[0]
     self._extra_flats = flats[1:]
     self.use_graphs = use_graphs
@@ -426,12 +433,26 @@ class GraphedTrainStep:
       if n_layers >= 2:
         st['run'](n_layers - 1, n_layers - 1)
 
-    names = dict(self.model.grad_regions())
+    names = dict(self._grad_regions())
     stages = [(top, (['top'] if 'top' in names else []) + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
     for l in range(n_layers - 2, 0, -1):
       stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
-    stages.append((bottom, ['bottom']))
+    if 'layer0' in names:  # split bottom: layer 0 alone, then the embedding stage + video tokens
+      def bottom_split():
+        st['run'](-1, -1)
+        side = self._side if (self._fork_on and self.fork & FORK_TOKENS) else None
+        model._video_tokens_backward(model._stages['plan'], st['run'].dfeat, side_stream=side)
+        if side is not None and self._multi:
+          self._join()
+      stages.append((lambda: st['run'](0, 0, embed=False), ['layer0']))
+      stages.append((bottom_split, ['bottom']))
+    else:
+      stages.append((bottom, ['bottom']))
     return stages
+
+  def _grad_regions(self):
+    """The model's flat-gradient spans in backward order; in staged multi-rank mode with layer 0 as its own span."""
+    return self.model.grad_regions(split_bottom=self._split_bottom and self.staged)
 
   def _text_heads_backward_forked(self, e, txt):
     """Fork mode: the text heads' backward (3 launches, latency-bound) on the side stream, called directly -- autograd
@@ -475,7 +496,7 @@ class GraphedTrainStep:
   def _region_table(self):
     """name -> (flat, offset, count): the video flat's spans in backward order + every other flat as one span (the
     native text tower's backward runs with the text heads, in the first stage)."""
-    tab = {n: (self.model._flat, off, cnt) for n, (off, cnt) in self.model.grad_regions()}
+    tab = {n: (self.model._flat, off, cnt) for n, (off, cnt) in self._grad_regions()}
     for i, f in enumerate(self._extra_flats):
       tab['flat%d' % (i + 1)] = (f, 0, f.count)
     return tab
@@ -706,10 +727,38 @@ class GraphedTrainStep:
       for gs, names in gb:
         gs.replay()
         handles += self._reduce_async(names)
+      ev = self._exposed_pair()
+      if ev:
+        ev[0].record()
       self._finish(handles)
+      if ev:
+        ev[1].record()
     else:
       gb.replay()
+      ev = self._exposed_pair()
+      if ev:
+        ev[0].record()
       self._sync_all()
+      if ev:
+        ev[1].record()
     if gc is not None:
       gc.replay()
     return self.loss
+
+  measure_exposed = False
+
+  def _exposed_pair(self):
+    if not (self.measure_exposed and self._multi):
+      return None
+    pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    self._exposed.append(pair)
+    if len(self._exposed) > 512:
+      self._exposed.pop(0)
+    return pair
+
+  def exposed_collective_ms(self):
+    """Mean time per step the compute stream spent between the end of the last backward stage and the point where every
+    gradient reduction has landed (HIP events on the compute stream around the final waits; `measure_exposed = True`
+    before the steps, synchronize before reading): the part of the gradient exchange the backward did NOT hide."""
+    ms = [a.elapsed_time(b) for a, b in self._exposed if a.query() and b.query()]
+    return sum(ms) / len(ms) if ms else None

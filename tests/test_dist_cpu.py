@@ -83,3 +83,46 @@ def test_single_process_paths_are_identity():
   x = torch.randn(4, 3, requires_grad=True)
   assert mdist.all_gather_rows(x) is x
   mdist.GradSync(None, [x]).sync()  # no process group: no-op
+
+
+def _wire_worker(rank, world, port, out):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from mmt_amd import dist as mdist
+  res = {}
+  for n in (4096, 4099):  # divisible by the world size (reduced in place) and not (zero-padded wire buffer)
+    g = torch.Generator().manual_seed(100 + rank)
+    base = torch.randn(n + 64, generator=g)
+    for algo in ('allreduce', 'rs_ag'):
+      for dt in (None, torch.bfloat16):
+        flat = base.clone()
+        span = flat[32:32 + n]  # a span in the middle of a flat buffer: its neighbours must stay untouched
+        wire = mdist.WireBuffer(dt, algo)
+        for _ in range(2):  # the wire buffers are reused from step to step
+          span.copy_(base[32:32 + n])
+          h, fin = wire.reduce(span, None)
+          h.wait()
+          fin()
+        assert torch.equal(flat[:32], base[:32]) and torch.equal(flat[32 + n:], base[32 + n:])
+        res[(n, algo, 'bf16' if dt else 'f32')] = span.clone()
+  torch.save(res, '%s.%d' % (out, rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_variant_equals_all_reduce(tmp_path):
+  """dist.WireBuffer(algo='rs_ag'): reduce_scatter_tensor + all_gather_into_tensor of a gradient span (what RCCL maps to
+  the full xGMI mesh) gives every rank the sums the single all_reduce gives -- fp32 bit for bit on two ranks, also when
+  the span length is not a multiple of the world size; in the bf16 wire format both round the same addends."""
+  out = str(tmp_path / 'wire')
+  mp.spawn(_wire_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+  for n in (4096, 4099):
+    want = sum(torch.randn(n + 64, generator=torch.Generator().manual_seed(100 + r))[32:32 + n] for r in range(2))
+    for algo in ('allreduce', 'rs_ag'):
+      assert torch.equal(r0[(n, algo, 'f32')], r1[(n, algo, 'f32')])
+      assert torch.equal(r0[(n, algo, 'f32')], want), (n, algo)
+      assert torch.equal(r0[(n, algo, 'bf16')], r1[(n, algo, 'bf16')])
+      assert (r0[(n, algo, 'bf16')] - want).abs().max() < 0.05
+    assert torch.equal(r0[(n, 'rs_ag', 'bf16')], r0[(n, 'allreduce', 'bf16')])

@@ -53,7 +53,7 @@ def _slice_batch(mb, text, sl):
 
 
 def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, force_collectives=False,
-         capture_collectives=False, fork=None, **build_kw):
+         capture_collectives=False, fork=None, grad_algo='allreduce', **build_kw):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
@@ -66,7 +66,7 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
   model.txt_bert.text = static['text']
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
                             overlap_grad_sync=overlap, grad_dtype=grad_dtype, force_collectives=force_collectives,
-                            capture_collectives=capture_collectives, fork=fork)
+                            capture_collectives=capture_collectives, fork=fork, grad_algo=grad_algo)
   if fork is not None:
     assert runner._fork_on == bool(fork)
   assert runner.staged == ((world > 1 or force_collectives) if overlap is None else overlap)
@@ -90,15 +90,23 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
 def _worker(rank, world, port, out, kw):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
-  torch.cuda.set_device(0)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
   backend = kw.pop('backend', 'gloo')
+  # RCCL with more than one rank needs one GPU per rank; gloo (which moves CUDA tensors through the host) lets every
+  # rank share cuda:0 on the 1-GPU boxes
+  index = rank if (backend == 'nccl' and world > 1) else 0
+  torch.cuda.set_device(index)
+  dev = torch.device('cuda', index)
   if backend == 'nccl':
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
   else:
     dist.init_process_group(backend, rank=rank, world_size=world)
-  torch.save(_run(rank, world, torch.device('cuda', 0), **kw), '%s.%d' % (out, rank))
+  torch.save(_run(rank, world, dev, **kw), '%s.%d' % (out, rank))
   dist.barrier()
   dist.destroy_process_group()
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL with 2 ranks needs 2 GPUs')
 
 
 def test_two_ranks_equal_single_process_global_batch(tmp_path):
@@ -164,6 +172,56 @@ def test_two_ranks_bench_configuration_stays_in_lock_step(tmp_path):
   assert r0['master'].isfinite().all()
 
 
+@needs_two_gpus
+@pytest.mark.parametrize('grad_algo', ['allreduce', 'rs_ag'])
+def test_two_ranks_over_rccl_one_gpu_each(tmp_path, grad_algo):
+  """The bench configuration's step on the REAL backend: 2 ranks, one MI355X each, RCCL moving the embeddings all-gather
+  and the staged gradient reductions over xGMI (skipped on 1-GPU boxes).  Same contract as the gloo variant: one global
+  loss, rank-different dropout, bit-identical weights on both ranks after the all-reduced updates -- and the same
+  trajectory as two gloo ranks sharing one GPU would produce is checked by that test's twin assertions."""
+  out = str(tmp_path / 'rccl')
+  kw = dict(txt_pro='gbn', dropout=0.1, layers=4, steps=3, backend='nccl', grad_algo=grad_algo)
+  mp.spawn(_worker, args=(2, _free_port(), out, kw), nprocs=2, join=True)
+  r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+  assert r0['seed'] != r1['seed']
+  assert max(abs(a - b) for a, b in zip(r0['losses'], r1['losses'])) < 1e-6
+  assert all(l == l and l > 0 for l in r0['losses'])
+  assert torch.equal(r0['grad'], r1['grad'])
+  assert torch.equal(r0['master'], r1['master'])
+  assert r0['master'].isfinite().all()
+
+
+@needs_two_gpus
+def test_two_ranks_over_rccl_equal_single_process_global_batch(tmp_path):
+  """test_two_ranks_equal_single_process_global_batch with RCCL between two GPUs instead of gloo on one."""
+  out = str(tmp_path / 'rccl1')
+  mp.spawn(_worker, args=(2, _free_port(), out, dict(backend='nccl')), nprocs=2, join=True)
+  r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+  single = _run(0, 1, torch.device('cuda', 0))
+  g1 = single['grad']
+  assert (r0['grad'] - r1['grad']).abs().max() < 1e-7
+  scale = g1.abs().max().item()
+  assert (r0['grad'] - g1).abs().max() < 2e-3 * scale
+  assert max(abs(a - b) for a, b in zip(r0['losses'], single['losses'])) < 1e-4
+  assert (r0['master'] - r1['master']).abs().max() < 1e-6
+
+
+def test_reduce_scatter_all_gather_gradient_sync_equals_all_reduce(tmp_path):
+  """GraphedTrainStep(grad_algo='rs_ag'): every staged gradient span as reduce-scatter + all-gather (dist.WireBuffer).
+  Two ranks (gloo, one GPU): the sums are the all-reduce's bit for bit, so losses, gradients and weights are too."""
+  outs = {}
+  for algo in ('allreduce', 'rs_ag'):
+    out = str(tmp_path / algo)
+    kw = dict(txt_pro='gbn', dropout=0.1, layers=4, steps=3, grad_algo=algo)
+    mp.spawn(_worker, args=(2, _free_port(), out, kw), nprocs=2, join=True)
+    outs[algo] = (torch.load(out + '.0'), torch.load(out + '.1'))
+  a, b = outs['allreduce'][0], outs['rs_ag'][0]
+  assert torch.equal(outs['rs_ag'][0]['master'], outs['rs_ag'][1]['master'])
+  assert a['losses'] == b['losses']
+  assert torch.equal(a['grad'], b['grad'])
+  assert torch.equal(a['master'], b['master'])
+
+
 def test_bf16_gradient_wire_format_tracks_fp32_reduction(tmp_path):
   """grad_dtype=torch.bfloat16 halves the bytes of the gradient all-reduce (dist.WireBuffer): after 10 optimisation
   steps on two ranks the weights stay within 1e-3 (relative L2) of the fp32-reduced run."""
@@ -216,6 +274,26 @@ def _sharded_worker(rank, world, port, out):
   dist.destroy_process_group()
 
 
+def _sharded_worker_rccl(rank, world, port, out):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.cuda.set_device(rank)
+  dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+  from mmt_amd.large_sim import ShardedSimLoss
+  vid, txt, tw, vw = _sharded_inputs()
+  b = vid.shape[0] // world
+  sl = slice(rank * b, (rank + 1) * b)
+  lv = [x[sl].clone().cuda().requires_grad_(True) for x in (vid, txt, tw)]
+  loss = ShardedSimLoss(0.05, True)(lv[0], lv[1][:, :, None, :], vw[sl].cuda(), lv[2][:, None, :])
+  loss.backward()
+  torch.cuda.synchronize()
+  torch.save(dict(loss=float(loss.item()), dvid=lv[0].grad.cpu(), dtxt=lv[1].grad.cpu(), dtw=lv[2].grad.cpu()),
+             '%s.%d' % (out, rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
 def _sharded_inputs():
   import numpy as np
   rs = np.random.RandomState(7)
@@ -248,3 +326,17 @@ def test_sharded_sim_loss_with_a_real_process_group_matches_oracle(tmp_path):
     cos = float(got @ want / (got.norm() * want.norm()))
     assert cos > 0.995, (key, cos)
     assert abs(float(got.norm() / want.norm()) - 1.0) < 0.03, key
+
+
+@needs_two_gpus
+def test_sharded_sim_loss_over_rccl_matches_gloo_run(tmp_path):
+  """The row-sharded similarity + max-margin loss (BASELINE configs[4] path) with RCCL between two GPUs: same loss and
+  gradients as the two-rank gloo run on one GPU (skipped on 1-GPU boxes)."""
+  a, b = str(tmp_path / 'gl'), str(tmp_path / 'rc')
+  mp.spawn(_sharded_worker, args=(2, _free_port(), a), nprocs=2, join=True)
+  mp.spawn(_sharded_worker_rccl, args=(2, _free_port(), b), nprocs=2, join=True)
+  for r in range(2):
+    x, y = torch.load('%s.%d' % (a, r)), torch.load('%s.%d' % (b, r))
+    assert abs(x['loss'] - y['loss']) < 1e-6
+    for k in ('dvid', 'dtxt', 'dtw'):
+      assert (x[k] - y[k]).abs().max() <= 1e-6 * max(1.0, x[k].abs().max().item()), k

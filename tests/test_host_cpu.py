@@ -171,6 +171,30 @@ def test_grad_regions_tile_the_flat_layout_in_backward_order():
     assert bottom[0] <= f.offset(p) < bottom[0] + bottom[1]
 
 
+def test_split_bottom_regions_tile_the_layout_too():
+  """grad_regions(split_bottom=True): layer 0 is its own span, reduced before the embedding / token stage runs; the spans
+  still tile the layout back to front."""
+  meta = json.loads(str(load_npz('cenet_configB')['meta']))
+  model = build_native_cenet(meta)
+  f = model._flat
+  regions = model.grad_regions(split_bottom=True)
+  names = [n for n, _ in regions]
+  n_layers = model.vid_bert.config.num_hidden_layers
+  assert names == ['top'] + ['layer%d' % l for l in range(n_layers - 2, -1, -1)] + ['bottom']
+  spans = sorted(s for _, s in regions)
+  assert spans[0][0] == 0 and spans[-1][0] + spans[-1][1] == f.count
+  for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+    assert o0 + c0 == o1
+  offs = [off for _, (off, _) in regions]
+  assert offs == sorted(offs, reverse=True)
+  layer0, bottom = dict(regions)['layer0'], dict(regions)['bottom']
+  p0 = model.vid_bert.encoder.layer[0].output.dense.weight
+  assert layer0[0] <= f.offset(p0) < layer0[0] + layer0[1]
+  for p in (model.video_dim_reduce[model.modalities[0]].fc.weight, model.vid_bert.embeddings.position_embeddings.weight):
+    assert bottom[0] <= f.offset(p) < bottom[0] + bottom[1]
+  assert bottom[1] + layer0[1] == dict(model.grad_regions())['bottom'][1]
+
+
 def test_text_tower_state_dict_uses_huggingface_names():
   """bert-base-cased checkpoints (and trained MMT checkpoints, whose text tower is a transformers BertModel) must load:
   same keys and shapes as transformers' BertModel, `LayerNorm` spelling included."""
