@@ -218,8 +218,11 @@ def assemble_video_tokens(P, modalities, expert_dims, batch, same_dim, max_pos):
           torch.cat(masks, 1), agg)
 
 
-def text_moe_weights(P, modalities, text):
-  """model/model.py:262-283 (text branch) + :618.  text: (B, C, 768) -> (B, C, M)."""
+def text_moe_weights(P, modalities, text, masks=None, p=0.0):
+  """model/model.py:262-283 (text branch) + :618.  text: (B, C, 768) -> (B, C, M).
+  masks['moe'] (same shape as text) replays moe_txt_dropout (:274) in train mode."""
+  if masks is not None and 'moe' in masks and p > 0.0:
+    text = text * masks['moe'].to(text.dtype).view_as(text) / (1.0 - p)
   logits = torch.cat([F.linear(text, P['moe_fc_txt.%s.weight' % m], P['moe_fc_txt.%s.bias' % m])
                       for m in modalities], dim=-1)
   w = torch.softmax(logits, dim=-1)
@@ -282,7 +285,8 @@ def cenet_forward(P, cfg, batch, text, training, masks=None, out='conf'):
   vid = torch.stack([l2_normalize(last[:, agg[m]]) for m in mods], 1)  # :583-587, :621-625
   txt = torch.stack([l2_normalize(t) for t in text_embd], 1)  # (B,M,C,d) second normalise :623
   vw = torch.full((b, len(mods)), 1.0 / len(mods), dtype=text.dtype)  # :594,607
-  tw = text_moe_weights(P, mods, text)  # :610-618 (moe dropout off unless masks; not replayed)
+  # :610-618; moe_txt_dropout (:274) only when its keep-mask is supplied (cfg['moe_dropout_prob'], masks['moe'])
+  tw = text_moe_weights(P, mods, text, masks, float(cfg.get('moe_dropout_prob', 0.0)))
   if out != 'conf':
     return {'vid_embds': vid, 'text_embds': txt, 'vid_weights': vw, 'text_weights': tw}
   merge = 'avg' if training else cfg.get('test_caption_mode', 'indep')  # :627-631

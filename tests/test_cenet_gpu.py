@@ -247,6 +247,104 @@ def test_train_mode_dropout_replay_through_oracle():
   assert (seq.detach().cpu() - ref).abs().max() < 0.05
 
 
+def _export_step_masks(model, batch, seq, heads, layers, p_drop, text_shape):
+  """Every keep-mask the kernels drew in the forward that just ran, regenerated from the same (site key, device seed):
+  hidden-state sites through a zero-input GEMM epilogue (dropout(bias = 1) + 0: kept elements are non-zero), attention
+  probabilities through mmt_attn_dropout_mask -- both keyed on ORIGINAL (sample, position) coordinates, i.e. the dense
+  grid, whatever rows the packed step computed -- and moe_txt_dropout from the key the text-head kernel saved."""
+  import ctypes
+  from mmt_amd import _lib, ops
+  d = model.same_dim
+  seed = model.vid_bert._seed_dev
+  rows, R = batch * seq, ops.pad_rows(batch * seq)
+  masks = {}
+
+  def hidden_mask(layer, site):
+    a = torch.zeros(R, 64, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(d, 64, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(R, d, device=DEV)
+    ops.gemm_nt(a, w, out, 'BIAS_DROP_RES', bias=torch.ones(d, device=DEV), res=torch.zeros(R, d, device=DEV),
+                drop_key=0x5eed0000 + layer * 16 + site, drop_p=p_drop, seed_dev=seed)
+    return (out[:rows] != 0).float().view(batch, seq, d).cpu()
+
+  masks['emb'] = hidden_mask(0, 0)
+  for l in range(layers):
+    masks['l%d.attn_out' % l] = hidden_mask(l, 2)
+    masks['l%d.ffn_out' % l] = hidden_mask(l, 3)
+    masks['l%d.probs' % l] = ops.attn_dropout_mask(batch, heads, seq, 0x5eed0000 + l * 16 + 1, p_drop, seed_dev=seed).float().cpu()
+  if getattr(model, '_th_key', None) is not None and model._th_opts.moe_drop_thr16:
+    ones = torch.ones(text_shape, device=DEV)
+    out = torch.empty_like(ones)
+    o = model._th_opts
+    _lib.check(_lib.lib().mmt_dropout_f32(ops._p(ones), ops._p(out), ones.numel(), o.moe_drop_key, o.moe_drop_thr16,
+                                          o.moe_drop_scale, None, None, ops._p(model._th_key), ops._stream()), 'mmt_dropout_f32')
+    masks['moe'] = (out != 0).float().cpu()
+  return masks
+
+
+def test_bench_configuration_replayed_through_oracle_with_every_dropout_and_packing():
+  """The configuration bench.py times -- config B (batch 32, 4 layers, 7 experts x 30 tokens), token packing ON, last-layer
+  row elimination, dropout 0.1 at EVERY site (embeddings, attention probabilities, both projections, the MoE logits),
+  BatchNorm text heads in train mode -- against the CPU oracle directly: the masks the kernels drew are exported and
+  replayed through oracle.cenet_forward(training=True, masks=...).  Similarities atol 2e-3, max-margin loss rel 2e-2, and
+  the WHOLE flat gradient (under the smooth objective of test_every_parameter_gradient_matches_oracle_autograd: max-margin
+  gradients measure hinge flips) relative L2 <= 4 % as one vector, <= 5 % per parameter."""
+  from mmt_amd import ops
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from oracle import mmt_oracle as O
+  p_drop = 0.1
+  fx = load_cenet_fixture('configB')
+  torch.manual_seed(11)
+  model = build_native_cenet(fx.meta, pack_tokens=True, dropout=p_drop)
+  model.load_state_dict(fx.state_dict)
+  model.to(DEV).train()
+  assert model.pack_tokens and model.tail_rows_only and model.moe_txt_dropout.p == p_drop
+  sims = _run(model, _to_dev(fx.batch), fx.text.to(DEV))['cross_view_conf_matrix']
+  plan = model._plans[next(iter(model._plans))]
+  assert int(plan.n_rows.item()) < plan.rows  # the packed step really dropped padded tokens
+  loss = MaxMarginRankingLoss(margin=0.05, fix_norm=True)(sims.detach())
+  R = torch.from_numpy(np.random.RandomState(5).randn(*sims.shape).astype(np.float32))
+  (sims * R.to(DEV)).sum().backward()
+  vbp = fx.cfg['vid_bert_params']
+  b, c = fx.text.shape[0], fx.text.shape[1]
+  seq = 1 + len(fx.cfg['modalities']) * (fx.meta['fixture']['max_tokens'] + 1)
+  masks = _export_step_masks(model, b, seq, vbp['num_attention_heads'], vbp['num_hidden_layers'], p_drop,
+                             (b * c, fx.text.shape[-1]))
+  assert 'moe' in masks and 0.85 < masks['moe'].mean().item() < 0.95 and 0.85 < masks['l2.probs'].mean().item() < 0.95
+  thr, _ = ops.dropout_params(p_drop)
+  q = thr / 65536.0  # the kernels' keep probability is quantised to 1/65536
+  cfg = dict(fx.cfg, vid_bert_params=dict(vbp, hidden_dropout_prob=q, attention_probs_dropout_prob=q), moe_dropout_prob=q)
+  P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v.clone()) for k, v in fx.state_dict.items()}
+  ref = O.cenet_forward(P, cfg, copy.deepcopy(fx.batch), fx.text, training=True, masks=masks)['cross_view_conf_matrix']
+  ref_loss = O.max_margin_ranking_loss(ref.detach(), 0.05, True)
+  (ref * R).sum().backward()
+  err = (sims.detach().cpu() - ref.detach()).abs().max().item()
+  assert err < 2e-3, err
+  # a DIFFERENT mask anywhere moves the similarities by > 1e-2: the same forward without masks must NOT match
+  with torch.no_grad():
+    nodrop = O.cenet_forward(P, fx.cfg, copy.deepcopy(fx.batch), fx.text, training=True)['cross_view_conf_matrix']
+  assert (sims.detach().cpu() - nodrop).abs().max().item() > 5 * err
+  assert abs(loss.item() - ref_loss.item()) <= 2e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+  got, want, worst = [], [], (0.0, None)
+  for k, p in model.named_parameters():
+    if k.startswith('vid_bert.pooler.'):
+      continue
+    g, r = p.grad.detach().cpu().double(), P[k].grad.double()
+    if k.endswith('attention.self.key.bias') or (k.endswith('.cg.fc.bias') and 'text_GU' in k):
+      continue  # zero in exact arithmetic (see test_every_parameter_gradient_matches_oracle_autograd)
+    got.append(g.reshape(-1))
+    want.append(r.reshape(-1))
+    if not (k.startswith('moe_fc_txt.') and k.endswith('.bias')):
+      rel = float((g - r).norm() / r.norm())
+      assert rel <= 5e-2, (k, rel)
+      worst = max(worst, (rel, k))
+  got, want = torch.cat(got), torch.cat(want)
+  total = float((got - want).norm() / want.norm())
+  print('config B, dropout + packing replay: sims max err %.2e, loss %.6f vs %.6f, whole-gradient rel L2 %.4f, worst '
+        'parameter %s %.4f' % (err, loss.item(), ref_loss.item(), total, worst[1], worst[0]))
+  assert total <= 4e-2, total
+
+
 def test_eval_path_on_device_metrics_match_reference():
   """N_text x N_video similarity + tie-averaged R@K on the device vs the reference's metric code.
   (a) the golden metric cases produced by the REAL reference's model/metric.py; (b) 1000 videos x 3 captions with

@@ -45,6 +45,35 @@ def test_real_trainer_epoch_reproduces_golden_and_mimic_is_the_same_loop():
   assert (st.n_samples, st.n_steps) == (tr.n_samples, tr.n_steps)
 
 
+def test_real_valid_epoch_reproduces_golden_and_mimic_is_the_same_loop():
+  """Evaluation half: the reference's own `Trainer._valid_epoch` (+ `_get_embeddings`, trainer/trainer.py:286-483) on the
+  validation loader with 3 captions per video and masked captions gives tests/golden/trainer_valid.npz, and
+  `trainer_harness.mimic_valid_epoch` (what the GPU test drives the drop-in with) is that method: identical similarity
+  matrix, metrics and rank vectors."""
+  from oracle import gen_trainer_golden as G
+  R = load_reference()
+  g = load_npz('trainer_valid')
+  model, _ = G.build_reference_model(R)
+  sims, qm, metrics = G.run_real_valid(R, model)
+  assert np.abs(sims - g['sims']).max() < 1e-6 and np.array_equal(qm, g['query_masks'])
+  want = json.loads(str(g['metrics']))
+  for name in ('t2v_metrics', 'v2t_metrics'):
+    for k in H.METRIC_KEYS:
+      assert abs(float(metrics[name][k]) - want[name][k]) < 1e-4, (name, k)
+  sims2, nested2, _ = H.mimic_valid_epoch(model, H.MODS, H.EvalLoader(), torch.device('cpu'),
+                                          R.model.sharded_cross_view_inner_product,
+                                          [R.metric.t2v_metrics, R.metric.v2t_metrics])
+  assert np.array_equal(sims, sims2)
+  for name in ('t2v_metrics', 'v2t_metrics'):
+    assert np.array_equal(metrics[name]['cols'], nested2[name]['cols'])
+  # and the oracle's restatement of model/metric.py (what the GPU tests compare the device-side ranks with) agrees
+  from oracle import mmt_oracle as O
+  for name, fn in (('t2v_metrics', O.t2v_metrics), ('v2t_metrics', O.v2t_metrics)):
+    got = fn(sims, query_masks=qm)
+    for k in H.METRIC_KEYS:
+      assert abs(got[k] - float(metrics[name][k])) < 1e-4, (name, k)
+
+
 def _native_cenet(max_pos, txt_bert=None):
   from mmt_amd import synthetic
   from mmt_amd.model import CENet

@@ -8,6 +8,10 @@ config system, datasets and logging.
                           `move_dict_to_device` drops (trainer/trainer.py:36-52).
   * `real_trainer`        the reference's OWN `trainer.trainer.Trainer` (needs /root/reference: build container only),
                           constructed around its `__init__` (which wants the config parser, data loaders, visualiser ...).
+  * `real_valid_epoch` / `mimic_valid_epoch`   the same pair for the evaluation half, `Trainer._valid_epoch` +
+                          `_get_embeddings` (trainer/trainer.py:286-447): out='embds' under no_grad, torch.cat over the
+                          batches, move to the CPU, `sharded_cross_view_inner_product(..., 'indep')`, t2v / v2t metrics with
+                          query_masks -- on `EvalLoader` (several captions per video, some of them masked out).
   * `mimic_train_epoch`   a line-by-line restatement of `Trainer._train_epoch` (trainer/trainer.py:120-249) for the GPU box,
                           where the reference tree does not exist.  tests/test_reference_integration_cpu.py pins it to the
                           real method: same model, same loader => bit-identical losses and weights.
@@ -205,3 +209,159 @@ def run_epochs(step_fn, epochs=EPOCHS):
 PROBE_PARAMS = ['vid_bert.encoder.layer.0.attention.self.query.weight', 'vid_bert.encoder.layer.0.output.dense.bias',
                 'video_dim_reduce.s3d.fc.weight', 'text_GU.vggish.cg.fc.weight', 'moe_fc_txt.s3d.weight',
                 'vid_bert.embeddings.position_embeddings.weight']
+
+
+# ---- evaluation half (trainer/trainer.py:286-447) ------------------------------------------------------------------
+EVAL_ITERS, EVAL_BATCH, EVAL_CAPS = 3, 8, 3   # 24 videos x 3 captions = 72 text queries
+
+
+class _EvalDataset:
+  dataset_name = 'SyntheticMSRVTT_full_val'   # <basename>_<cut>_<split>, trainer/trainer.py:404-406
+  split_name = 'val'
+  n_pairs = 1
+
+
+class EvalLoader:
+  """A validation loader as the reference's collate hands it to `_get_embeddings`: C captions per video, `query_masks` a
+  NUMPY array (trainer.py:317 wraps it with torch.from_numpy) with some captions missing, tensors for the rest."""
+
+  def __init__(self, iters=EVAL_ITERS, batch=EVAL_BATCH, caps=EVAL_CAPS, seed=SEED + 100):
+    self.batch_size, self.dataset = batch, _EvalDataset()
+    self._mbs = []
+    for i in range(iters):
+      mb, _ = synthetic.make_batch(seed + i, batch, MODS, TOKENS, captions=caps, max_pos=VB['max_pos'])
+      qm = np.ones((batch, caps), dtype=np.float32)
+      rs = np.random.RandomState(seed + 1000 + i)
+      qm[:, 1:] = (rs.rand(batch, caps - 1) < 0.7).astype(np.float32)  # the first caption always exists
+      mb['query_masks'] = qm
+      mb['raw_captions'] = [[np.array(['a', 'caption'])] * caps for _ in range(batch)]
+      mb['paths'] = ['video%d' % (i * batch + k) for k in range(batch)]
+      mb['sources'] = ['SyntheticMSRVTT'] * batch
+      self._mbs.append(mb)
+
+  def __len__(self):
+    return len(self._mbs)
+
+  def __iter__(self):
+    for mb in self._mbs:
+      out = {}
+      for k, v in mb.items():
+        out[k] = collections.OrderedDict((kk, vv.clone()) for kk, vv in v.items()) if isinstance(v, dict) else (
+            v.clone() if torch.is_tensor(v) else (v.copy() if isinstance(v, np.ndarray) else list(v)))
+      yield out
+
+
+class _Sink:
+  """writer / visualizer / logger stand-in: accepts every call."""
+
+  def __getattr__(self, name):
+    return lambda *a, **k: None
+
+
+def real_valid_trainer(R, model, loader, device):
+  """The reference's Trainer with the state `_valid_epoch` / `_get_embeddings` touch (trainer/trainer.py:286-483)."""
+  import importlib
+  T = importlib.import_module('trainer.trainer')
+  timing = importlib.import_module('utils.timing_utils')
+  tr = T.Trainer.__new__(T.Trainer)
+  tr.model, tr.device = model, device
+  tr.data_loaders = {'continuous_eval_sets': [{'loader': loader, 'dataset': loader.dataset}]}
+  tr.modalities = list(MODS)
+  tr.metrics = [R.metric.t2v_metrics, R.metric.v2t_metrics]   # config['metrics'], train.py:94
+  tr.timer = timing.AverageMeter()
+  tr.debug_dataloader = False
+  tr.writer, tr.visualizer, tr.tokenizer, tr.exp_dir = _Sink(), _Sink(), None, '/tmp'
+  return tr
+
+
+def mimic_get_embeddings(model, modalities, val_loader, device):
+  """`Trainer._get_embeddings` (trainer/trainer.py:286-370), minus timers / debug display."""
+  out = 'embds'
+  with torch.no_grad():
+    vid_embds, text_embds = collections.OrderedDict(), collections.OrderedDict()
+    query_masks_list, raw_captions_list, token_ids_list, paths_list = [], [], [], []
+    vid_weights_list, text_weights_list = [], []
+    for batch_idx, minibatch in enumerate(val_loader):                   # :301
+      if 'raw_captions' in minibatch.keys():                              # :305-307
+        raw_captions_list.extend(minibatch['raw_captions'])
+        paths_list.extend(minibatch['paths'])
+      if 'token_ids' in minibatch.keys():                                 # :316-317
+        token_ids_list.extend(minibatch['token_ids'])
+      query_masks_list.append(torch.from_numpy(minibatch['query_masks']))   # :319
+      minibatch = move_dict_to_device(minibatch, device)                  # :329
+      output = model(**minibatch, out=out, device=device, debug=False)    # :335-338
+      vid_weights_list.append(output['vid_weights'])                      # :340-341
+      text_weights_list.append(output['text_weights'])
+      for idx, mod in enumerate(modalities):                              # :342-344
+        vid_embds.setdefault(mod, []).append(output['vid_embds'][:, idx])
+        text_embds.setdefault(mod, []).append(output['text_embds'][:, idx])
+    query_masks = torch.cat(query_masks_list, 0)                          # :350-355
+    vid_weights = torch.cat(vid_weights_list, 0)
+    text_weights = torch.cat(text_weights_list, 0)
+    for idx, mod in enumerate(modalities):
+      vid_embds[mod] = torch.cat(vid_embds[mod], 0)
+      text_embds[mod] = torch.cat(text_embds[mod], 0)
+    token_ids = np.concatenate(token_ids_list)                            # :357
+    res = {'vid_embds': vid_embds, 'text_embds': text_embds, 'vid_weights': vid_weights, 'text_weights': text_weights,
+           'raw_captions': raw_captions_list, 'token_ids': token_ids, 'query_masks': query_masks, 'paths': paths_list}
+    move_dict_to_device(res, device='cpu', only_tensors=False)            # :368
+    return res
+
+
+def mimic_valid_epoch(model, modalities, loader, device, sims_fn, metric_fns, embds_device='cpu'):
+  """`Trainer._valid_epoch` (trainer/trainer.py:372-483) for one loader: eval mode, embeddings of the whole set, the
+  'indep' similarity through `sims_fn` (the name the trainer imports: sharded_cross_view_inner_product) on CPU tensors,
+  every metric in `metric_fns` with the query masks.  embds_device='cuda': the gathered embeddings stay on the device
+  instead of taking the trainer's detour through the host (what a maintainer who drops trainer.py:368 gets).
+  -> (sims numpy [N_text, N_video], {metric name: {...}}, embds)"""
+  model.eval()                                                            # :377
+  with torch.no_grad():
+    embds = mimic_get_embeddings(model, modalities, loader, device)      # :392
+    if embds_device != 'cpu':
+      move_dict_to_device(embds, device=embds_device, only_tensors=False)
+    conf = sims_fn(vid_embds=embds['vid_embds'], text_embds=embds['text_embds'], vid_weights=embds['vid_weights'],
+                   text_weights=embds['text_weights'], subspaces=modalities,
+                   merge_caption_similiarities='indep')                    # :396-403
+    sims = conf.data.cpu().float().numpy()                                # :404
+    query_masks = embds['query_masks'].cpu().numpy()                      # :405
+    nested = {}
+    for metric in metric_fns:                                             # :444-447
+      nested[metric.__name__] = metric(sims, query_masks=query_masks)
+  return sims, nested, embds
+
+
+METRIC_KEYS = ('R1', 'R5', 'R10', 'R50', 'MedR', 'MeanR', 'geometric_mean_R1-R5-R10')
+
+# ---- a WELL-SEPARATED retrieval problem through the real loops: the trainer memorises SEP_N pairs (one minibatch,
+# SEP_EPOCHS Adam steps at SEP_LR), then evaluates them in batches of 8: every positive ends up far above every
+# negative, so R@K must be EXACTLY the reference's (no "one bucket flip" slack) --------------------------------------
+SEP_N, SEP_EPOCHS, SEP_LR = 24, 100, 5e-4
+
+
+class SepTrainLoader(SyntheticLoader):
+  """ONE minibatch of SEP_N pairs per epoch."""
+
+  def __init__(self):
+    super().__init__(iters=1, batch=SEP_N, seed=SEED + 500)
+
+
+class SepEvalLoader:
+  """The same SEP_N pairs as a validation loader: batches of 8, one caption per video, no caption masked."""
+
+  def __init__(self):
+    self.batch_size, self.dataset = 8, _EvalDataset()
+    mb, _ = synthetic.make_batch(SEED + 500, SEP_N, MODS, TOKENS, max_pos=VB['max_pos'])
+    self._mbs = []
+    for i in range(0, SEP_N, 8):
+      sl = slice(i, i + 8)
+      part = {k: (collections.OrderedDict((kk, vv[sl].clone()) for kk, vv in v.items()) if isinstance(v, dict) else v[sl].clone())
+              for k, v in mb.items()}
+      part['query_masks'] = np.ones((8, 1), dtype=np.float32)
+      part['raw_captions'] = [[np.array(['a', 'caption'])] for _ in range(8)]
+      part['paths'] = ['video%d' % (i + k) for k in range(8)]
+      self._mbs.append(part)
+
+  def __len__(self):
+    return len(self._mbs)
+
+  __iter__ = EvalLoader.__iter__
