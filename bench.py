@@ -30,7 +30,25 @@ from mmt_amd.feature_store import RaggedFeatures  # noqa: E402
 from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER = 32, 30, 512, 4, 4, 3072
+BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS = 32, 30, 512, 4, 4, 3072, 32
+# --config N = BASELINE.json configs[N] (single-GPU shapes; the default, 1, is the one the metric is quoted on)
+CONFIGS = {
+    1: dict(batch=32, tokens=30, hidden=512, layers=4, heads=4, inter=3072, max_pos=32,
+            name='configs[1]: MSRVTT jsfusion shape, 7 experts x 30 tokens, d512, L4, H4, I3072'),
+    3: dict(batch=32, tokens=100, hidden=512, layers=4, heads=4, inter=3072, max_pos=102,
+            name='configs[3]: ActivityNet-style long sequences, 7 experts x 100 tokens (S = 708), d512, L4, H4, I3072'),
+    4: dict(batch=128, tokens=30, hidden=1024, layers=6, heads=8, inter=6144, max_pos=32,
+            name='configs[4] (per-rank encoder step): HowTo100M-scale synthetic, 7 experts x 30 tokens, d1024, L6, H8, I6144'),
+}
+WORKLOAD = CONFIGS[1]['name']
+
+
+def select_config(n):
+  global BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS, WORKLOAD
+  c = CONFIGS[n]
+  BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS = (c[k] for k in ('batch', 'tokens', 'hidden', 'layers', 'heads',
+                                                                         'inter', 'max_pos'))
+  WORKLOAD = c['name']
 
 
 class SyntheticTextTower(torch.nn.Module):
@@ -48,7 +66,7 @@ class SyntheticTextTower(torch.nn.Module):
 
 
 def build_model(pack, dropout=0.1, text_tower='synthetic'):
-  vb = synthetic.vid_bert_params(hidden=HIDDEN, layers=LAYERS, heads=HEADS, inter=INTER, max_pos=32, dropout=dropout)
+  vb = synthetic.vid_bert_params(hidden=HIDDEN, layers=LAYERS, heads=HEADS, inter=INTER, max_pos=MAX_POS, dropout=dropout)
   return CENet(l2renorm=False, expert_dims=synthetic.compute_dims(synthetic.MSRVTT_MODALITIES), tokenizer=None,
                keep_missing_modalities=True, test_caption_mode='indep', txt_inp='bertftn', txt_agg='bertftn',
                txt_wgh='emb', vid_wgh='none', vid_cont='bert', vid_inp='both', pos_enc='tint', out_tok='mxp',
@@ -100,8 +118,8 @@ def pmc_traffic(kernel_subs, grid_sub):
   read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
   import csv
   path = os.path.join(ROOT, PMC_CSV)
-  if not os.path.exists(path):
-    return None
+  if not os.path.exists(path) or WORKLOAD != CONFIGS[1]['name']:
+    return None  # (the committed PMC passes are of the headline shape)
   with open(path) as f:
     for row in csv.DictReader(f):
       if any(k in row['kernel'] for k in kernel_subs) and grid_sub in row['kernel']:
@@ -110,6 +128,16 @@ def pmc_traffic(kernel_subs, grid_sub):
         except (KeyError, ValueError):
           return None
   return None
+
+
+def pmc_blob():
+  """git blob id of the PMC CSV the `traffic` figures come from (so a stale profile is visible in the JSON line)."""
+  import hashlib
+  path = os.path.join(ROOT, PMC_CSV)
+  if not os.path.exists(path):
+    return None
+  data = open(path, 'rb').read()
+  return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
 
 
 def site_roofline(site, rows, sec, used):
@@ -134,7 +162,8 @@ def site_roofline(site, rows, sec, used):
   return dict(kernel=name, bound='mfma', achieved=tf, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
               frac=tf / BF16_DENSE_PEAK_TFLOPS, flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes,
               hbm_frac_of_8TBps=nbytes / sec / 8e12, avg_launch_us=sec * 1e6, launches_timed=used,
-              traffic=pmc_traffic(subs, grid), traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV)
+              traffic=pmc_traffic(subs, grid), traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV,
+              traffic_source_git_blob=pmc_blob())
 
 
 def executed_flops_per_step(batch, live_rows, seq_lens_sq_sum, m_experts):
@@ -146,6 +175,36 @@ def executed_flops_per_step(batch, live_rows, seq_lens_sq_sum, m_experts):
   tail_rows = batch * m_experts
   last = live_rows * 6 * d * d + tail_rows * (2 * d * d + 4 * d * i) + 4 * tail_rows * (live_rows / batch) * d
   return 3.0 * ((LAYERS - 1) * full + last)
+
+
+def row_block_timing(b=8192, n=65536, m=7, d=1024, iters=3):
+  """configs[4], second half: one rank's row block of the 64k-pair similarity + max-margin loss (mmt_amd/large_sim.py:
+  8192 texts x 65536 videos, M = 7, d = 1024), forward + backward on this GPU, cross-rank quantities stood in by the
+  block's own (parity at this size: tests/test_large_sim_gpu.py)."""
+  from mmt_amd.large_sim import RowBlock
+  dev = torch.device('cuda', torch.cuda.current_device())
+  g = torch.Generator(device=dev).manual_seed(0)
+  nrm = lambda x: torch.nn.functional.normalize(x, dim=-1)
+  vid = nrm(torch.randn(n, m, d, device=dev, generator=g))
+  txt = nrm(torch.randn(b, m, d, device=dev, generator=g) + 0.3 * vid[:b])
+  tw = torch.softmax(torch.randn(b, m, device=dev, generator=g), -1)
+  vw = torch.full((n, m), 1.0 / m, device=dev)
+  best = None
+  for _ in range(iters):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    blk = RowBlock(txt, tw, vid, vw, 0, 0.05)
+    diag = torch.zeros(n, device=dev)
+    diag[:b] = blk.phase_similarity()
+    colcnt, loss = blk.phase_counts(diag)
+    dtxt, dtw, q = blk.phase_backward(colcnt)
+    blk.phase_video_grad(q[:b], vid[:b], vw[:b])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+  flops = 3 * 2.0 * b * n * m * d
+  return dict(rows=b, cols=n, experts=m, dim=d, ms_fwd_bwd=best * 1e3, gemm_tflops=flops / best / 1e12,
+              mfma_frac=flops / best / 1e12 / BF16_DENSE_PEAK_TFLOPS, loss=float(loss.item()))
 
 
 def cpu_baseline(steps=6):
@@ -227,6 +286,9 @@ def spawn_ranks(n):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--config', type=int, choices=sorted(CONFIGS), default=1,
+                  help='BASELINE.json configs[N]: 1 = the headline MSRVTT shape (default), 3 = long sequences (S = 708), '
+                       '4 = the d1024 / L6 encoder at batch 128 per rank (+ one rank\'s 8192 x 65536 similarity / loss row block)')
   ap.add_argument('--steps', type=int, default=50)
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--dense', action='store_true', help='keep padded tokens (no variable-length packing)')
@@ -260,6 +322,9 @@ def main():
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
+  select_config(args.config)
+  if args.config != 1:
+    args.no_cpu_baseline = True  # the CPU port is timed on the headline shape only (a bounded sample of THAT workload)
   if args.ragged_inputs:
     if args.dense:
       ap.error('--ragged-inputs carries live rows only: it cannot feed the dense (unpacked) step')
@@ -302,10 +367,10 @@ def main():
 
   # NBATCH different synthetic minibatches resident in HBM; each step copies one (device-to-device) into
   # the static input buffers of the captured graphs.
-  NBATCH = 16
+  NBATCH = 16 if args.config == 1 else 4
   batches, input_bytes = [], []
   for i in range(NBATCH):
-    mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS)
+    mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS, max_pos=MAX_POS)
     mb['text'] = text.view(-1, 768)
     if args.ragged_inputs:
       rag = RaggedFeatures.from_dense(mb['features'], mb['features_t'], mb['features_ind'], mb['features_maxpool'],
@@ -419,12 +484,11 @@ def main():
     rows = live if not args.dense else dense_rows
     executed = executed_flops_per_step(BATCH, rows, sum(sq_sums) / len(sq_sums), len(synthetic.MSRVTT_MODALITIES))
     out = {
-        'metric': 'video-text pairs/sec (fwd+bwd+Adam), MSRVTT 7-expert d512 L4', 'value': pairs_per_s,
+        'metric': 'video-text pairs/sec (fwd+bwd+Adam), MSRVTT 7-expert d%d L%d' % (HIDDEN, LAYERS), 'value': pairs_per_s,
         'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: MSRVTT jsfusion shape, 7 experts x 30 tokens, d512, L4, H4, I3072, '
-                               'batch 32/GPU, dropout 0.1, train mode, Adam; ' +
+        'config': {'workload': WORKLOAD + ', batch %d/GPU, dropout 0.1, train mode, Adam; ' % BATCH +
                                ('text tower replaced by synthetic (B,768) vectors' if args.text_tower == 'synthetic' else
                                 'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
                    'global_batch': world * BATCH, 'seq_len': seq,
@@ -463,6 +527,8 @@ def main():
       out['roofline_top3'] = tops
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
+    if args.config == 4:
+      out['similarity_loss_row_block'] = row_block_timing()
     # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise come out at
     # exit, AFTER the result: flush it first so that the JSON line is the last line of stdout
     try:

@@ -262,6 +262,38 @@ def max_margin_ranking_loss(x, margin=0.05, fix_norm=True):
   return h.sum() / (2.0 * n * n)
 
 
+def cross_view_rows(txt_rows, tw_rows, vid_all, vw_all):
+  """model/model.py:789-837 for a SUBSET of the text rows against every video (one caption per video):
+  txt_rows (r, M, d), tw_rows (r, M), vid_all (n, M, d), vw_all (n, M) -> (r, n).  Same arithmetic as
+  cross_view_inner_product, without the square-batch assumption -- for sampled-row checks of matrices too large to form."""
+  moe = tw_rows[:, None, :] * vid_all.new_tensor(1.0) * vw_all[None, :, :]                     # :810
+  norm = moe.sum(-1, keepdim=True)
+  norm = torch.where(norm == 0, torch.full_like(norm, 1e-5), norm)                            # :816
+  dots = torch.stack([txt_rows[:, m] @ vid_all[:, m].t() for m in range(txt_rows.shape[1])], -1)   # (r, n, M)
+  return ((moe / norm) * dots).sum(-1)
+
+
+def max_margin_rows(s_rows, row_ids, diag_all, margin, n_total, col_hinge_counts=None, fix_norm=True):
+  """model/loss.py:38-65 restricted to the text rows `row_ids` of an n x n similarity matrix (fix_norm=True):
+  entry (R, c), c != R, contributes relu(m - s_RR + s_Rc) [row R's hinge] + relu(m - s_cc + s_Rc) [column c's hinge].
+  s_rows (r, n); diag_all (n) = s_jj.  -> (loss contribution of these rows, d loss / d s_rows) with the diagonal entry's
+  gradient -(#active row hinges of R + col_hinge_counts[i]) / norm, col_hinge_counts[i] = #active column hinges
+  relu(m - s_RR + s_r'R) over the OTHER rows r' (they live outside s_rows; 0 if not given)."""
+  assert fix_norm
+  r, n = s_rows.shape
+  norm = 2.0 * n_total * (n_total - 1)
+  off = torch.ones_like(s_rows)
+  off[torch.arange(r), row_ids] = 0.0
+  a_row = (margin - diag_all[row_ids][:, None] + s_rows) * off
+  a_col = (margin - diag_all[None, :] + s_rows) * off
+  loss = (torch.relu(a_row) + torch.relu(a_col)).sum(1) / norm
+  g = ((a_row > 0).to(s_rows.dtype) + (a_col > 0).to(s_rows.dtype)) * off / norm
+  rowcnt = (a_row > 0).sum(1)
+  cc = torch.zeros_like(rowcnt) if col_hinge_counts is None else col_hinge_counts
+  g[torch.arange(r), row_ids] = -(rowcnt + cc).to(s_rows.dtype) / norm
+  return loss, g, rowcnt
+
+
 def info_nce_loss(x):
   """model/loss.py:68-81."""
   t = torch.arange(x.shape[0])
