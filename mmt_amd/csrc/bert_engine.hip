@@ -58,10 +58,8 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     L.h32 = (float*)take(R * d * 4); L.h16 = take(R * d * 2);
   }
   w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
-  for (int p = 0; p < 2; ++p) {
-    w->dy_[p] = take(R * d * 2); w->dy2_[p] = take(R * d * 2); w->dhpre_[p] = take(R * I * 2); w->dqkv_[p] = take(R * 3 * d * 2);
-  }
-  w->dctx = take(R * d * 2);
+  w->dy_[0] = take(R * d * 2); w->dy2_[0] = take(R * d * 2); w->dhpre_[0] = take(R * I * 2); w->dctx = take(R * d * 2);
+  w->dqkv_[0] = take(R * 3 * d * 2);
   w->delta = (float*)take(R * H * 4);
   size_t ln_nb = ((size_t)R + 15) / 16;  // blocks of mmt_ln_bwd: rows/16, or rows/4 when rows <= 2048
   const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
@@ -84,6 +82,9 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     t.slabs = (float*)take((size_t)mmt_gemm_nt_splitk_workspace_floats((int)C, (int)d, (int)I) * 4);
   }
   for (int i = 0; i < 2; ++i) w->table_scratch[i] = (float*)take((size_t)mmt_table_grad_scratch_floats(vmax, (int)d) * 4);
+  // second set of the weight-gradient operands (odd layers under MMT_FORK_WGRAD), behind everything else: the buffers of
+  // the serial path keep the addresses (and the cache-set relationships) they had before forking existed
+  w->dy_[1] = take(R * d * 2); w->dy2_[1] = take(R * d * 2); w->dhpre_[1] = take(R * I * 2); w->dqkv_[1] = take(R * 3 * d * 2);
   w->bytes = off;
 }
 
@@ -315,7 +316,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
-    const int par = l & 1;
+    const int par = fork_w ? (l & 1) : 0;  // one set unless weight gradients may still be running from two layers up
     char *dy = w.dy_[par], *dy2 = w.dy2_[par], *dhpre = w.dhpre_[par], *dqkv = w.dqkv_[par];
     // the weight gradients of layer l + 2 read the buffers this layer is about to overwrite (only an issue when they
     // were forked and not joined since: with MMT_FORK_JOIN every range call ends with the side stream drained)

@@ -479,6 +479,306 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   }
 }
 
+// Transpose reads issued from inline asm.  The compiler cannot tell an LDS-DMA write from the LDS location a transpose
+// read touches and drains vmcnt to ZERO in front of every builtin ds_read_tr that follows a global_load_lds -- i.e. it
+// waits for the prefetches of later units as well.  Issued this way the reads are invisible to that analysis; the price
+// is that their completion has to be waited for by hand (TR_WAIT ties the loaded registers to the s_waitcnt so that no
+// consumer can be scheduled above it).
+// Both halves of one fragment (rows r0 and r0 + 16 of the same 16-byte chunk: the swizzle repeats every 8 rows, so the
+// second read is the first one's address + 16 rows = 4096 bytes, an instruction immediate).
+__device__ __forceinline__ void tr_frag_issue(u32x2& lo, u32x2& hi, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(addr));
+}
+// LDS byte offset (inside a [64][128] bf16 tile) of the first half of the fragment for columns colbase .. colbase + 15,
+// k-sub-step ks.  Fragments 16 columns further on are this offset XOR 32 per step (two 16-byte chunks: the chunk index is
+// XOR-swizzled, and colbase only sets bits the swizzle leaves alone in a multiple of 64).
+__device__ __forceinline__ unsigned tr_frag_offset(int ks, int colbase, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  const int col = colbase + 4 * (t & 3);
+  const int r0 = ks * 32 + 4 * g + (t >> 2);
+  const int ch = col >> 3, w = col & 7;
+  return (unsigned)((r0 * 128 + ((ch ^ ((r0 & 7) << 1)) << 3) + w) * 2);
+}
+#define TR_TIE4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+__device__ __forceinline__ bf16x8_t tr_join(const u32x2& lo, const u32x2& hi) {
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The same grouped weight gradients with the two wave groups in OPPOSITE phase and 64 x 128 wave tiles (default; the
+// lock-step kernel above stays for same-box A/B, MMT_WGRAD_LOCKSTEP=1).
+//   * The 64-row units of the contraction alternate between the groups: unit u belongs to group u & 1 and lives in stage
+//     u & 3 of ONE four-deep ring.  In half-step h, group h & 1 runs the transpose reads + MFMAs of unit h while the other
+//     group issues the LDS-DMA loads of unit h + 3 (its own next but one): the ~90 cycles a global_load_lds stalls its wave
+//     at issue hide under the other group's MFMAs, loads have two half-steps to land (counted vmcnt: a group waits for
+//     its OWN loads), and one workgroup barrier per half-step orders both hazards (unit h has landed; the stage of unit
+//     h - 1 is free).
+//   * What then bounds a half-step is LDS read bandwidth: ds_read_b64_tr_b16 delivers ~64 B/clk/CU, and four 64 x 64 wave
+//     tiles read 64 KiB per unit (measured 1620 cycles per unit against 544 cycles of MFMA, tools/wgrad_instr.py).  The
+//     four waves of a group therefore split the unit 2 (32-row halves = the two k-sub-steps) x 2 (halves of the tile's
+//     128 dW rows): a wave computes 64 x 128 outputs over 32 rows from 4 + 8 fragments (48 KiB per unit, -25 %), at the
+//     price of four partial tiles per output (2 groups x 2 row halves) summed through LDS at the end, in a fixed order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+#ifdef MMT_GEMM2_INSTR
+  const long long t_entry = clock64();
+#endif
+  bf16_t* smem = (bf16_t*)wg_smem;  // ring: 4 units x [A 64x128 | B 64x128]
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < g.count; ++q)
+    if (id >= g.item[q].tile_begin) p = q;
+  const MmtWgradItem& it = g.item[p];
+  const bf16_t* __restrict__ A = (const bf16_t*)it.A;
+  const bf16_t* __restrict__ B = (const bf16_t*)it.B;
+  const int64_t lda = it.lda, ldb = it.ldb;
+  const int nsplit = it.splits > 1 ? it.splits : 1;
+  const int tile = (id - it.tile_begin) / nsplit, split = (id - it.tile_begin) % nsplit;
+  const int tiles_k = it.K2 / 128;
+  int tn, tk;
+  {
+    const int PN = it.reserved2 >> 16, PK = it.reserved2 & 0xffff;  // XCD-sized patches, see the lock-step kernel
+    if (PN > 0 && PK > 0) {
+      const int per = PN * PK, patches_k = tiles_k / PK;
+      const int patch = tile / per, within = tile % per;
+      tn = (patch / patches_k) * PN + within / PK;
+      tk = (patch % patches_k) * PK + within % PK;
+    } else {
+      tn = tile / tiles_k;
+      tk = tile % tiles_k;
+    }
+  }
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int nrows = it.reserved > 0 ? it.reserved
+                    : it.n_rows_dev ? min(*it.n_rows_dev, g.rows)
+                                    : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
+  const int units_all = (nrows + 63) / 64;
+  const int per_split = (units_all + nsplit - 1) / nsplit;
+  const int u0 = split * per_split;
+  const int units = max(0, min(units_all, u0 + per_split) - u0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int kg = wave8 >> 2, wave = wave8 & 3;
+  const int wk = wave >> 1, wt = wave & 1;  // row half of the unit (k-sub-step), half of the tile's 128 dW rows
+  const int li = lane & 15, lg = lane >> 4;
+  const bool want_bias = it.bias_out != nullptr && tk == 0;
+  f32x4 acc[4][8], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  constexpr int GSTAGE = 2 * 64 * 128;  // one unit's [A | B] tiles
+
+  auto issue = [&](int u) {  // by the four waves of group u & 1
+    if (u < units) {
+      bf16_t* base = smem + (u & 3) * GSTAGE;
+      stage_tn(A, lda, (u0 + u) * 64, n0, base, wave, lane);
+      stage_tn(B, ldb, (u0 + u) * 64, k0, base + 64 * 128, wave, lane);
+    }
+  };
+  if (kg == 0) { issue(0); issue(2); } else { issue(1); }
+  const unsigned aoff = tr_frag_offset(wk, wt * 64, lane), boff = tr_frag_offset(wk, 0, lane);
+#ifdef MMT_GEMM2_INSTR
+  long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, t0 = clock64(), tp = t0;
+#endif
+  for (int h = 0; h < units; ++h) {
+    const bool mine = (h & 1) == kg;
+    WTICK(t_comp);  // (loop overhead + the tail of the previous half-step)
+    if (mine) {
+      // outstanding loads of this wave: unit h and (issued one half-step ago) unit h + 2, eight instructions each
+      if (h + 2 < units) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" ::: "memory");
+    WTICK(t_wait);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WTICK(t_bar);
+    bf16_t* at = smem + (h & 3) * GSTAGE;
+    bf16_t* bt = at + 64 * 128;
+    const int live = nrows - (u0 + h) * 64;  // rows of unit h that exist (> 0)
+    if (live < 64) {  // ragged last unit (block-uniform): its group zeroes the dead rows of both operands
+      if (mine) {
+        for (int e = wave * 64 + lane; e < (64 - live) * 32; e += 256) {
+          const int r = live + e / 32, q = e % 32;
+          u32x4 z = {0, 0, 0, 0};
+          if (q < 16) *(u32x4*)(at + r * 128 + q * 8) = z;
+          else *(u32x4*)(bt + r * 128 + (q - 16) * 8) = z;
+        }
+      }
+      __syncthreads();
+    }
+    if (!mine) {
+      issue(h + 3);
+      WTICK(t_issue);
+      continue;
+    }
+    // transpose reads: the 4 A fragments and the first two PAIRS of B fragments go out at once; after that each pair's
+    // MFMAs run under the reads of the pair after next (in-order returns: "at most 4 outstanding" = this pair has landed).
+    // One base address per operand; every fragment's address is that XOR a constant, formed right at the read (the asm
+    // barrier keeps the compiler from hoisting 24 loop-invariant addresses into registers the accumulators need).
+    u32x2 alo[4], ahi[4], blo[4][2], bhi[4][2];
+    unsigned abase = (unsigned)(uintptr_t)LDS_PTR(at) + aoff, bbase = (unsigned)(uintptr_t)LDS_PTR(bt) + boff;
+    asm volatile("" : "+v"(abase), "+v"(bbase));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tr_frag_issue(alo[i], ahi[i], abase ^ (unsigned)(i << 5));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) tr_frag_issue(blo[q][jj], bhi[q][jj], bbase ^ (unsigned)((2 * q + jj) << 5));
+    bf16x8_t af[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == 0) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : TR_TIE4(alo), TR_TIE4(ahi), "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = tr_join(alo[i], ahi[i]);
+      } else if (q < 3) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(blo[q][0]), "+v"(bhi[q][0]), "+v"(blo[q][1]), "+v"(bhi[q][1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[q][0]), "+v"(bhi[q][0]), "+v"(blo[q][1]), "+v"(bhi[q][1]));
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * q + jj;
+        const bf16x8_t bfr = tr_join(blo[q][jj], bhi[q][jj]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[i], acc[i][j], 0, 0, 0);
+      }
+      if (q + 2 < 4) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) tr_frag_issue(blo[q + 2][jj], bhi[q + 2][jj], bbase ^ (unsigned)((2 * (q + 2) + jj) << 5));
+      }
+      if (q == 0 && want_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MMT_GEMM2_INSTR
+  asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[3][7][3]));
+  WTICK(t_comp);
+  const long long t_loop_end = clock64();
+  if (g_wgrad_dbg && (tid == 0 || tid == 256)) {  // wave 0 of either group
+    long long* d = g_wgrad_dbg + ((int64_t)blockIdx.x * 2 + kg) * 8;
+    d[0] = t_wait; d[1] = t_bar; d[2] = t_issue; d[3] = t_comp; d[4] = t_loop_end - t0; d[5] = units; d[6] = t0 - t_entry; d[7] = t_entry;
+  }
+#endif
+  // ---- four partial tiles per output (group x row half), summed by two pairwise EXCHANGES through LDS so that all
+  // eight waves stay busy and each ends up storing one eighth of the tile:
+  //   round 1, (g, k0) <-> (g, k1): the k0 wave keeps dW rows i = 0, 1 of its 64, the k1 wave rows i = 2, 3;
+  //   round 2, (0, k) <-> (1, k): the group-0 wave keeps columns j = 0..3, the group-1 wave j = 4..7.
+  // Every output is (P00 + P01) + (P10 + P11) (fp32 addition commutes): deterministic, the same order everywhere. ----
+  f32x4* xch = (f32x4*)wg_smem;  // round 1: 2 regions x [18][256] f32x4 = 144 KiB; round 2: 2 x [10][256]
+  __syncthreads();
+  {
+    const int pid = (kg * 2 + wt) * 64 + lane;
+    f32x4* to_k0 = xch;                 // written by the k1 waves: rows i = 0, 1 (+ their bias sums)
+    f32x4* to_k1 = xch + 18 * 256;      // written by the k0 waves: rows i = 2, 3
+    if (wk == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) to_k1[(ii * 8 + j) * 256 + pid] = acc[2 + ii][j];
+        to_k1[(16 + ii) * 256 + pid] = accb[2 + ii];
+      }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) to_k0[(ii * 8 + j) * 256 + pid] = acc[ii][j];
+        to_k0[(16 + ii) * 256 + pid] = accb[ii];
+      }
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ii][j] += to_k0[(ii * 8 + j) * 256 + pid];
+        accb[ii] += to_k0[(16 + ii) * 256 + pid];
+      }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {  // (kept in slots 0, 1 from here on: slot ii = row i = 2 + ii)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ii][j] = acc[2 + ii][j] + to_k1[(ii * 8 + j) * 256 + pid];
+        accb[ii] = accb[2 + ii] + to_k1[(16 + ii) * 256 + pid];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int pid = (wk * 2 + wt) * 64 + lane;
+    f32x4* to_g0 = xch;                 // written by the group-1 waves: columns j = 0..3 (+ bias sums)
+    f32x4* to_g1 = xch + 10 * 256;      // written by the group-0 waves: columns j = 4..7
+    if (kg == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) to_g1[(ii * 4 + jj) * 256 + pid] = acc[ii][4 + jj];
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) to_g0[(ii * 4 + jj) * 256 + pid] = acc[ii][jj];
+        to_g0[(8 + ii) * 256 + pid] = accb[ii];
+      }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += to_g0[(ii * 4 + jj) * 256 + pid];
+        accb[ii] += to_g0[(8 + ii) * 256 + pid];
+      }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = acc[ii][4 + jj] + to_g1[(ii * 4 + jj) * 256 + pid];
+    }
+  }
+  // this wave now holds rows i = 2 wk + ii (ii = 0, 1), columns j = 4 kg + jj (jj = 0..3) in acc[ii][jj]
+  float* __restrict__ out = nsplit > 1 ? it.slab + (int64_t)split * it.N_out * it.ldo : it.out;
+  float* __restrict__ bias_out = nsplit > 1 ? (it.bias_slab ? it.bias_slab + (int64_t)split * it.N_out : nullptr) : it.bias_out;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int n = n0 + wt * 64 + (2 * wk + ii) * 16 + li;
+    if (n >= it.N_out) continue;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int k2 = k0 + (4 * kg + jj) * 16 + lg * 4;
+      if (k2 + 3 < it.K2_out && !(it.ldo & 3)) {
+        *(f32x4*)(out + (int64_t)n * it.ldo + k2) = acc[ii][jj];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k2 + e < it.K2_out) out[(int64_t)n * it.ldo + k2 + e] = acc[ii][jj][e];
+      }
+    }
+    if (want_bias && kg == 0 && lg == 0) bias_out[n] = accb[ii][0];
+  }
+#ifdef MMT_GEMM2_INSTR
+  if (g_wgrad_dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left the wave
+    g_wgrad_dbg[((int64_t)blockIdx.x * 2 + 1) * 8 + 7] = clock64() - t_loop_end;  // epilogue cycles (reduction + stores)
+  }
+#endif
+}
+
 extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
   if (!g || g->count <= 0 || g->count > MMT_WGRAD_MAX || g->rows <= 0) return MMT_ERR_ARG;
   MmtWgradGroup h = *g;
@@ -505,14 +805,19 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
       it.reserved2 = (pn << 16) | pk;
     }
   }
-  constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;  // 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
-  static bool configured = false;
-  if (!configured) {
+  constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;   // lock-step: 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
+  constexpr int lds_phased = 36 * 256 * 16;       // phased: the same 128 KiB ring; 144 KiB for the final exchange
+  static int lockstep = -1;
+  if (lockstep < 0) {
     hipError_t rc = hipFuncSetAttribute((const void*)wgrad_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)wgrad_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_phased);
     if (rc != hipSuccess) return (int)rc;
-    configured = true;
+    const char* e = getenv("MMT_WGRAD_LOCKSTEP");
+    lockstep = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, h);
+  if (lockstep) hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, h);
+  else hipLaunchKernelGGL(wgrad_phased_kernel, dim3(tiles), dim3(512), lds_phased, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }
 
