@@ -887,6 +887,22 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
   //   * short batches (M <= 1024: the text tower's ~560..960 token rows): too few 128x128 tiles for 256 CUs; the
   //     128x64 8-wave tile wins everywhere (tools/gemm_lab.py --text: 10.3 vs 13.2 us FFN-up at 560 live rows).
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  // lab switches (same-box A/B): MMT_TILE_NARROW = tile for the packed N < 1024 GEMMs, MMT_TILE_WIDE = tile for N >= 1024
+  static int narrow = -1, wide = -1;
+  if (narrow < 0) {
+    const char* a = getenv("MMT_TILE_NARROW");
+    const char* b = getenv("MMT_TILE_WIDE");
+    // r03: the phased 128x64 tile (two 4-wave groups on alternate K-steps, gemm2.hip tile 18) replaces the 8-wave spatial
+    // split for the packed narrow GEMMs: step 1.397 -> 1.385 ms same box; K-loop 61.8k -> 52.0k cycles at two blocks per
+    // CU (dense rows), 49.5k -> 52.0k at one (what bounds both is the ~22-30 B/clk a CU ingests: 24 KiB per K-step of a
+    // 128x64 tile -- tools/gemm_instr.py).  MMT_TILE_NARROW=13 restores the r02 tile.
+    narrow = a ? atoi(a) : 18;
+    wide = b ? atoi(b) : 0;
+  }
+  if (e.reserved == 0 && M > 1024 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
+    if (narrow && N < 1024 && nr != nullptr) return mmt_gemm2_dispatch(narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
   if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
     const int t = wide192_tile(M, N, nr != nullptr);
     if (t) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

@@ -99,12 +99,20 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
+// PH ("phased"): TWO groups of WGM x WGN waves, each covering the whole BM x BN tile, take ALTERNATE K-steps (K-step kt
+// belongs to group kt & 1 and lives in stage kt % 4 of one four-deep ring): in half-step h group h & 1 runs the fragment
+// reads + MFMAs of K-step h while the other group issues the LDS-DMA loads of its own K-step h + 3 -- the scheme of the
+// weight-gradient kernel (gemm.hip: wgrad_phased_kernel).  Against the spatial split over 8 waves it doubles the wave
+// tile (half the LDS bytes per MAC), halves the barriers per MAC, and hides the ~90 cycles every LDS-DMA instruction
+// stalls its wave under the partner wave's MFMAs; the price is one LDS round trip of a partial tile at the end.
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false, bool PH = false>
 __device__ __forceinline__ void gemm2_body(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, const MmtEpilogue& epi,
     const int32_t* __restrict__ n_rows_dev, const int bid, const int nblk) {
-  constexpr int NW = WGM * WGN, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
+  constexpr int GW = WGM * WGN;  // waves that tile the output once
+  constexpr int NW = PH ? 2 * GW : GW, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
+  static_assert(!PH || NS == 4, "the phased loop runs on a four-deep ring");
   constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
   // the epilogue sweeps the image in column blocks of CB columns: the whole width when the thread count divides into
   // whole rows of it, 64-column blocks otherwise (BN = 192: 3 blocks of 16 lanes x 16 B per row)
@@ -117,7 +125,7 @@ __device__ __forceinline__ void gemm2_body(
   // 8-wave blocks run as two groups in opposite phase (waves w and w+4 share a SIMD): group 0 issues the next
   // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
   // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
-  constexpr bool STAG = NW == 8 && NS >= 3;
+  constexpr bool STAG = !PH && NW == 8 && NS >= 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;
 
@@ -156,7 +164,9 @@ __device__ __forceinline__ void gemm2_body(
     tn = id % tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave8 = tid >> 6;
+  const int kg = PH ? wave8 / GW : 0;           // group (phased mode)
+  const int wave = PH ? wave8 % GW : wave8;     // wave inside its group
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
   const bool late_issue = STAG && wave >= NW / 2;
@@ -170,11 +180,22 @@ __device__ __forceinline__ void gemm2_body(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   constexpr int STAGE = (BM + BN) * BK;
-  constexpr int L = (BM + BN) / 8 / NW;  // LDS-DMA instructions per wave per stage
+  constexpr int L = (BM + BN) / 8 / (PH ? GW : NW);  // LDS-DMA instructions per wave per stage
   const int KT = K / BK;
   const int amax = M - 1, bmax = N - 1;
   // NS-deep LDS ring, counted vmcnt: stage kt+NS-1 is issued while stage kt is consumed and the DMA queue is never
   // drained inside the loop (raw s_barrier -- __syncthreads() would add vmcnt(0), cdna guide section 5).
+  auto issue_ph = [&](int kt) {  // phased mode: the four waves of group kt & 1 load K-step kt
+    if (kt < KT) {
+      bf16_t* base = smem + (kt & 3) * STAGE;
+      stage2<BM, GW>(A, lda, m0, amax, kt * BK, base, wave, lane);
+      if constexpr (BKN) stage2_kn<BN, GW>(B, ldb, kt * BK, n0, base + BM * BK, wave, lane);
+      else stage2<BN, GW>(B, ldb, n0, bmax, kt * BK, base + BM * BK, wave, lane);
+    }
+  };
+  if constexpr (PH) {
+    if (kg == 0) { issue_ph(0); issue_ph(2); } else { issue_ph(1); }
+  } else {
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < KT) {
@@ -182,6 +203,7 @@ __device__ __forceinline__ void gemm2_body(
       if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, s0 * BK, n0, smem + s0 * STAGE + BM * BK, wave, lane);
       else stage2<BN, NW>(B, ldb, n0, bmax, s0 * BK, smem + s0 * STAGE + BM * BK, wave, lane);
     }
+  }
   // per-lane LDS offsets of this wave's fragments (row r, 16-byte chunk c lives at chunk c ^ ((r>>1)&7))
   int aoff[MI], boff[NJ], asw[MI], bsw[NJ];
 #pragma unroll
@@ -202,6 +224,26 @@ __device__ __forceinline__ void gemm2_body(
 #define TICK(acc) do {} while (0)
 #endif
   for (int kt = 0; kt < KT; ++kt) {
+    bool do_issue = false;
+    int nxt = 0;
+    if constexpr (PH) {
+      const bool mine = (kt & 1) == kg;
+      if (mine) {  // outstanding loads of this wave: K-step kt and (issued one half-step ago) kt + 2, L instructions each
+        if (kt + 2 < KT) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+      }
+      TICK(t_wait);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      TICK(t_bar);
+      cur = kt & 3;
+      if (!mine) {
+        issue_ph(kt + 3);
+        TICK(t_issue);
+        continue;
+      }
+    } else {
     const int ahead = min(KT - kt - 1, NS - 2);  // stages issued after kt that may stay in flight
     if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
@@ -210,9 +252,10 @@ __device__ __forceinline__ void gemm2_body(
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     TICK(t_bar);
-    int nxt = cur + NS - 1;
+    nxt = cur + NS - 1;
     if (nxt >= NS) nxt -= NS;
-    const bool do_issue = kt + NS - 1 < KT;
+    do_issue = kt + NS - 1 < KT;
+    }
     if (do_issue && !late_issue) {
       stage2<BM, NW>(A, lda, m0, amax, (kt + NS - 1) * BK, smem + nxt * STAGE, wave, lane);
       if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, (kt + NS - 1) * BK, n0, smem + nxt * STAGE + BM * BK, wave, lane);
@@ -220,6 +263,52 @@ __device__ __forceinline__ void gemm2_body(
     }
     TICK(t_issue);
     const bf16_t* st = smem + cur * STAGE;
+    if constexpr (PH) {
+      // One wave per SIMD computes here, so nothing else covers LDS latency: ALL fragment reads of the K-step go out first
+      // and the MFMAs of k-sub-step kk wait only for ITS fragments (in-order returns).  The reads are inline asm -- left to
+      // the compiler, each read is sunk in front of its MFMA (a full LDS round trip per MFMA) or all are waited for at
+      // once -- and a fragment's address for sub-step kk is the sub-step-0 address XOR 32 kk (chunk index bits 1-2).
+      static_assert(!BKN, "phased mode: NT operand form");
+      u32x4 pa[4][MI], pb[4][NJ];
+      unsigned abase[MI], bbase[NJ];
+      const unsigned sbase = (unsigned)(uintptr_t)LDS_PTR(st);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) abase[i] = sbase + (unsigned)(aoff[i] * 2) + (unsigned)((lh ^ asw[i]) << 4);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bbase[j] = sbase + (unsigned)(boff[j] * 2) + (unsigned)((lh ^ bsw[j]) << 4);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(pa[kk][i]) : "v"(abase[i] ^ (unsigned)(kk << 5)));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(pb[kk][j]) : "v"(bbase[j] ^ (unsigned)(kk << 5)));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // (MI + NJ) reads per sub-step: sub-step kk has landed when at most (3 - kk) (MI + NJ) are outstanding
+        constexpr int PER = MI + NJ;
+        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * PER) : "memory");
+        if (kk == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PER) : "memory");
+        if (kk == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(1 * PER) : "memory");
+        if (kk == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(pa[kk][i]));  // consumers stay below the wait
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(pb[kk][j]));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pb[kk][j]),
+                                                                __builtin_bit_cast(bf16x8_t, pa[kk][i]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // (or the scheduler sinks these MFMAs below the later waits)
+      }
+#ifdef MMT_GEMM2_INSTR
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[MI - 1][NJ - 1][15]));
+#endif
+      TICK(t_comp);
+      continue;
+    }
     // fragment reads software-pipelined one k-substep ahead of the MFMAs that consume them
     bf16x8_t af[2][MI], bfr[2][NJ];
 #pragma unroll
@@ -252,12 +341,13 @@ __device__ __forceinline__ void gemm2_body(
       if constexpr (BKN) stage2_kn<BN, NW>(B, ldb, (kt + NS - 1) * BK, n0, smem + nxt * STAGE + BM * BK, wave, lane);
       else stage2<BN, NW>(B, ldb, n0, bmax, (kt + NS - 1) * BK, smem + nxt * STAGE + BM * BK, wave, lane);
     }
-    cur = cur + 1 == NS ? 0 : cur + 1;
+    if constexpr (!PH) cur = cur + 1 == NS ? 0 : cur + 1;
 #ifdef MMT_GEMM2_INSTR
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[MI - 1][NJ - 1][15]));
 #endif
     TICK(t_comp);
   }
+  if constexpr (PH) wait_vmcnt<0>();
 #ifdef MMT_GEMM2_INSTR
   const long long t_loop_end = clock64();
 #endif
@@ -282,7 +372,7 @@ __device__ __forceinline__ void gemm2_body(
   __syncthreads();  // every wave is done with the stage buffers
 #pragma unroll
   for (int ch = 0; ch < BM / CH; ++ch) {
-    if ((wm * WTM) / CH == ch) {  // this wave's rows belong to chunk ch
+    if ((wm * WTM) / CH == ch && kg == 0) {  // this wave's rows belong to chunk ch
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -292,6 +382,22 @@ __device__ __forceinline__ void gemm2_body(
             f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
             *(f32x4*)(st + ((wm * WTM) % CH + i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh) = v;
           }
+    }
+    if constexpr (PH) {  // the other group's partial tile (odd K-steps) is added into the image: even + odd, fixed order
+      __syncthreads();
+      if ((wm * WTM) / CH == ch && kg == 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float* dst = st + ((wm * WTM) % CH + i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh;
+              f32x4 v = *(const f32x4*)dst;
+              v += (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *(f32x4*)dst = v;
+            }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -375,13 +481,13 @@ __device__ __forceinline__ void gemm2_body(
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm2_kernel(
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false, bool PH = false>
+__global__ __launch_bounds__((PH ? 2 : 1) * WGM * WGN * 64) void gemm2_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
     void* __restrict__ Cout, int64_t ldc, int M, int N, int K, MmtEpilogue epi,
     const int32_t* __restrict__ n_rows_dev) {
-  gemm2_body<BM, BN, WGM, WGN, NS, EPI, BKN>(A, lda, B, ldb, Cout, ldc, M, N, K, epi, n_rows_dev, (int)blockIdx.x,
-                                             (int)gridDim.x);
+  gemm2_body<BM, BN, WGM, WGN, NS, EPI, BKN, PH>(A, lda, B, ldb, Cout, ldc, M, N, K, epi, n_rows_dev, (int)blockIdx.x,
+                                                 (int)gridDim.x);
 }
 
 // Split-K for skinny problems (few output tiles, long K: the last layer's read-out rows): blockIdx.y = K-slice, every
@@ -595,10 +701,10 @@ extern "C" int mmt_gemm_nt_grouped(const MmtGemmItem* items, int n, int epilogue
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false>
+template <int BM, int BN, int WGM, int WGN, int NS, int EPI, bool BKN = false, bool PH = false>
 static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-  constexpr int NT = WGM * WGN * 64;
+  constexpr int NT = (PH ? 2 : 1) * WGM * WGN * 64;
   constexpr int CB = (NT * 4) % BN == 0 ? BN : 64;
   constexpr int RG = NT / (CB / 4);
   constexpr int CH = BM < 64 ? BM : 64;
@@ -609,13 +715,13 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static bool configured = false;
   if (!configured) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN>,
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN, PH>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
   const int grid = ((M + BM - 1) / BM) * (N / BN);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN, PH>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
@@ -640,6 +746,12 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
                                                               // <= 4096 live rows is ONE round of <= 256 tiles
     case 16: if (N % 192 == 0) G2(128, 192, 4, 2, 3); break;  // 8 waves on 128x192 (wave 32x96), staggered
     case 17: if (N % 192 == 0) G2(128, 192, 2, 2, 3); break;  // 4 waves on 128x192 (wave 64x96)
+    case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
+      if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      break;
+    case 19:  // 2 x 4 waves on 128x128, PHASED (wave tile 64x64)
+      if (N % 128 == 0) return launch2<128, 128, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      break;
   }
 #undef G2
   return MMT_ERR_ARG;

@@ -32,7 +32,8 @@ def run(rows, N, K, tile, epi='F32'):
         (rows, N, K, tile, d.shape[0], kt, m[0] / kt, m[1] / kt, m[2] / kt, m[3] / kt, m[4], m[5], span))
 
 
+tiles = [int(t) for t in sys.argv[1:]] or [5, 7, 3, 11, 12, 13, 18]
 for rows in (3596, 6976):
-  for (N, K) in ((512, 3072), (3072, 512)):
-    for tile in (5, 7, 3, 11, 12, 13):
+  for (N, K) in ((512, 3072), (512, 512), (3072, 512)):
+    for tile in tiles:
       run(rows, N, K, tile)
