@@ -900,7 +900,14 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     wide = b ? atoi(b) : 0;
   }
   if (e.reserved == 0 && M > 1024 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
-    if (narrow && N < 1024 && nr != nullptr) return mmt_gemm2_dispatch(narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    // the phased tile keeps a 96 KiB ring = ONE block per CU: it only pays while the live tiles fit one round of 256 CUs
+    // (config B: ~224 of 440); beyond that the 8-wave tile at two blocks per CU wins (tools/splitk_lab.py: 38 vs 49 us at
+    // 440 tiles).  The live row count is on the device; the host estimates it as for the 192-wide tiles.
+    const char* lf = getenv("MMT_LIVE_FRACTION");
+    const double frac = (lf && atof(lf) > 0.0) ? atof(lf) : 0.52;
+    const bool one_round = (double)((M + 127) / 128) * frac * (N / 64) <= 256.0;
+    if (narrow && N < 1024 && nr != nullptr && (narrow != 18 || one_round))
+      return mmt_gemm2_dispatch(narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   }
   if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {

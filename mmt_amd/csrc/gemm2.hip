@@ -576,7 +576,7 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
-  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3((Mpad / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
+  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3(((Mpad + BM - 1) / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
                      lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr);
   return 0;
 }
@@ -609,6 +609,9 @@ static int splitk_impl(const void* A, int64_t lda, const void* B, int64_t ldb, v
   if (b_kn)
     rc = wide ? launch_splitk<128, 128, 2, 4, 2, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
               : launch_splitk<128, 64, 4, 2, 3, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
+  else if (wide == 2)  // 256x128 tiles: half the L2 -> LDS bytes per MAC of the 128x128 tile (the N = 512 GEMMs re-read
+                       // their operands from L2 ~10x; at ~15 TB/s aggregate that traffic is what bounds them)
+    rc = launch_splitk<256, 128, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
   else
     rc = wide ? launch_splitk<128, 128, 2, 4, 2>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
               : launch_splitk<128, 64, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);

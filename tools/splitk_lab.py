@@ -23,20 +23,20 @@ def main():
       ws = torch.empty(16 * (R + 128) * N, device=dev)
       ref = a[:rows].float() @ b.float().t() + res[:rows]
       names, fns = [], []
-      for tile in (0, 13, 14):
+      for tile in (0, 13, 18):
         names.append('tile%d' % tile)
         fns.append(lambda tile=tile: ops.gemm_nt(a, b, out, 'ADD_F32', m=rows, res=res, tile=tile))
-      for wide in (0, 1):
-        for splits in (2, 3, 4):
+      for wide in (0, 1, 2):
+        for splits in (2, 3, 4, 6):
           if K // 64 < splits:
             continue
           ops.gemm_nt_splitk(a, b, out, 'ADD_F32', m=rows, res=res, splits=splits, wide=wide, ws=ws)
           err = (out[:rows] - ref).abs().max().item()
           assert err < 2e-2, (wide, splits, err)
-          names.append('%s s%d part' % ('w' if wide else 'n', splits))
+          names.append('%s s%d part' % ('nwW'[wide], splits))
           fns.append(lambda s=splits, w=wide: ops.gemm_nt_splitk(a, b, out, 'ADD_F32', m=rows, res=res, splits=s, wide=w,
                                                                  ws=ws, no_epilogue=True))
-          names.append('%s s%d full' % ('w' if wide else 'n', splits))
+          names.append('%s s%d full' % ('nwW'[wide], splits))
           fns.append(lambda s=splits, w=wide: ops.gemm_nt_splitk(a, b, out, 'ADD_F32', m=rows, res=res, splits=s, wide=w, ws=ws))
       torch.cuda.synchronize()
       ts = timeit(fns)
