@@ -148,7 +148,9 @@ __global__ __launch_bounds__(64 * SB_WAVES) void simloss_bwd_small_kernel(SimLos
   float* lse_r = S + n * n;              // [n]  (InfoNCE) / diag counts scratch
   float* lse_c = lse_r + n;              // [n]
   float* gself = lse_c + n;              // [n]  G of this block's row (side 0) or column (side 1)
-  float* racc = gself + ((n + 3) & ~3);  // [SB_WAVES][d]
+  // (S + lse_r + lse_c + gself rounded up to whole 16-byte slots: racc is accessed as f32x4 -- for odd n the prefix
+  // n*n + 2n + roundup4(n) is itself odd)
+  float* racc = sl + ((n * n + 3 * n + 3) & ~3) + 4;  // [SB_WAVES][d]
   float* rw = racc + SB_WAVES * d;       // [SB_WAVES]
   float* twl = rw + SB_WAVES;            // [n][M] text / video mixture weights
   float* vwl = twl + n * M;
@@ -571,7 +573,7 @@ extern "C" int mmt_simloss_bwd_small(const float* txt, const float* vid, const f
   if (dlast && !inv_norm) return MMT_ERR_ARG;
   SimLossArgs a = {txt, vid, tw, vw, sims, dots, n, M, d, kind, fix_norm, margin, loss, dtxt, dvid, dtw, dvw, inv_norm, out_rows,
                    dlast};
-  const size_t lds = ((size_t)n * n + 2 * n + ((n + 3) & ~3) + (size_t)SB_WAVES * d + SB_WAVES + 2 * (size_t)n * M) * sizeof(float);
+  const size_t lds = ((size_t)(((n * n + 3 * n + 3) & ~3) + 4) + (size_t)SB_WAVES * d + SB_WAVES + 2 * (size_t)n * M) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     hipError_t rc = hipFuncSetAttribute((const void*)simloss_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

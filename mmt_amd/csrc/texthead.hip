@@ -348,9 +348,7 @@ int mmt_text_heads_bwd_small(const MmtTextHeads* h, const float* text, const flo
                              int K, int use_bn, int training, float* ws, const float* dtext_embds, const float* text_weights,
                              const float* dtext_weights, float* dtext_moe, const MmtTextHeadsOpts* opts, hipStream_t s);
 static bool small_path(int N, int M, int d, int K) {
-  static int off = -1;
-  if (off < 0) off = getenv("MMT_TEXT_HEADS_V1") ? 1 : 0;  // lab switch: the one-kernel-per-op path
-  return !off && mmt_text_heads_fast(N, M, d, K);
+  return mmt_text_heads_fast(N, M, d, K);  // (honours the lab switch MMT_TEXT_HEADS_V1: the one-kernel-per-op path)
 }
 static bool fused_dropout(const MmtTextHeadsOpts* o, const float* text_moe) { return o && o->moe_drop_thr16 && !text_moe; }
 

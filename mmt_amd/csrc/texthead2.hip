@@ -14,6 +14,7 @@
 //   th_bwd3 : dy = dyg + dx1 . W2 (16 waves split the contraction), g_b1, g_w1 = dy^T . text; MoE weight gradients
 // The GEMMs stay on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32 = an fp32 fma chain).  A wave's operands for
 // its whole K slice are loaded before the first MFMA, so a block's critical path is ONE memory round trip.
+#include <stdlib.h>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -461,8 +462,13 @@ __global__ __launch_bounds__(TH_T) void th_bwd3_kernel(ThArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The predicate the HOST side asks before it relies on what only these kernels do (on-the-fly MoE dropout, in-kernel
+// num_batches_tracked): it therefore includes the lab switch MMT_TEXT_HEADS_V1 (one kernel per op), which the dispatcher in
+// texthead.hip obeys -- host and device must agree on the path.
 extern "C" int mmt_text_heads_fast(int N, int M, int d, int K) {
-  return N >= 1 && N <= 32 && M >= 1 && M <= MMT_MAX_EXPERTS && d % 32 == 0 && d >= 32 && d <= 1024 && K % 32 == 0 &&
+  static int off = -1;
+  if (off < 0) off = getenv("MMT_TEXT_HEADS_V1") ? 1 : 0;
+  return !off && N >= 1 && N <= 32 && M >= 1 && M <= MMT_MAX_EXPERTS && d % 32 == 0 && d >= 32 && d <= 1024 && K % 32 == 0 &&
          K >= 32 && K <= 1024;
 }
 

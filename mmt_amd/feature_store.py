@@ -366,22 +366,31 @@ class RaggedCollator:
     return torch.from_numpy(tok.astype(np.int32)), torch.from_numpy(qm.astype(np.int32))
 
   def collate(self, indices, out=None, window=None):
+    """Rows are drawn SAMPLE-major -- for every sample, every expert in turn -- as `BaseDataset.__getitem__` does
+    (base/base_dataset.py:772-833), so a seeded `rng` is consumed sample by sample like the reference's np.random.
+    (The reference iterates `self.experts`, a Python set: its expert order inside a sample depends on the process' hash
+    seed, so an identical draw SEQUENCE over a whole batch cannot be pinned; each draw is `choose_or_pad_to_len`'s.)
+    Inside DataLoader workers pass a per-worker RandomState: the global np.random is duplicated across forked workers."""
     L = self.layout
     if len(indices) != L.batch:
       raise ValueError('expected %d samples, got %d' % (L.batch, len(indices)))
     out = self.new_buffer() if out is None else out
     b, T = L.batch, L.tokens
     f32 = self.store.dtype == 'f32'
+    views, cursor = {}, {}
     for n, d in L.experts:
       xv = out.x[n].view(torch.int16).numpy().view(np.uint16)
       ind, tt = out.ind[n].numpy(), out.t[n].numpy()
       ind[:] = 0.0
       tt[:] = 1.0
       xv[:b] = 0
-      cursor = b
-      for s, i in enumerate(indices):
+      views[n] = (xv, ind, tt)
+      cursor[n] = b
+    for s, i in enumerate(indices):
+      start, end = (0.0, float('inf')) if window is None else window(i)
+      for n, d in L.experts:
+        xv, ind, tt = views[n]
         rows, sec = self.store.rows(n, i)
-        start, end = (0.0, float('inf')) if window is None else window(i)
         if rows.shape[0] and window is not None:
           sel = np.nonzero(np.logical_and(start <= sec, sec <= end))[0]  # base_dataset.py:780-782
         else:
@@ -393,14 +402,16 @@ class RaggedCollator:
         src = pick if sel is None else sel[pick]
         keep = src.shape[0]
         window_rows = rows if sel is None else rows[sel]
+        cur = cursor[n]
         if f32:
           xv[s, :d] = to_bf16(np.max(window_rows, axis=0))
-          xv[cursor:cursor + keep, :d] = to_bf16(rows[src])
+          xv[cur:cur + keep, :d] = to_bf16(rows[src])
         else:  # max over bf16 values == bf16(max over the fp32 values): the rounding is monotone
           xv[s, :d] = to_bf16(np.max(from_bf16(window_rows), axis=0))
-          xv[cursor:cursor + keep, :d] = rows[src]
+          xv[cur:cur + keep, :d] = rows[src]
         ind[s, :keep] = 1.0
         tt[s, :keep] = ((sec[src] - start) / self.window_len + 2).astype(np.float32)  # base_dataset.py:773-776
-        cursor += keep
-      out.live[n] = cursor
+        cursor[n] = cur + keep
+    for n, _ in L.experts:
+      out.live[n] = cursor[n]
     return out

@@ -734,7 +734,7 @@ class CENet(nn.Module):
     grads = [self._flat.view(p, grad_buf) if p.requires_grad else None for p in self._text_head_params()]
     return dtext, dmoe, grads
 
-  # ---- text side (stock PyTorch-ROCm) --------------------------------------------------------------
+  # ---- text side: token ids -> text tower (native engine, or a foreign module) -> [CLS] / pooled features -------------
   def text_features(self, token_ids, device):
     """model/model.py:349-379: (B, C, W, 2) -> (B*C, text_dim) via the text tower's [CLS]."""
     b, c, w, f = token_ids.size()

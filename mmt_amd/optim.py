@@ -18,7 +18,9 @@ class FlatAdam:
   `GraphedTrainStep.step` does.  `state_dict()` / `load_state_dict()` use torch.optim.Adam's layout (per-parameter
   `step` / `exp_avg` / `exp_avg_sq`, parameters numbered in `param_groups` order), so the reference's checkpoints
   (base/base_trainer.py:353-365 saves `optimizer.state_dict()`, :426-432 restores it) round-trip, also to and from a
-  stock torch.optim.Adam over the same parameter list."""
+  stock torch.optim.Adam over the same parameter list.  A checkpoint of the REFERENCE holds ONE Adam over every trainable
+  model parameter (train.py:95-100); `merged_state_dict` / `load_merged_state_dict` translate between that layout and
+  the several optimizers of a step (one FlatAdam per flat buffer + a torch Adam for the rest)."""
 
   def __init__(self, flat, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
@@ -227,3 +229,60 @@ def build_optimizers(model, lr=5e-5, **kw):
   flat_ids = {id(p) for p in model.engine_params()}
   rest = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
   return FlatAdam(model._flat, lr=lr, **kw), (torch.optim.Adam(rest, lr=lr, **kw) if rest else None)
+
+
+def _reference_param_order(model):
+  """The parameter list the reference hands its single optimizer: filter(requires_grad, model.parameters()), train.py:95-100."""
+  return [p for p in model.parameters() if p.requires_grad]
+
+
+def merged_state_dict(model, optimizers):
+  """The state of several optimizers over disjoint subsets of `model`'s parameters (FlatAdam and/or torch.optim.Adam) as ONE
+  torch.optim.Adam state dict over the reference's parameter order -- what base/base_trainer.py:353-365 would have saved
+  for the same training run.  Parameters no optimizer holds state for (never stepped: the unused pooler) have no entry,
+  exactly as torch leaves them out."""
+  order = _reference_param_order(model)
+  index = {id(p): i for i, p in enumerate(order)}
+  state, group = {}, None
+  for opt in optimizers:
+    if opt is None:
+      continue
+    sd = opt.state_dict()
+    params = [p for g in opt.param_groups for p in g['params']]
+    ids = [i for g in sd['param_groups'] for i in g['params']]
+    for local, p in zip(ids, params):
+      st = sd['state'].get(local)
+      if st is not None and id(p) in index:
+        state[index[id(p)]] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    if group is None:
+      group = {k: v for k, v in sd['param_groups'][0].items() if k != 'params'}
+      if torch.is_tensor(group.get('lr')):  # (a captured step keeps the rate of its torch Adam in a device scalar)
+        group['lr'] = float(group['lr'])
+  group = dict(group or {}, params=list(range(len(order))))
+  return {'state': state, 'param_groups': [group]}
+
+
+def load_merged_state_dict(model, optimizers, sd):
+  """Inverse of merged_state_dict: a reference optimizer checkpoint (one Adam, reference parameter order;
+  base/base_trainer.py:426-432) split over the optimizers of the step."""
+  order = _reference_param_order(model)
+  groups = sd['param_groups']
+  if len(groups) != 1 or len(groups[0]['params']) != len(order):
+    raise ValueError('expected ONE param group over the model\'s %d trainable parameters, got %s'
+                     % (len(order), [len(g['params']) for g in groups]))
+  ref_ids = groups[0]['params']
+  at = {id(p): ref_ids[i] for i, p in enumerate(order)}
+  hyper = {k: v for k, v in groups[0].items() if k != 'params'}
+  for opt in optimizers:
+    if opt is None:
+      continue
+    params = [p for g in opt.param_groups for p in g['params']]
+    sub_state = {}
+    for local, p in enumerate(params):
+      st = sd['state'].get(at.get(id(p)), sd['state'].get(str(at.get(id(p)))))
+      if st is not None:
+        sub_state[local] = st
+    own = opt.state_dict()['param_groups'][0]
+    g = dict(own, **{k: v for k, v in hyper.items() if k in own and not torch.is_tensor(own[k])})
+    g['params'] = list(range(len(params)))
+    opt.load_state_dict({'state': sub_state, 'param_groups': [g]})

@@ -333,7 +333,7 @@ class GraphedTrainStep:
     loss = torch.empty((), device=dev, dtype=torch.float32)
     b = e['vid_embds'].shape[0]
     sl = slice(self.rank * b, (self.rank + 1) * b)
-    if n <= L.mmt_simloss_small_max_n():
+    if 2 <= n <= L.mmt_simloss_small_max_n():  # (n == 1: the generic kernels below; the fused one rejects it)
       # small (single-rank) batches: loss, d loss / d sims and the whole similarity backward in ONE launch -- and, when
       # the video embeddings are the read-out of this model's own encoder output, the read-out backward too
       kind = 0 if isinstance(self.loss_fn, MaxMarginRankingLoss) else 1
@@ -533,6 +533,18 @@ class GraphedTrainStep:
   def _sync_all(self):
     for sy in self.syncs:
       sy.sync(force=self._force_coll)
+
+  def optimizer_state_dict(self):
+    """The optimizer state of the step as the REFERENCE would have checkpointed it: one torch.optim.Adam state dict over
+    filter(requires_grad, model.parameters()) (train.py:95-100, base/base_trainer.py:353-365)."""
+    from .optim import merged_state_dict
+    return merged_state_dict(self.model, self.opt_flats + [self.opt_rest])
+
+  def load_optimizer_state_dict(self, sd):
+    """Resume from a reference optimizer checkpoint (base/base_trainer.py:426-432); the captured graphs read the Adam
+    moments / step counts from the same device buffers, so no re-capture is needed."""
+    from .optim import load_merged_state_dict
+    load_merged_state_dict(self.model, self.opt_flats + [self.opt_rest], sd)
 
   def set_lr(self, lr):
     """One learning rate for every optimizer of the step (the reference has a single param group, train.py:100)."""

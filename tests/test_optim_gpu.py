@@ -109,3 +109,93 @@ def test_fused_adam_refreshes_the_bf16_shadows():
   want = torch.cat([P['q'], P['k'], P['v']], 0).detach().to(torch.bfloat16).t()
   assert torch.equal(qkv_t[:128, :192], want)
   assert flat.shadow('r')[0][:, 300:].abs().max().item() == 0.0
+
+
+def test_flat_adam_state_dict_round_trips_through_torch_adam():
+  """FlatAdam.state_dict() IS a torch.optim.Adam state dict: load it into a stock Adam over the same parameters, keep
+  stepping both, and load the stock optimizer's state back -- weights, moments and step count stay together."""
+  from mmt_amd.optim import FlatAdam
+  dev, params, ref, flat = _setup(5)
+  opt = FlatAdam(flat, lr=1e-3)
+  for step in range(3):
+    _set_grads(flat, params, ref, step)
+    opt.step()
+  for p, r in zip(params, ref):
+    r.data.copy_(p.data)
+  topt = torch.optim.Adam(ref, lr=123.0)           # every hyper-parameter comes from the state dict
+  topt.load_state_dict(opt.state_dict())
+  assert topt.param_groups[0]['lr'] == 1e-3 and int(topt.state[ref[0]]['step']) == 3
+  for step in range(3, 6):
+    _set_grads(flat, params, ref, step)
+    opt.step()
+    topt.step()
+  for p, r in zip(params, ref):
+    assert torch.allclose(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+  opt2 = FlatAdam(flat, lr=7.0)
+  opt2.load_state_dict(topt.state_dict())          # and back
+  assert opt2.lr == 1e-3 and int(opt2.step_dev.item()) == 6 and float(opt2.lr_dev.item()) == pytest.approx(1e-3)
+  for step in range(6, 8):
+    _set_grads(flat, params, ref, step)
+    opt2.step()
+    topt.step()
+  for p, r in zip(params, ref):
+    assert torch.allclose(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_reference_optimizer_checkpoint_splits_over_the_steps_optimizers():
+  """A reference checkpoint holds ONE Adam over filter(requires_grad, model.parameters()) (train.py:95-100); the step
+  runs a FlatAdam for the flat buffer + a torch Adam for the rest.  merged_state_dict / load_merged_state_dict translate:
+  the merged dict loads into a stock single Adam over the whole model, and a stock dict loads back."""
+  from mmt_amd.flat import FlatParams
+  from mmt_amd.optim import FlatAdam, load_merged_state_dict, merged_state_dict
+  torch.manual_seed(9)
+  dev = torch.device('cuda', 0)
+
+  class Net(torch.nn.Module):
+    def __init__(self):
+      super().__init__()
+      self.a = torch.nn.Linear(24, 16)      # outside the flat buffer
+      self.b = torch.nn.Linear(16, 32)      # flat
+      self.c = torch.nn.Linear(32, 8)       # flat
+      self.unused = torch.nn.Linear(4, 4)   # never receives a gradient (the pooler's situation)
+
+  net = Net().to(dev)
+  flat = FlatParams([('b.weight', net.b.weight), ('b.bias', net.b.bias), ('c.weight', net.c.weight), ('c.bias', net.c.bias)])
+  flat.ensure(dev)
+  rest = [net.a.weight, net.a.bias, net.unused.weight, net.unused.bias]
+  fo, ro = FlatAdam(flat, lr=2e-3), torch.optim.Adam(rest, lr=2e-3)
+  twin = Net().to(dev)
+  twin.load_state_dict(net.state_dict())
+  single = torch.optim.Adam([p for p in twin.parameters() if p.requires_grad], lr=2e-3)
+
+  def grads(step):
+    gen = torch.Generator(device='cuda').manual_seed(500 + step)
+    for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+      if n.startswith('unused'):
+        continue
+      g = torch.randn(p.shape, device=dev, generator=gen) * 0.1
+      q.grad = g.clone()
+      if any(p is fp for fp in flat.params):
+        flat.view(p, flat.current_grad()).copy_(g)
+      else:
+        p.grad = g.clone()
+
+  for step in range(3):
+    grads(step)
+    fo.step(); ro.step(); single.step()
+  merged = merged_state_dict(net, [fo, ro])
+  want = single.state_dict()
+  assert sorted(merged['state']) == sorted(want['state'])          # no entry for the never-stepped parameters
+  for i, st in want['state'].items():
+    assert float(merged['state'][i]['step']) == float(st['step'])
+    assert torch.allclose(merged['state'][i]['exp_avg'], st['exp_avg'], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(merged['state'][i]['exp_avg_sq'], st['exp_avg_sq'], rtol=1e-5, atol=1e-9)
+  fresh = torch.optim.Adam([p for p in twin.parameters() if p.requires_grad], lr=9.0)
+  fresh.load_state_dict(merged)                                      # the reference's resume path accepts it
+  fo2, ro2 = FlatAdam(flat, lr=9.0), torch.optim.Adam(rest, lr=9.0)
+  load_merged_state_dict(net, [fo2, ro2], want)                      # and a reference checkpoint loads into the split
+  for step in range(3, 5):
+    grads(step)
+    fo2.step(); ro2.step(); fresh.step()
+  for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+    assert torch.allclose(p.detach(), q.detach(), rtol=2e-5, atol=2e-6), n
