@@ -188,8 +188,8 @@ def test_reference_optimizer_checkpoint_splits_over_the_steps_optimizers():
   assert sorted(merged['state']) == sorted(want['state'])          # no entry for the never-stepped parameters
   for i, st in want['state'].items():
     assert float(merged['state'][i]['step']) == float(st['step'])
-    assert torch.allclose(merged['state'][i]['exp_avg'], st['exp_avg'], rtol=1e-5, atol=1e-7)
-    assert torch.allclose(merged['state'][i]['exp_avg_sq'], st['exp_avg_sq'], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(merged['state'][i]['exp_avg'], st['exp_avg'], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(merged['state'][i]['exp_avg_sq'], st['exp_avg_sq'], rtol=1e-4, atol=1e-9)
   fresh = torch.optim.Adam([p for p in twin.parameters() if p.requires_grad], lr=9.0)
   fresh.load_state_dict(merged)                                      # the reference's resume path accepts it
   fo2, ro2 = FlatAdam(flat, lr=9.0), torch.optim.Adam(rest, lr=9.0)
