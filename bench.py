@@ -109,7 +109,7 @@ class KernelProbe:
     return sum(ms) / max(1, len(ms)) * 1e-3, len(ms)
 
 
-PMC_CSV = os.path.join('profiles', 'r02_pmc_kernels.csv')
+PMC_CSV = os.path.join('profiles', 'r03_pmc_kernels.csv')
 
 
 def pmc_traffic(kernel_subs, grid_sub):
@@ -150,14 +150,14 @@ def site_roofline(site, rows, sec, used):
     nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
     subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2'], '[grid '
   elif site == 1:
-    name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64>, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
+    name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
     nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
-    subs, grid = ['gemm2_kernel<128, 64, 4, 2, 3, 3'], '[grid 440 '
+    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3'], '[grid 440 '
   else:
-    name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_grouped_kernel)'
+    name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_phased_kernel)'
     flops = 2.0 * rows * (2 * i * d + 4 * d * d)
     nbytes = rows * (2 * i + 6 * d) * 2 + (2 * i * d + 4 * d * d) * 4
-    subs, grid = ['wgrad_grouped_kernel'], '[grid 256 '
+    subs, grid = ['wgrad_phased_kernel', 'wgrad_grouped_kernel'], '[grid 256 '
   tf = flops / sec / 1e12
   return dict(kernel=name, bound='mfma', achieved=tf, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
               frac=tf / BF16_DENSE_PEAK_TFLOPS, flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes,

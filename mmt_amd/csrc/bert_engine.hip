@@ -347,7 +347,10 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       }
       add_job(w.ln_partials[2 * l + 1], cblocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
       e = {};
-      TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));
+      // (K = hidden: 8..16 K-steps -- one pass on 16+ tiles costs what the split-K slab kernel alone does, and the
+      // slab-reducing epilogue launch goes away)
+      if (d <= 512) TRY(mmt_gemm_nt_bf16(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, nullptr, stream));
+      else TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));
       // dQ exists for the read-out rows only (the dq kernel zero-fills the rest of the Q section); the residual
       // gradient t.dz likewise: the input-gradient GEMM runs without residual and t.dz is scatter-added afterwards
       TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
