@@ -32,7 +32,7 @@ def build(force=False, verbose=False, instr=False):
   global OBJ, LIB, FLAGS
   if instr:
     OBJ, LIB = os.path.join(HERE, 'lib', 'obj_instr'), os.path.join(HERE, 'lib', 'libmmt_hip_instr.so')
-    FLAGS = FLAGS + ['-DMMT_GEMM2_INSTR']
+    FLAGS = FLAGS + ['-DMMT_GEMM2_INSTR'] + ['-D' + d for d in os.environ.get('MMT_LAB_DEFINES', '').split() if d]
   os.makedirs(OBJ, exist_ok=True)
   sources = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
   headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))

@@ -487,8 +487,13 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
 // Both halves of one fragment (rows r0 and r0 + 16 of the same 16-byte chunk: the swizzle repeats every 8 rows, so the
 // second read is the first one's address + 16 rows = 4096 bytes, an instruction immediate).
 __device__ __forceinline__ void tr_frag_issue(u32x2& lo, u32x2& hi, unsigned addr) {
+#ifndef MMT_WGRAD_LAB_NOREADS
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(addr));
+#else  // lab: no LDS traffic, the MFMAs run on whatever the registers hold
+  asm volatile("v_mov_b32 %0, %1" : "=v"(lo[0]) : "v"(addr));
+  lo[1] = lo[0]; hi = lo;
+#endif
 }
 // LDS byte offset (inside a [64][128] bf16 tile) of the first half of the fragment for columns colbase .. colbase + 15,
 // k-sub-step ks.  Fragments 16 columns further on are this offset XOR 32 per step (two 16-byte chunks: the chunk index is
@@ -579,11 +584,27 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   constexpr int GSTAGE = 2 * 64 * 128;  // one unit's [A | B] tiles
 
+  // Source addresses of this lane's 4 + 4 LDS-DMA instructions for unit 0; unit u is 64 u rows further on, a wave-uniform
+  // byte offset -- one 64-bit add per instruction in the loop instead of the row x leading-dimension product (the issuing
+  // wave's VALU work comes out of the issue slots of the computing wave on the same SIMD).
+  const bf16_t *pa[4], *pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ ((r & 7) << 1);
+    pa[i] = A + (int64_t)(u0 * 64 + r) * lda + n0 + c * 8;
+    pb[i] = B + (int64_t)(u0 * 64 + r) * ldb + k0 + c * 8;
+  }
+  const int64_t astep = 64 * lda, bstep = 64 * ldb;
   auto issue = [&](int u) {  // by the four waves of group u & 1
     if (u < units) {
       bf16_t* base = smem + (u & 3) * GSTAGE;
-      stage_tn(A, lda, (u0 + u) * 64, n0, base, wave, lane);
-      stage_tn(B, ldb, (u0 + u) * 64, k0, base + 64 * 128, wave, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(pa[i] + u * astep), LDS_PTR(base + (wave * 4 + i) * 4 * 128), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(pb[i] + u * bstep), LDS_PTR(base + 64 * 128 + (wave * 4 + i) * 4 * 128), 16, 0, 0);
     }
   };
   if (kg == 0) { issue(0); issue(2); } else { issue(1); }
@@ -623,8 +644,11 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
       WTICK(t_issue);
       continue;
     }
-    // transpose reads: the 4 A fragments and the first two PAIRS of B fragments go out at once; after that each pair's
-    // MFMAs run under the reads of the pair after next (in-order returns: "at most 4 outstanding" = this pair has landed).
+    // transpose reads: the 4 A fragments and the first THREE pairs of B fragments go out at once, the fourth after the
+    // first pair's MFMAs: an LDS round trip (~150-200 cycles) then hides behind two pairs of MFMAs (in-order returns:
+    // "at most N outstanding" = everything issued before the last N reads has landed).  Measured with the MFMAs compiled
+    // out (tools/wgrad_instr.py, MMT_LAB_DEFINES=MMT_WGRAD_LAB_NOMFMA): the reads' latency chain alone is 1040 of the 1400
+    // cycles of a compute half-step when only one pair is in flight ahead of the MFMAs.
     // One base address per operand; every fragment's address is that XOR a constant, formed right at the read (the asm
     // barrier keeps the compiler from hoisting 24 loop-invariant addresses into registers the accumulators need).
     u32x2 alo[4], ahi[4], blo[4][2], bhi[4][2];
@@ -633,36 +657,43 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) tr_frag_issue(alo[i], ahi[i], abase ^ (unsigned)(i << 5));
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) tr_frag_issue(blo[q][jj], bhi[q][jj], bbase ^ (unsigned)((2 * q + jj) << 5));
     bf16x8_t af[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q == 0) {
-        asm volatile("s_waitcnt lgkmcnt(4)" : TR_TIE4(alo), TR_TIE4(ahi), "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]));
+      if (q == 0) {  // outstanding allowed: pairs 1, 2
+        asm volatile("s_waitcnt lgkmcnt(8)" : TR_TIE4(alo), TR_TIE4(ahi), "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]));
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = tr_join(alo[i], ahi[i]);
-      } else if (q < 3) {
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(blo[q][0]), "+v"(bhi[q][0]), "+v"(blo[q][1]), "+v"(bhi[q][1]));
+      } else if (q == 1) {  // pairs 2, 3
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(blo[1][0]), "+v"(bhi[1][0]), "+v"(blo[1][1]), "+v"(bhi[1][1]));
+      } else if (q == 2) {  // pair 3
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(blo[2][0]), "+v"(bhi[2][0]), "+v"(blo[2][1]), "+v"(bhi[2][1]));
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[q][0]), "+v"(bhi[q][0]), "+v"(blo[q][1]), "+v"(bhi[q][1]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[3][0]), "+v"(bhi[3][0]), "+v"(blo[3][1]), "+v"(bhi[3][1]));
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = 2 * q + jj;
         const bf16x8_t bfr = tr_join(blo[q][jj], bhi[q][jj]);
 #pragma unroll
+#ifndef MMT_WGRAD_LAB_NOMFMA
         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[i], acc[i][j], 0, 0, 0);
+#else   // lab: the reads stay (consumed by one cheap op), the matrix pipe idles
+        for (int i = 0; i < 1; ++i) acc[i][j][0] += (float)bfr[0] + (float)af[jj][0];
+#endif
       }
-      if (q + 2 < 4) {
+      if (q == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) tr_frag_issue(blo[q + 2][jj], bhi[q + 2][jj], bbase ^ (unsigned)((2 * (q + 2) + jj) << 5));
-      }
-      if (q == 0 && want_bias) {
+        for (int jj = 0; jj < 2; ++jj) tr_frag_issue(blo[3][jj], bhi[3][jj], bbase ^ (unsigned)((6 + jj) << 5));
+        if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);  // (or the scheduler sinks this pair's MFMAs below the later waits)
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
