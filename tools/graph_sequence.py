@@ -13,7 +13,9 @@ c = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else '0')
 rows = c.execute('select name, start, end, grid_x, workgroup_x, %s from kernels order by start' % qcol).fetchall()
-idx = [i for i, r in enumerate(rows) if 'copyBuffer' in r[0] and r[3] // max(r[4], 1) == 256]
+copies = [r[3] // max(r[4], 1) for r in rows if 'copyBuffer' in r[0]]
+big = max(copies)  # the minibatch copy that opens every step is the largest copy of the run
+idx = [i for i, r in enumerate(rows) if 'copyBuffer' in r[0] and r[3] // max(r[4], 1) == big]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 mid, nxt = idx[which], idx[which + 1]
 t0 = rows[mid][1]
