@@ -369,6 +369,33 @@ __device__ __forceinline__ void gemm2_body(
   float csum[NCB][4];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) csum[cb][0] = csum[cb][1] = csum[cb][2] = csum[cb][3] = 0.f;
+  // Second operands of the epilogue (residual rows, GELU pre-activations, original row numbers of the dropout key) for
+  // the WHOLE tile go out now, all at once: fetched inside the sweep, each sits behind the previous row's store -- a
+  // chain of (BM / RG) global round trips per thread at the end of every tile.
+  constexpr int SW = CH / RG, NPF = (BM / CH) * SW * NCB;
+  constexpr bool PF_FITS = NPF <= 8;  // (the 256-row lab tiles would spend > 64 registers on it: they keep the in-sweep loads)
+  constexpr bool PF_RES = PF_FITS && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32);
+  constexpr bool PF_AUX = PF_FITS && EPI == MMT_EPI_DGELU;
+  f32x4 pf_res[PF_RES ? NPF : 1];
+  u32x2 pf_aux[PF_AUX ? NPF : 1];
+  int pf_orow[PF_RES && EPI == MMT_EPI_BIAS_DROP_RES ? (BM / CH) * SW : 1];
+  if constexpr (PF_RES || PF_AUX) {
+#pragma unroll
+    for (int ch = 0; ch < BM / CH; ++ch)
+#pragma unroll
+      for (int sw = 0; sw < SW; ++sw) {
+        const int row = min(m0 + ch * CH + sw * RG + rg, M - 1);
+        if constexpr (PF_RES && EPI == MMT_EPI_BIAS_DROP_RES)
+          pf_orow[ch * SW + sw] = (epi.drop_thr16 && epi.row_index) ? epi.row_index[row] : row;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int col = n0 + cb * CB + cg * 4;
+          if constexpr (PF_RES) pf_res[(ch * SW + sw) * NCB + cb] = *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+          if constexpr (PF_AUX)
+            pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+        }
+      }
+  }
   __syncthreads();  // every wave is done with the stage buffers
 #pragma unroll
   for (int ch = 0; ch < BM / CH; ++ch) {
@@ -424,16 +451,21 @@ __device__ __forceinline__ void gemm2_body(
             *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
           } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
             if (epi.drop_thr16) {
-              const int orow = epi.row_index ? epi.row_index[row] : row;
+              int orow;
+              if constexpr (PF_RES) orow = pf_orow[ch * SW + r0 / RG];
+              else orow = epi.row_index ? epi.row_index[row] : row;
               bool k[4];
               keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
             }
-            v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+            if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
+            else v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
             *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
           } else if constexpr (EPI == MMT_EPI_DGELU) {
-            const u32x2 a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+            u32x2 a;
+            if constexpr (PF_AUX) a = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
+            else a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
             v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
             v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
             v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
@@ -445,7 +477,8 @@ __device__ __forceinline__ void gemm2_body(
               csum[cb][2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[cb][3] += bf2f((bf16_t)(o[1] >> 16));
             }
           } else if constexpr (EPI == MMT_EPI_ADD_F32) {
-            v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
+            if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
+            else v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
             *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
           } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
             *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
