@@ -301,6 +301,9 @@ def main():
   ap.add_argument('--host-inputs', action='store_true',
                   help='minibatches live in pinned host memory: every step uploads one over PCIe (the PCIe-inclusive rate; '
                        'the headline value keeps the inputs resident in HBM)')
+  ap.add_argument('--input-slots', type=int, default=0,
+                  help='sets of static input buffers the step is captured for (GraphedTrainStep(input_slots=)); 0 = one per '
+                       'resident minibatch (3 with --host-inputs); 1 = one set, every minibatch copied into it inside the step')
   ap.add_argument('--ragged-inputs', action='store_true',
                   help='video features in the ragged bf16 wire format (mmt_amd.feature_store.RaggedFeatures: live rows only, '
                        'no cast kernel) instead of the reference\'s dict of dense fp32 tensors')
@@ -365,8 +368,9 @@ def main():
   seq = 1 + len(synthetic.MSRVTT_MODALITIES) * (TOKENS + 1)
   grad_dtype = torch.bfloat16 if args.grad_dtype == 'bf16' else None
 
-  # NBATCH different synthetic minibatches resident in HBM; each step copies one (device-to-device) into
-  # the static input buffers of the captured graphs.
+  # NBATCH different synthetic minibatches resident in HBM (or in pinned host memory); the captured step exists once
+  # per input slot and consumes a minibatch where it lies (--input-slots 1: each step copies one, device to device, into
+  # the single set of static input buffers).
   NBATCH = 16 if args.config == 1 else 4
   batches, input_bytes = [], []
   for i in range(NBATCH):
@@ -384,6 +388,8 @@ def main():
     # one contiguous buffer per minibatch (HBM, or pinned host memory with --host-inputs): load = ONE copy
     batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
 
+  slots_used = 1
+
   def timed_run(pack, steps, warmup):
     """Builds the model + captured step for one token layout and times `steps` steps as the contract prescribes
     (barrier + synchronize on both sides, MAX over ranks).  -> dict(model, runner, elapsed, first_loss, final_loss)"""
@@ -391,29 +397,58 @@ def main():
     model = build_model(pack=pack, text_tower=args.text_tower).to(dev).train()
     mdist.broadcast_parameters(model)
     static = FlatMinibatch(batches[0], dev)
-    if args.text_tower == 'synthetic':
-      model.txt_bert.text = static['text']
+
+    def bind(st):  # the synthetic "text tower" hands out the minibatch's caption vectors: it holds a pointer to them
+      if args.text_tower == 'synthetic':
+        model.txt_bert.text = st['text']
+    bind(static)
+    # Input slots: the captured step exists once per set of input buffers, so a resident minibatch (or one that a copy
+    # stream uploads while the previous step runs) is consumed where it lies.  --input-slots 1 = the r01-r02 arrangement:
+    # ONE set of static inputs, every minibatch copied into it (device to device) inside the timed step.
+    slots = 1 if args.eager else (args.input_slots or (3 if args.host_inputs else NBATCH))
     runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
-                              capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo)
+                              capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
+                              input_slots=slots, bind_inputs=bind)
     runner.measure_exposed = world > 1 or args.force_collectives
+    nonlocal slots_used
+    slots_used = slots
     it, first = 0, None
-    if args.host_inputs:
+    if slots > 1 and args.host_inputs:
+      # minibatch i+1 crosses PCIe on a copy stream, straight into the next slot, while step i computes
+      def feed():
+        nonlocal it
+        cur = it % slots
+        it += 1
+        runner.upload(batches[it % NBATCH], it % slots)
+        return cur
+      runner.upload(batches[0], 0)
+    elif slots > 1:
+      for i in range(slots):  # the resident minibatches ARE the slots' inputs
+        runner.load(batches[i % NBATCH], i)
+
+      def feed():
+        nonlocal it
+        cur = it % slots
+        it += 1
+        return cur
+    elif args.host_inputs:
       # double-buffered upload: minibatch i+1 crosses PCIe on a copy stream while step i computes
       def feed():
         nonlocal it
         runner.load_prefetched()
         it += 1
         runner.prefetch(batches[it % NBATCH])
+        return 0
       runner.prefetch(batches[0])
     else:
       def feed():
         nonlocal it
         runner.load(batches[it % NBATCH]); it += 1
+        return 0
     for _ in range(warmup):
-      feed()
-      l = runner.step()
+      l = runner.step(feed())
       if first is None:
         first = float(l.item())  # loss of the FIRST optimisation step (the runner's warm-up does not train)
     if world > 1:
@@ -421,8 +456,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-      feed()
-      loss = runner.step()
+      loss = runner.step(feed())
     torch.cuda.synchronize()
     if world > 1:
       dist.barrier()
@@ -494,6 +528,9 @@ def main():
                    'global_batch': world * BATCH, 'seq_len': seq,
                    'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager,
                    'inputs': 'pinned host, uploaded every step (double-buffered on a copy stream)' if args.host_inputs else 'resident in HBM',
+                   # sets of input buffers the step was captured for (1 = every minibatch is copied, device to device, into
+                   # one static set inside the timed step; > 1 = a minibatch is consumed in the slot it was put into)
+                   'input_slots': slots_used,
                    'input_format': 'ragged bf16 wire buffer (live rows)' if args.ragged_inputs else 'dense fp32 dict',
                    'video_input_bytes_per_step': int(sum(input_bytes) / len(input_bytes)),
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',

@@ -33,10 +33,10 @@ template <int DH> __device__ __forceinline__ int swz(int r) {
 }
 
 // 64 x DH bf16 tile by LDS-DMA: one wave-instruction moves 1 KiB = 64 / (DH/8) rows
-template <int DH>
+template <int DH, int NW = 4>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_last,
                                         bf16_t* lds_tile, int wave, int lane) {
-  constexpr int CH = DH / 8, RPI = 64 / CH, NI = 16 / RPI;
+  constexpr int CH = DH / 8, RPI = 64 / CH, NI = 64 / NW / RPI;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int rbase = (wave * NI + i) * RPI;
@@ -154,17 +154,18 @@ __device__ __forceinline__ void keep4_keys(unsigned rowkey, const int* kp, bool 
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward: grid (q tiles of 64, H, B), 4 waves x 16 queries
+// forward: grid (q tiles of 16 NW, H, B), NW waves x 16 queries.  NW = 8 (one block per CU) stages every key / value
+// tile once per 128 queries instead of once per 64: half the L2 -> LDS traffic per CU for the same waves per CU.
 // ------------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2 + 2 * 64 * 2];
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][64]
   int* kpos_s = (int*)(bias_s + 2 * 64);              // [2][64] original positions of the tile's keys
   const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * (16 * NW);
   const int nqs = a.qsel ? a.nq : Sb;  // queries of this sample
   if (q0 >= nqs || Sb <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   auto stage = [&](int kt, int st) {
     bf16_t* base = smem + st * (2 * 64 * DH);
-    stage64<DH>(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
-    stage64<DH>(Vg, a.ld, off + kt * 64, row_last, base + 64 * DH, wave, lane);
+    stage64<DH, NW>(Kg, a.ld, off + kt * 64, row_last, base, wave, lane);
+    stage64<DH, NW>(Vg, a.ld, off + kt * 64, row_last, base + 64 * DH, wave, lane);
     if (tid < 64) {
       const int k = kt * 64 + tid;
       bias_s[st * 64 + tid] = k < Sb ? a.mask_bias[off + k] * LOG2E : -INFINITY;
@@ -540,6 +541,24 @@ static int check_args(const void* qkv, int B, int S, int H, int d) {
   return 0;
 }
 
+// nq queries per sample.  8-wave blocks (128 queries) when a sample has more than 64 queries; MMT_ATTN_FWD_WAVES=4 (lab:
+// same-box A/B) keeps the 4-wave blocks of r01-r02.
+static int launch_fwd(const AttnArgs& a, int nq, int H, int B, bool dh128, hipStream_t s) {
+  static int waves = -1;
+  if (waves < 0) {
+    const char* e = getenv("MMT_ATTN_FWD_WAVES");
+    waves = e ? atoi(e) : 8;
+  }
+  if (waves == 8 && nq > 64) {
+    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 8>), dim3((nq + 127) / 128, H, B), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), dim3((nq + 127) / 128, H, B), dim3(512), 0, s, a);
+  } else {
+    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), dim3((nq + 63) / 64, H, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), dim3((nq + 63) / 64, H, B), dim3(256), 0, s, a);
+  }
+  return (int)hipGetLastError();
+}
+
 // tq query tiles (dQ role) + tk key tiles (dK/dV role) in one launch.  MMT_ATTN_BWD_SPLIT=1 (lab: same-box A/B) issues
 // the two roles as two launches of the same kernel, the r02 structure.
 static int launch_bwd(const AttnArgs& a, int tq, int tk, int H, int B, bool dh128, hipStream_t s) {
@@ -571,9 +590,7 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
-  if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch_fwd(a, S, H, B, d == H * 128, (hipStream_t)stream);
 }
 
 extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
@@ -606,9 +623,7 @@ extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
-  if (d == H * 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((nq + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch_fwd(a, nq, H, B, d == H * 128, (hipStream_t)stream);
 }
 
 extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel,

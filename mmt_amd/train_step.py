@@ -93,6 +93,23 @@ class FlatMinibatch(dict):
       out[k] = view
 
 
+def _clone_tree(src):
+  """A second set of input buffers with the layout of `src` (FlatMinibatch, or a plain dict of device tensors)."""
+  if isinstance(src, FlatMinibatch):
+    return FlatMinibatch(src, src.flat.device)
+  out = {}
+  for k, v in src.items():
+    if isinstance(v, dict):
+      out[k] = _clone_tree(v)
+    elif torch.is_tensor(v):
+      out[k] = v.clone()
+    elif isinstance(v, RaggedFeatures):
+      out[k] = RaggedFeatures(v.layout, v.device).copy_from(v, non_blocking=False)
+    else:
+      out[k] = v
+  return out
+
+
 def _copy_tree(dst, src):
   for k, v in src.items():
     if isinstance(v, dict):
@@ -120,7 +137,7 @@ class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
                overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
-               grad_algo='allreduce', split_bottom=True):
+               grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -129,6 +146,12 @@ class GraphedTrainStep:
     grad_algo: 'allreduce' | 'rs_ag' (reduce-scatter + all-gather per span, `dist.WireBuffer`).
     split_bottom: staged mode reduces layer 0's gradients before the embedding / token stage runs, so that only the
     expert projections + embedding tables (about half of the last span) are reduced after the backward has ended.
+    input_slots: K > 1 keeps K sets of static input buffers and captures the step once per set (same kernels, same
+    weights / optimizer state / seeds; only the input pointers differ): `step(slot)` then runs on whatever was put into
+    `inputs(slot)` -- a loader writes minibatch i + 1 straight into the next slot (`upload`, `load(mb, slot)`) while step i
+    runs, and the device-to-device copy of the whole minibatch into ONE set of static buffers (12 us for 26 MB at
+    config B) disappears from the step.  bind_inputs(static): called before the captures of each slot, for modules
+    that hold a pointer to an input tensor (bench.py's synthetic text tower).
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
@@ -147,6 +170,10 @@ class GraphedTrainStep:
     self._want_stages = self._multi if overlap_grad_sync is None else bool(overlap_grad_sync)
     self.staged = False
     self.static = minibatch
+    self._statics = [minibatch]
+    self._bind = bind_inputs
+    self._caps = None
+    self._slot_ev = None
     self.capture_collectives = bool(capture_collectives)
     self._one_graph = False
     self._staging = None  # device-side landing buffer of prefetch()
@@ -200,7 +227,21 @@ class GraphedTrainStep:
         self._restore(snap)
     torch.cuda.current_stream().wait_stream(self._stream)
     if use_graphs:
-      self._capture()
+      if int(input_slots) > 1:
+        self._statics += [_clone_tree(minibatch) for _ in range(int(input_slots) - 1)]
+        self._caps = []
+        for st in self._statics:
+          self.static = st
+          if self._bind:
+            self._bind(st)
+          self._capture()
+          self._caps.append((self._graphs, self._e, self.loss, self._one_graph))
+        self.static = self._statics[0]
+        if self._bind:
+          self._bind(self.static)
+        self._graphs, self._e, self.loss, self._one_graph = self._caps[0]
+      else:
+        self._capture()
 
   # ---- warm-up must not train --------------------------------------------------------------------
   def _snapshot(self):
@@ -667,17 +708,50 @@ class GraphedTrainStep:
     torch.cuda.synchronize()
 
   # ---- public ------------------------------------------------------------------------------------
-  def load(self, minibatch):
-    """Copy a new minibatch (device tensors, same shapes) into the static input buffers.  (Running this copy on a side
-    stream under the previous step's optimizer graph was measured: the cross-stream event waits cost 70 us per step,
-    more than the 14 us copy -- it stays on the compute stream.)"""
-    if isinstance(minibatch, FlatMinibatch) and isinstance(self.static, FlatMinibatch) \
-        and minibatch.flat.numel() == self.static.flat.numel():
-      self.static.flat.copy_(minibatch.flat, non_blocking=True)
+  @property
+  def input_slots(self):
+    return len(self._statics)
+
+  def inputs(self, slot=0):
+    """The static input buffers of `slot` (what the captured step of that slot reads)."""
+    return self._statics[slot]
+
+  def load(self, minibatch, slot=0):
+    """Copy a new minibatch (device tensors, same shapes) into the static input buffers of `slot`.  (Running this copy on
+    a side stream under the previous step's optimizer graph was measured: the cross-stream event waits cost 70 us per
+    step, more than the 14 us copy -- it stays on the compute stream.)"""
+    static = self._statics[slot]
+    if isinstance(minibatch, FlatMinibatch) and isinstance(static, FlatMinibatch) \
+        and minibatch.flat.numel() == static.flat.numel():
+      static.flat.copy_(minibatch.flat, non_blocking=True)
       for k in minibatch.ragged:
-        self.static[k].copy_from(minibatch[k])
+        static[k].copy_from(minibatch[k])
     else:
-      _copy_tree(self.static, minibatch)
+      _copy_tree(static, minibatch)
+
+  def upload(self, minibatch, slot):
+    """Start copying a HOST (pinned) FlatMinibatch straight into the input buffers of `slot` on a copy stream; the next
+    `step(slot)` waits for it, and the upload itself waits until the previous `step(slot)` has been issued AND has run.
+    With K >= 2 slots minibatch i + 1 crosses PCIe under step i and no device-to-device copy is left in the step."""
+    static = self._statics[slot]
+    if not isinstance(minibatch, FlatMinibatch) or not isinstance(static, FlatMinibatch):
+      raise TypeError('upload needs FlatMinibatch inputs (one buffer per minibatch)')
+    if self._slot_ev is None:
+      self._slot_ev = [dict(ready=None, free=None) for _ in self._statics]
+      self._copy_stream = torch.cuda.Stream()
+    ev = self._slot_ev[slot]
+    if ev['free'] is not None:
+      self._copy_stream.wait_event(ev['free'])  # the last step that read this slot has finished
+    else:
+      self._copy_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._copy_stream):
+      static.flat.copy_(minibatch.flat, non_blocking=True)
+      for k in minibatch.ragged:
+        static[k].copy_from(minibatch[k])
+      if ev['ready'] is None:
+        ev['ready'] = torch.cuda.Event()
+      ev['ready'].record(self._copy_stream)
+    ev['pending'] = True
 
   def prefetch(self, minibatch):
     """Start uploading a HOST (pinned) FlatMinibatch into a device staging buffer on a copy stream: the PCIe transfer
@@ -722,12 +796,29 @@ class GraphedTrainStep:
     cur.wait_stream(self._stream)
     return self.loss
 
-  def step(self):
-    """Runs one optimisation step on the current static inputs; returns the (device) loss tensor."""
+  def step(self, slot=0):
+    """Runs one optimisation step on the static inputs (of `slot`); returns the (device) loss tensor."""
     if not self.use_graphs:
       return self.eager_step()
     for o in self.opt_flats:
       o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
+    if self._caps is not None:
+      self._graphs, self._e, self.loss, self._one_graph = self._caps[slot]
+    elif slot:
+      raise ValueError('step(slot=%d): the runner was built with one input slot' % slot)
+    ev = self._slot_ev[slot] if self._slot_ev is not None else None
+    if ev is not None and ev.get('pending'):
+      torch.cuda.current_stream().wait_event(ev['ready'])
+      ev['pending'] = False
+    try:
+      return self._replay()
+    finally:
+      if ev is not None:
+        if ev['free'] is None:
+          ev['free'] = torch.cuda.Event()
+        ev['free'].record(torch.cuda.current_stream())
+
+  def _replay(self):
     ga, gb, gc = self._graphs
     ga.replay()
     if self._multi and not self._one_graph:

@@ -152,6 +152,59 @@ def test_forked_step_graph_equals_the_serial_chain(fork):
     assert torch.equal(a['buffers'][k], b['buffers'][k]), k
 
 
+def _run_feed(dev, slots, host, steps=7):
+  """`steps` optimisation steps on DIFFERENT minibatches: slots == 1 copies each one into the single set of static
+  inputs (`load`), slots > 1 puts minibatch i into slot i % slots -- by a device copy, or (host=True) by an upload from
+  pinned memory on the copy stream -- and runs the step captured for that slot."""
+  from mmt_amd import synthetic
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
+  torch.manual_seed(0)
+  model = _build(dev, txt_pro='gbn', dropout=0.1, layers=2)
+  mbs = []
+  for i in range(steps):
+    mb, text = synthetic.make_batch(40 + i, BATCH, MODS, TOKENS)
+    mbs.append(_slice_batch(mb, text, slice(0, BATCH)))
+  static = FlatMinibatch(mbs[0], dev)
+
+  def bind(st):
+    model.txt_bert.text = st['text']
+  bind(static)
+  runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, warmup_steps=1, input_slots=slots,
+                            bind_inputs=bind)
+  assert runner.input_slots == slots
+  feed = [FlatMinibatch(m, 'cpu', pin_memory=True) if host else FlatMinibatch(m, dev) for m in mbs]
+  losses = []
+  if host:
+    runner.upload(feed[0], 0)
+  for i in range(steps):
+    slot = i % slots
+    if host:
+      if i + 1 < steps:
+        runner.upload(feed[i + 1], (i + 1) % slots)  # under step i; waits until the last step on that slot has run
+    else:
+      runner.load(feed[i], slot)
+    losses.append(runner.step(slot).clone())  # (the loss tensor is an output buffer of the captured step: copy it out)
+  torch.cuda.synchronize()
+  return dict(losses=[float(l.item()) for l in losses], master=model._flat.master.detach().clone().cpu(),
+              buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()})
+
+
+@pytest.mark.parametrize('slots,host', [(3, False), (2, True), (3, True)])
+def test_input_slots_run_the_same_steps_as_one_static_input_set(slots, host):
+  """GraphedTrainStep(input_slots=K): the step captured once per set of input buffers (a minibatch is consumed where the
+  loader put it -- no device-to-device copy inside the step) trains exactly as the single-set step that copies every
+  minibatch in: identical losses, weights and BatchNorm statistics over 7 different minibatches, also when the next
+  minibatch is uploaded from pinned host memory into its slot while the current step runs."""
+  dev = torch.device('cuda', 0)
+  a, b = _run_feed(dev, 1, False), _run_feed(dev, slots, host)
+  assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
+  assert len(set(a['losses'])) == len(a['losses'])  # (the minibatches did differ)
+  assert torch.equal(a['master'], b['master'])
+  for k in a['buffers']:
+    assert torch.equal(a['buffers'][k], b['buffers'][k]), k
+
+
 def test_two_ranks_bench_configuration_stays_in_lock_step(tmp_path):
   """The configuration bench.py runs at N > 1 -- BatchNorm text heads (txt_pro='gbn'), dropout 0.1 everywhere, 4 layers,
   staged backward with per-stage all-reduces -- on two ranks: the ranks draw DIFFERENT dropout masks (the rank is folded

@@ -47,11 +47,11 @@ def case(B, S, drop_p):
   scale = 128 ** -0.5
 
   def fwd():
-    _lib.check(L.mmt_attn_fwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), B, S, H, d, scale, 7, thr, sc, None, _stream()), 'f')
+    _lib.check(L.mmt_attn_fwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), B, S, H, d, scale, 7, thr, sc, None, None, _stream()), 'f')
 
   def bwd():
     _lib.check(L.mmt_attn_bwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), B, S, H, d, scale,
-                              7, thr, sc, None, _stream()), 'b')
+                              7, thr, sc, None, None, _stream()), 'b')
 
   torch.cuda.synchronize()  # inputs were produced on the default stream; timeit launches on a side stream
   tf, tb = timeit([fwd, bwd])
