@@ -44,8 +44,9 @@ WORKLOAD = CONFIGS[1]['name']
 
 
 def select_config(n):
-  global BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS, WORKLOAD
+  global BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS, WORKLOAD, PMC_CSV
   c = CONFIGS[n]
+  PMC_CSV = os.path.join('profiles', PMC_CSVS[n])
   BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS = (c[k] for k in ('batch', 'tokens', 'hidden', 'layers', 'heads',
                                                                          'inter', 'max_pos'))
   WORKLOAD = c['name']
@@ -109,25 +110,30 @@ class KernelProbe:
     return sum(ms) / max(1, len(ms)) * 1e-3, len(ms)
 
 
-PMC_CSV = os.path.join('profiles', 'r03_pmc_kernels.csv')
+PMC_CSVS = {1: 'r03_pmc_kernels.csv', 3: 'r03_pmc_config3.csv', 4: 'r03_pmc_config4.csv'}  # one set of passes per shape
+PMC_CSV = os.path.join('profiles', PMC_CSVS[1])
 
 
-def pmc_traffic(kernel_subs, grid_sub):
+def pmc_traffic(kernel_subs, grid_sub=None):
   """HBM traffic per launch of a kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this same command,
   tools/final_profiles.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a wide coalesced
-  read (MI355X_MICROARCH.md, HBM section).  None if the profile is not there."""
+  read (MI355X_MICROARCH.md, HBM section).  Of the grids a kernel was launched with, the one that holds most of its time
+  (the full layers' launches, not the tail's).  None if the profile is not there."""
   import csv
   path = os.path.join(ROOT, PMC_CSV)
-  if not os.path.exists(path) or WORKLOAD != CONFIGS[1]['name']:
-    return None  # (the committed PMC passes are of the headline shape)
+  if not os.path.exists(path):
+    return None
+  best, best_time = None, -1.0
   with open(path) as f:
     for row in csv.DictReader(f):
-      if any(k in row['kernel'] for k in kernel_subs) and grid_sub in row['kernel']:
+      if any(k in row['kernel'] for k in kernel_subs) and (grid_sub is None or grid_sub in row['kernel']):
         try:
-          return (2.0 * float(row['FETCH_SIZE']) + float(row['WRITE_SIZE'])) * 1024.0
+          t = float(row['dispatches']) * float(row['avg_ns'])
+          if t > best_time:
+            best, best_time = (2.0 * float(row['FETCH_SIZE']) + float(row['WRITE_SIZE'])) * 1024.0, t
         except (KeyError, ValueError):
-          return None
-  return None
+          pass
+  return best
 
 
 def pmc_blob():
@@ -148,16 +154,16 @@ def site_roofline(site, rows, sec, used):
   if site == 0:
     name, flops = 'FFN up-projection GEMM + bias + erf-GELU (N=%d, K=%d; gemm2_kernel, EPI BIAS_GELU)' % (i, d), 2.0 * rows * i * d
     nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
-    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2'], '[grid '
+    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2'], None
   elif site == 1:
     name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
     nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
-    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3'], '[grid 440 '
+    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3', 'gemm2_kernel<128, 128, 2, 4, 2, 3'], None
   else:
     name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_phased_kernel)'
     flops = 2.0 * rows * (2 * i * d + 4 * d * d)
     nbytes = rows * (2 * i + 6 * d) * 2 + (2 * i * d + 4 * d * d) * 4
-    subs, grid = ['wgrad_phased_kernel', 'wgrad_grouped_kernel'], '[grid 256 '
+    subs, grid = ['wgrad_phased_kernel', 'wgrad_grouped_kernel'], None
   tf = flops / sec / 1e12
   return dict(kernel=name, bound='mfma', achieved=tf, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
               frac=tf / BF16_DENSE_PEAK_TFLOPS, flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes,
@@ -371,7 +377,7 @@ def main():
   # NBATCH different synthetic minibatches resident in HBM (or in pinned host memory); the captured step exists once
   # per input slot and consumes a minibatch where it lies (--input-slots 1: each step copies one, device to device, into
   # the single set of static input buffers).
-  NBATCH = 16 if args.config == 1 else 4
+  NBATCH = 8 if args.config == 1 else 4
   batches, input_bytes = [], []
   for i in range(NBATCH):
     mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS, max_pos=MAX_POS)

@@ -16,6 +16,8 @@ timeout 600 python bench.py --config 3 --steps 60 --warmup 10 2>/dev/null | tail
 timeout 600 python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > $O/bench_config4.json
 timeout 600 python bench.py --steps 100 --warmup 10 --text-tower native --no-cpu-baseline --no-dense 2>/dev/null | tail -1 > $O/bench_native_text_tower.json
 timeout 600 python bench.py --steps 200 --warmup 20 --host-inputs --no-cpu-baseline --no-dense 2>/dev/null | tail -1 > $O/bench_host_inputs.json
+timeout 600 python bench.py --steps 200 --warmup 20 --host-inputs --ragged-inputs --no-cpu-baseline --no-dense 2>/dev/null | tail -1 > $O/bench_host_inputs_ragged.json
+timeout 600 python bench.py --steps 200 --warmup 20 --input-slots 1 --no-cpu-baseline --no-dense 2>/dev/null | tail -1 > $O/bench_one_input_slot.json
 MMT_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_2ranks_gloo_one_gpu.json
 for f in 0 32 16 1 21 117; do
   timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-dense --fork $f 2>/dev/null | tail -1 | python -c "

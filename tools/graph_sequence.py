@@ -1,4 +1,5 @@
-"""One replayed training step (between two minibatch copies) from a rocprofv3 kernel-trace database, in start order,
+"""One replayed training step (from its first text-head kernel to the first kernel of the next step) from a
+rocprofv3 kernel-trace database, in start order,
 with per-kernel start offset, duration, the gap to the latest end seen so far (negative = it OVERLAPS an earlier kernel:
 a parallel branch of the step graph) and the queue it ran on:
 
@@ -13,11 +14,14 @@ c = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else '0')
 rows = c.execute('select name, start, end, grid_x, workgroup_x, %s from kernels order by start' % qcol).fetchall()
-copies = [r[3] // max(r[4], 1) for r in rows if 'copyBuffer' in r[0]]
-big = max(copies)  # the minibatch copy that opens every step is the largest copy of the run
-idx = [i for i, r in enumerate(rows) if 'copyBuffer' in r[0] and r[3] // max(r[4], 1) == big]
-which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
-mid, nxt = idx[which], idx[which + 1]
+# A step OPENS with the first text-head kernel (th_fwd1_kernel: once per step in every mode; the video plan kernel when
+# the text heads run elsewhere).  (Up to r02 every step opened with the device-to-device copy of the minibatch; with
+# input slots there is no such copy.)
+starts = [i for i, r in enumerate(rows) if 'th_fwd1_kernel' in r[0]] or [i for i, r in enumerate(rows) if 'video_plan_kernel' in r[0]]
+if len(starts) < 3:
+  sys.exit('fewer than three steps in the trace')
+which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
+mid, nxt = starts[which], starts[which + 1]
 t0 = rows[mid][1]
 prev_end, tot, union, overlapped = None, 0.0, 0.0, 0
 queues = {}
