@@ -175,6 +175,10 @@ class GraphedTrainStep:
     self._caps = None
     self._slot_ev = None
     self.capture_collectives = bool(capture_collectives)
+    # With a process group alive, its watchdog thread polls events of collectives still in flight (the eager all-gather
+    # issued between two captures, a neighbour's slow broadcast): in 'global' mode such a call from ANOTHER thread
+    # invalidates a capture that happens to be open.  Calls of the capturing thread itself stay checked.
+    self._cap_mode = 'thread_local' if dist.is_initialized() else 'global'
     self._one_graph = False
     self._staging = None  # device-side landing buffer of prefetch()
     flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
@@ -644,7 +648,7 @@ class GraphedTrainStep:
     self._zero()
     if not self._multi and self._fork_on:
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream):
+      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
         self._fork_step()  # ONE graph whose branches are the main and the side stream
       self._graphs, self._e = (ga, None, None), None
       torch.cuda.synchronize()
@@ -652,7 +656,7 @@ class GraphedTrainStep:
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     e = g = pool = None
     if self._multi or self.staged:
-      with torch.cuda.graph(ga, stream=self._stream):
+      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
       pool = ga.pool()
       with torch.cuda.stream(self._stream):
@@ -662,7 +666,7 @@ class GraphedTrainStep:
       # single-rank one -- RCCL's stream joins the capture through the events torch.distributed records, the cross-stream
       # waits become graph edges.  Verified on a 1-rank RCCL group only (no multi-GPU box this round), hence not default.
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream):
+      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
         g = self._gather(e)
         if self.staged:
@@ -683,7 +687,7 @@ class GraphedTrainStep:
     if not self._multi and not self.staged:
       # nothing happens between forward and backward on one rank: one graph for both (one launch gap less per step)
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream):
+      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
         g = self._gather(e)
         self.loss = self._loss_backward(e, g)
@@ -696,13 +700,13 @@ class GraphedTrainStep:
       gb = []
       for fn, names in self._stage_list(e, g):
         gs = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gs, pool=pool, stream=self._stream):
+        with torch.cuda.graph(gs, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
           fn()
         gb.append((gs, names))
     else:
-      with torch.cuda.graph(gb, pool=pool, stream=self._stream):
+      with torch.cuda.graph(gb, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
         self.loss = self._loss_backward(e, g)
-    with torch.cuda.graph(gc, pool=pool, stream=self._stream):
+    with torch.cuda.graph(gc, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
       self._opt()
     self._graphs, self._e = (ga, gb, gc), e
     torch.cuda.synchronize()

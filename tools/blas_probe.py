@@ -22,6 +22,12 @@ def bench(m, n, k, iters=20, reps=5):
       best = min(best, e0.elapsed_time(e1) / iters)
   print('M %5d N %5d K %5d : %7.2f us  %7.1f TFLOP/s' % (m, n, k, best * 1e3, 2.0 * m * n * k / best / 1e9))
 
-for m in (3573, 6976):
-  for n, k in ((3072, 512), (512, 3072), (1536, 512), (512, 512), (512, 1536)):
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == 'big':  # configs[4] (d1024 L6 I6144, batch 128: ~22.8k live rows of 55.9k) and configs[3]
+  for m, n, k in ((22784, 6144, 1024), (22784, 1024, 6144), (22784, 3072, 1024), (22784, 1024, 1024), (22784, 1024, 3072),
+                  (11904, 3072, 512), (11904, 512, 3072), (8192, 8192, 8192)):
     bench(m, n, k)
+else:
+  for m in (3573, 6976):
+    for n, k in ((3072, 512), (512, 3072), (1536, 512), (512, 512), (512, 1536)):
+      bench(m, n, k)
