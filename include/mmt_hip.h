@@ -453,6 +453,20 @@ int64_t mmt_text_heads_workspace_floats(int N, int M, int d);
  *     text (pass text_moe = NULL): stream key = hash(moe_drop_key, *seed_dev) at forward time, stored in *key_dev and
  *     re-read from there by the backward (which runs after the seed has moved on);
  *   num_batches_tracked: int64 [M], += 1 per training forward with use_bn (BatchNorm1d bookkeeping, on the device). */
+/* The video side's token plan (+ feature cast) riding along as extra blocks of the text heads' first two launches
+ * (N <= 32 caption rows, mmt_text_heads_fast): the arguments of mmt_video_plan / mmt_video_cast, which the caller then
+ * does NOT call for this forward.  Two dependent launches (13 + 7 us under graph replay) leave the step; results are
+ * those of the separate launches bit for bit (the dropout-seed bump moves from the plan to the second launch, i.e. it
+ * still follows the text heads' read of the seed and precedes the encoder's). */
+typedef struct MmtVideoFront {
+  const MmtExpertIO* experts;
+  int32_t M, B, T, pack, max_pos, do_cast;  /* do_cast = 0: the features arrive as bf16 (RaggedFeatures) */
+  int32_t *counts, *cu_seqlens, *n_rows_dev, *slot, *row_index, *type_ids, *pos_ids;
+  float* mask_bias;
+  int32_t* agg_row;
+  uint32_t* seed_bump;
+  const MmtVideoSrc* src;
+} MmtVideoFront;
 typedef struct MmtTextHeadsOpts {
   uint32_t moe_drop_key, moe_drop_thr16;
   float moe_drop_scale;
@@ -460,6 +474,7 @@ typedef struct MmtTextHeadsOpts {
   const uint32_t* seed_dev;
   uint32_t* key_dev;
   int64_t* num_batches_tracked;
+  const MmtVideoFront* video_front;  /* nullable; forward only, small path only (MMT_ERR_ARG otherwise) */
 } MmtTextHeadsOpts;
 int mmt_text_heads_fast(int N, int M, int d, int K);
 /* text [N = B*C, K] -> text_embds (B, M, C, d) L2-normalised, text_weights (B, C, M) (NULL: txt_wgh='none').

@@ -109,9 +109,16 @@ class MmtTextHeads(ctypes.Structure):
   _fields_ = [(n, _PTR16) for n in _TEXT_HEAD_FIELDS]
 
 
+class MmtVideoFront(ctypes.Structure):
+  _fields_ = [('experts', c_vp), ('M', ctypes.c_int32), ('B', ctypes.c_int32), ('T', ctypes.c_int32), ('pack', ctypes.c_int32),
+              ('max_pos', ctypes.c_int32), ('do_cast', ctypes.c_int32), ('counts', c_vp), ('cu_seqlens', c_vp),
+              ('n_rows_dev', c_vp), ('slot', c_vp), ('row_index', c_vp), ('type_ids', c_vp), ('pos_ids', c_vp),
+              ('mask_bias', c_vp), ('agg_row', c_vp), ('seed_bump', c_vp), ('src', c_vp)]
+
+
 class MmtTextHeadsOpts(ctypes.Structure):
   _fields_ = [('moe_drop_key', c_u32), ('moe_drop_thr16', c_u32), ('moe_drop_scale', c_f32), ('reserved', ctypes.c_int32),
-              ('seed_dev', c_vp), ('key_dev', c_vp), ('num_batches_tracked', c_vp)]
+              ('seed_dev', c_vp), ('key_dev', c_vp), ('num_batches_tracked', c_vp), ('video_front', c_vp)]
 
 
 EPI = dict(BF16=0, BIAS_BF16=1, BIAS_GELU=2, BIAS_DROP_RES=3, DGELU=4, ADD_F32=5, F32=6, BIAS_F32=7)

@@ -13,125 +13,13 @@
 //   scatter_bwd : gradient of the slot -> gradient of Y (bf16, zero for dropped tokens).
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
+#include "video_front.h"
 
-struct ExpertTable { MmtExpertIO e[MMT_MAX_EXPERTS]; };
-
-__device__ __forceinline__ void decode_slot(int s, int T, int& expert, int& j) {
-  expert = (s - 1) / (T + 1);
-  j = (s - 1) % (T + 1);  // 0 = AGG, 1..T = FEA t = j-1
-}
-
-// grid = B blocks of 256 threads, ONE launch: block b derives the row offset of its sample (and, per expert, the offset
-// of its valid feature rows inside the expert's COMPACT source matrix) from the validity flags of the samples in front of
-// it (<= B*M*T flags: trivial), then fills the slot map, ids, mask and the source-row maps.
-//
-// Compact source matrix of expert e (X_e / Y_e / dY_e): rows [0, B) = the max-pooled vector of every sample (the AGG
-// token's input, always present: keep_missing_modalities), rows B + i = the VALID feature rows in (sample, time) order.
-// Padded feature rows are never projected: the ReduceDim GEMM, its weight gradient and the cast only see live rows
-// (src_cnt[e] on the device; ~52 % of B*(T+1) at the synthetic MSRVTT fill).  Without token packing every feature row
-// counts as valid (the dense token grid of the reference).
-__global__ __launch_bounds__(256) void video_plan_kernel(ExpertTable tab, int B, int M, int T, int S, int pack, int max_pos,
-                                                         int32_t* __restrict__ counts, int32_t* __restrict__ cu,
-                                                         int32_t* __restrict__ n_rows, int32_t* __restrict__ slot,
-                                                         int32_t* __restrict__ row_index, int32_t* __restrict__ type_ids,
-                                                         int32_t* __restrict__ pos_ids, float* __restrict__ mask_bias,
-                                                         int32_t* __restrict__ agg_row, uint32_t* __restrict__ seed_bump,
-                                                         MmtVideoSrc src) {
-  __shared__ int scan[256];
-  __shared__ int carry;
-  __shared__ int offs[MMT_MAX_EXPERTS], own[MMT_MAX_EXPERTS];  // valid feature rows of expert e: before sample b / in it
-  extern __shared__ float ind_s[];  // [M][T] validity flags of THIS sample (the per-slot loops below read them from LDS)
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (b == 0 && tid == 0 && seed_bump) *seed_bump += 1u;  // per-step dropout seed (one launch less)
-  for (int i = tid; i < M * T; i += 256) ind_s[i] = tab.e[i / T].ind[(int64_t)b * T + i % T];
-  for (int ex = wave; ex < M; ex += 4) {  // one wave per expert
-    const float* __restrict__ ind_e = tab.e[ex].ind;
-    int before = 0, mine = 0;
-    if (pack) {
-      for (int i = lane; i < b * T; i += 64) before += ind_e[i] != 0.f;
-      for (int t = lane; t < T; t += 64) mine += ind_e[(int64_t)b * T + t] != 0.f;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); mine += __shfl_xor(mine, o, 64); }
-    } else {
-      before = b * T;
-      mine = T;
-    }
-    if (lane == 0) { offs[ex] = before; own[ex] = mine; }
-  }
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  int base = b * S;
-  if (pack) {
-    base = b * (1 + M);
-    for (int ex = 0; ex < M; ++ex) base += offs[ex];
-  }
-  if (b == B - 1 && tid < M && src.src_cnt) src.src_cnt[tid] = B + offs[tid] + own[tid];
-  for (int s0 = 0; s0 < S; s0 += 256) {
-    const int s = s0 + tid;
-    int live = 0, expert = 0, j = 0;
-    float ind = 1.f;
-    if (s < S) {
-      if (s == 0) live = 1;
-      else {
-        decode_slot(s, T, expert, j);
-        if (j == 0) live = 1;
-        else { ind = ind_s[expert * T + (j - 1)]; live = pack ? (ind != 0.f) : 1; }
-      }
-    }
-    scan[tid] = live;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
-      const int v = tid >= o ? scan[tid - o] : 0;
-      __syncthreads();
-      scan[tid] += v;
-      __syncthreads();
-    }
-    const int before = carry + scan[tid] - live;
-    if (s < S) {
-      const int row = live ? base + before : -1;
-      slot[(int64_t)b * S + s] = row;
-      if (live) {
-        row_index[row] = b * S + s;
-        int type = 0, pos = 0, srow = -1;
-        float mask = 1.f;
-        if (s > 0) {
-          type = tab.e[expert].type_idx;
-          const float* ind_e = ind_s + expert * T;
-          if (j == 0) {
-            float mx = 0.f;  // th.max(features_ind, 1)  model.py:330
-            for (int t = 0; t < T; ++t) mx = fmaxf(mx, ind_e[t]);
-            mask = mx;
-            agg_row[b * M + expert] = row;
-            srow = b;  // the max-pooled rows lead the compact source matrix
-          } else {
-            mask = ind;
-            float tv = tab.e[expert].t[(int64_t)b * T + (j - 1)];
-            tv = fminf(fmaxf(tv, 0.f), (float)max_pos);  // clamp_ then .long()  model.py:516-520
-            pos = (int)tv;
-            int rank = j - 1;
-            if (pack) {
-              rank = 0;
-              for (int t = 0; t < j - 1; ++t) rank += ind_e[t] != 0.f;
-            }
-            srow = B + offs[expert] + rank;
-            if (src.xsrc) src.xsrc[(int64_t)expert * B * T + offs[expert] + rank] = b * T + (j - 1);
-          }
-        }
-        type_ids[row] = type;
-        pos_ids[row] = pos;
-        mask_bias[row] = (1.0f - mask) * -10000.0f;  // bert.py:395
-        if (src.src_row) src.src_row[row] = srow;
-      }
-    }
-    __syncthreads();
-    if (tid == 255) carry += scan[255];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    counts[b] = carry;
-    cu[b] = base;
-    if (b == B - 1) { cu[B] = base + carry; *n_rows = base + carry; }
-  }
+// (ExpertTable, the plan and the cast live in video_front.h as block-level device functions: the text heads' launches can
+// carry them as extra blocks, texthead2.hip)
+__global__ __launch_bounds__(256) void video_plan_kernel(VideoPlanArgs p) {
+  extern __shared__ float plan_ind_s[];  // [M][T] validity flags of THIS sample
+  video_plan_block(p, (int)blockIdx.x, (int)threadIdx.x, plan_ind_s);
 }
 
 __global__ void scan_counts_kernel(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ cu,
@@ -144,29 +32,8 @@ __global__ void scan_counts_kernel(const int32_t* __restrict__ counts, int B, in
   }
 }
 
-// X_e (compact, see video_plan_kernel): row b < B = maxpool[b]; row B + i = features row xsrc[e][i]; bf16, K zero-padded.
-// Only the src_cnt[e] live rows are written: the rows behind them are never read as results (the GEMM's tiles past the
-// live count exit, the weight gradient zeroes the ragged tail of its last 64-row unit).
-__global__ __launch_bounds__(256) void cast_kernel(ExpertTable tab, int B, int T, MmtVideoSrc src) {
-  const MmtExpertIO e = tab.e[blockIdx.y];
-  const int rows = src.src_cnt[blockIdx.y];
-  const int32_t* __restrict__ xs = src.xsrc + (int64_t)blockIdx.y * B * T;
-  const int64_t n = (int64_t)rows * (e.Dpad / 4);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / (e.Dpad / 4)), c = (int)(i % (e.Dpad / 4)) * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* srcp = r < B ? e.maxpool + (int64_t)r * e.D : e.feat + (int64_t)xs[r - B] * e.D;
-    if (c + 3 < e.D && !(e.D & 3)) {
-      const f32x4 q = *(const f32x4*)(srcp + c);
-      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (c + k < e.D) v[k] = srcp[c + k];
-    }
-    u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-    *(u32x2*)((bf16_t*)e.x + (int64_t)r * e.Dpad + c) = o;
-  }
+__global__ __launch_bounds__(256) void cast_kernel(VideoCastArgs c) {
+  video_cast_block(c, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, 256);
 }
 
 // One wave per LIVE token row: CLS -> zero feature (model.py:502-503); otherwise normalise the ReduceDim output row
@@ -228,17 +95,6 @@ __global__ __launch_bounds__(256) void scatter_kernel(ExpertTable tab, int M, in
 }
 
 // ------------------------------------------------------------------------------------------------
-static int make_table(const MmtExpertIO* experts, int M, ExpertTable& tab) {
-  if (!experts || M <= 0 || M > MMT_MAX_EXPERTS) return MMT_ERR_ARG;
-  for (int i = 0; i < M; ++i) {
-    tab.e[i] = experts[i];
-    if (experts[i].n_part < 0 || experts[i].n_part > 2) return MMT_ERR_ARG;
-    for (int k = 0; k < experts[i].n_part; ++k)
-      if (!experts[i].y_part[k]) return MMT_ERR_ARG;
-  }
-  return 0;
-}
-
 // ---- text-side token plan ------------------------------------------------------------------------------------------
 // The reference pads every caption to max_text_words and runs the text tower on all of them (model/model.py:353-376).
 // Only the [CLS] row of the last layer is read (post_agg 'cls', :378-379) and padded tokens are masked as keys in every
@@ -310,37 +166,22 @@ extern "C" int mmt_text_plan(const int64_t* input_ids, const int64_t* token_type
   return (int)hipGetLastError();
 }
 
-static int check_src(const MmtVideoSrc* src) {
-  return (src && src->src_row && src->src_cnt && src->xsrc) ? 0 : MMT_ERR_ARG;
-}
-
 extern "C" int mmt_video_plan(const MmtExpertIO* experts, int M, int B, int T, int pack, int max_pos,
                               int32_t* counts, int32_t* cu_seqlens, int32_t* n_rows_dev, int32_t* slot,
                               int32_t* row_index, int32_t* type_ids, int32_t* pos_ids, float* mask_bias,
                               int32_t* agg_row, uint32_t* seed_bump, const MmtVideoSrc* src, void* stream) {
-  ExpertTable tab;
-  if (int e = make_table(experts, M, tab)) return e;
-  if (!counts || !cu_seqlens || !n_rows_dev || !slot || !row_index || !type_ids || !pos_ids || !mask_bias || !agg_row)
-    return MMT_ERR_ARG;
-  if (int e = check_src(src)) return e;
-  if (B <= 0 || T <= 0 || max_pos < 0) return MMT_ERR_ARG;
-  for (int i = 0; i < M; ++i)
-    if (!experts[i].ind || !experts[i].t || experts[i].type_idx < 0) return MMT_ERR_ARG;
-  const int S = 1 + M * (T + 1);
-  hipLaunchKernelGGL(video_plan_kernel, dim3(B), dim3(256), (size_t)M * T * sizeof(float), (hipStream_t)stream, tab, B, M, T, S, pack, max_pos, counts,
-                     cu_seqlens, n_rows_dev, slot, row_index, type_ids, pos_ids, mask_bias, agg_row, seed_bump, *src);
+  VideoPlanArgs p;
+  if (int e = video_plan_args(p, experts, M, B, T, pack, max_pos, counts, cu_seqlens, n_rows_dev, slot, row_index, type_ids,
+                              pos_ids, mask_bias, agg_row, seed_bump, src))
+    return e;
+  hipLaunchKernelGGL(video_plan_kernel, dim3(B), dim3(256), (size_t)M * T * sizeof(float), (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 
 extern "C" int mmt_video_cast(const MmtExpertIO* experts, int M, int B, int T, const MmtVideoSrc* src, void* stream) {
-  ExpertTable tab;
-  if (int e = make_table(experts, M, tab)) return e;
-  if (int e = check_src(src)) return e;
-  for (int i = 0; i < M; ++i)
-    if (!experts[i].feat || !experts[i].maxpool || !experts[i].x || (experts[i].Dpad & 3) ||
-        experts[i].rows_pad < B * (T + 1))
-      return MMT_ERR_ARG;
-  hipLaunchKernelGGL(cast_kernel, dim3(256, M), dim3(256), 0, (hipStream_t)stream, tab, B, T, *src);
+  VideoCastArgs c;
+  if (int e = video_cast_args(c, experts, M, B, T, src)) return e;
+  hipLaunchKernelGGL(cast_kernel, dim3(256, M), dim3(256), 0, (hipStream_t)stream, c);
   return (int)hipGetLastError();
 }
 

@@ -363,7 +363,7 @@ extern "C" int mmt_text_heads_fwd(const MmtTextHeads* h, const float* text, cons
   if (small_path(N, M, d, K))
     return mmt_text_heads_fwd_small(h, text, text_moe, N, C, M, d, K, use_bn, training, ws, text_embds, text_weights, opts,
                                     (hipStream_t)stream);
-  if (fused_dropout(opts, text_moe) || (opts && opts->num_batches_tracked)) return MMT_ERR_ARG;  // small-batch path only
+  if (fused_dropout(opts, text_moe) || (opts && (opts->num_batches_tracked || opts->video_front))) return MMT_ERR_ARG;  // small-batch path only
   const int64_t nmd = (int64_t)N * M * d;
   float *y = ws, *x1 = ws + nmd, *mean = ws + 2 * nmd, *rstd = mean + (int64_t)M * d;
   hipStream_t s = (hipStream_t)stream;

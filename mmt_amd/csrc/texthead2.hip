@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
+#include "video_front.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -124,14 +125,12 @@ __device__ __forceinline__ f32x4 moe_input4(const ThArgs& a, unsigned key, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TH_T) void th_fwd1_kernel(ThArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
-  ThSmem& sm = *(ThSmem*)th_smem_raw;
+__device__ __forceinline__ void th_fwd1_block(const ThArgs& a, const int bid, ThSmem& sm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int ct = a.d / 32, gemm_blocks = a.M * ct;
   const ThWs w = th_layout(a.ws, a.N, a.M, a.d);
-  if ((int)blockIdx.x < gemm_blocks) {
-    const int m = blockIdx.x / ct, j0 = (blockIdx.x % ct) * 32;
+  if (bid < gemm_blocks) {
+    const int m = bid / ct, j0 = (bid % ct) * 32;
     const int per = k_slice(a.K), kbeg = wave * per, kend = min(a.K, kbeg + per);
     const f32x16 acc = mm_nt_slice(a.text + (int64_t)min(l31, a.N - 1) * a.K, l31 < a.N,
                                    a.h.w1[m] + (int64_t)(j0 + l31) * a.K, true, kbeg, kend, h);
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(TH_T) void th_fwd1_kernel(ThArgs a) {
     return;
   }
   // ---- MoE weights of row n: logits (one wave per expert), softmax, L1 normalise (model.py:262-283, 618) ----
-  const int n = blockIdx.x - gemm_blocks;
+  const int n = bid - gemm_blocks;
   unsigned key = 0;
   if (!a.text_moe && a.thr16) {
     key = eff_key(a.drop_key, a.seed_dev);
@@ -167,14 +166,30 @@ __global__ __launch_bounds__(TH_T) void th_fwd1_kernel(ThArgs a) {
   }
 }
 
-__global__ __launch_bounds__(TH_T) void th_fwd2_kernel(ThArgs a) {
+__global__ __launch_bounds__(TH_T) void th_fwd1_kernel(ThArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
-  ThSmem& sm = *(ThSmem*)th_smem_raw;
+  th_fwd1_block(a, (int)blockIdx.x, *(ThSmem*)th_smem_raw);
+}
+
+static_assert(sizeof(ThArgs) + sizeof(VideoPlanArgs) + 64 <= 4096 && sizeof(ThArgs) + sizeof(VideoCastArgs) + 64 <= 4096,
+              "kernel arguments: 4 KiB");
+// The same launch carrying the video side's token plan as B extra blocks (4 of their 16 waves work, video_front.h).
+__global__ __launch_bounds__(TH_T) void th_fwd1_plan_kernel(ThArgs a, VideoPlanArgs p, int th_blocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
+  if ((int)blockIdx.x < th_blocks) {
+    th_fwd1_block(a, (int)blockIdx.x, *(ThSmem*)th_smem_raw);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  video_plan_block(p, (int)blockIdx.x - th_blocks, (int)threadIdx.x, (float*)th_smem_raw);
+}
+
+__device__ __forceinline__ void th_fwd2_block(const ThArgs& a, const int bid, ThSmem& sm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int ct = a.d / 32;
-  const int m = blockIdx.x / ct, jt = blockIdx.x % ct, j0 = jt * 32;
+  const int m = bid / ct, jt = bid % ct, j0 = jt * 32;
   const ThWs w = th_layout(a.ws, a.N, a.M, a.d);
-  if (blockIdx.x == 0 && tid < a.M && a.nbt && a.use_bn && a.training) a.nbt[tid] += 1;  // num_batches_tracked
+  if (bid == 0 && tid < a.M && a.nbt && a.use_bn && a.training) a.nbt[tid] += 1;  // num_batches_tracked
   const int per = k_slice(a.d), kbeg = wave * per, kend = min(a.d, kbeg + per);
   const f32x16 acc = mm_nt_slice(w.y + ((int64_t)min(l31, a.N - 1) * a.M + m) * a.d, l31 < a.N,
                                  a.h.w2[m] + (int64_t)(j0 + l31) * a.d, true, kbeg, kend, h);
@@ -228,6 +243,25 @@ __global__ __launch_bounds__(TH_T) void th_fwd2_kernel(ThArgs a) {
 #pragma unroll
   for (int s = 16; s > 0; s >>= 1) sq += __shfl_xor(sq, s, 64);
   if (j == 0 && n < a.N) w.part[((int64_t)n * a.M + m) * ct + jt] = sq;
+}
+
+__global__ __launch_bounds__(TH_T) void th_fwd2_kernel(ThArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
+  th_fwd2_block(a, (int)blockIdx.x, *(ThSmem*)th_smem_raw);
+}
+
+// The same launch carrying the video side's feature cast (cast_bx blocks per expert) and the per-step bump of the
+// dropout seed (the text heads read the seed in their FIRST launch, the encoder after this one).
+__global__ __launch_bounds__(TH_T) void th_fwd2_cast_kernel(ThArgs a, VideoCastArgs c, int th_blocks, int cast_bx,
+                                                            uint32_t* seed_bump) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && seed_bump) *seed_bump += 1u;
+  if ((int)blockIdx.x < th_blocks) {
+    th_fwd2_block(a, (int)blockIdx.x, *(ThSmem*)th_smem_raw);
+    return;
+  }
+  const int r = (int)blockIdx.x - th_blocks;
+  video_cast_block(c, r / cast_bx, r % cast_bx, cast_bx, (int)threadIdx.x, TH_T);
 }
 
 // one wave per (n, m): e = o / max(|o|, 1e-12) -> (B, M, C, d)
@@ -476,7 +510,7 @@ static int th_configure() {
   static bool done = false;
   if (done) return 0;
   const void* fns[] = {(const void*)th_fwd1_kernel, (const void*)th_fwd2_kernel, (const void*)th_bwd2_kernel,
-                       (const void*)th_bwd3_kernel};
+                       (const void*)th_bwd3_kernel, (const void*)th_fwd1_plan_kernel, (const void*)th_fwd2_cast_kernel};
   for (const void* f : fns) {
     hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ThSmem));
     if (rc != hipSuccess) return (int)rc;
@@ -506,8 +540,32 @@ int mmt_text_heads_fwd_small(const MmtTextHeads* h, const float* text, const flo
   a.text_embds = text_embds; a.text_weights = text_weights;
   if (!text_moe && a.thr16 && (!a.seed_dev || !a.key_dev)) return MMT_ERR_ARG;
   const int gemm_blocks = M * (d / 32);
-  hipLaunchKernelGGL(th_fwd1_kernel, dim3(gemm_blocks + (text_weights ? N : 0)), dim3(TH_T), sizeof(ThSmem), s, a);
-  hipLaunchKernelGGL(th_fwd2_kernel, dim3(gemm_blocks), dim3(TH_T), sizeof(ThSmem), s, a);
+  const int blocks1 = gemm_blocks + (text_weights ? N : 0);
+  const MmtVideoFront* vf = opts ? opts->video_front : nullptr;
+  if (vf) {
+    // the plan rides in launch 1 (its seed bump moves to launch 2: the MoE blocks of launch 1 read the seed), the cast in 2
+    VideoPlanArgs p;
+    if (int e = video_plan_args(p, vf->experts, vf->M, vf->B, vf->T, vf->pack, vf->max_pos, vf->counts, vf->cu_seqlens,
+                                vf->n_rows_dev, vf->slot, vf->row_index, vf->type_ids, vf->pos_ids, vf->mask_bias, vf->agg_row,
+                                nullptr, vf->src))
+      return e;
+    if ((size_t)vf->M * vf->T * sizeof(float) > sizeof(ThSmem)) return MMT_ERR_ARG;
+    VideoCastArgs c = {};
+    int cast_blocks = 0;
+    // cast blocks per expert: with the text heads' blocks, two 1024-thread blocks per CU at most (they all carry the
+    // text heads' 78 KiB of dynamic LDS)
+    const int cast_bx = 56;
+    if (vf->do_cast) {
+      if (int e = video_cast_args(c, vf->experts, vf->M, vf->B, vf->T, vf->src)) return e;
+      cast_blocks = cast_bx * vf->M;
+    }
+    hipLaunchKernelGGL(th_fwd1_plan_kernel, dim3(blocks1 + vf->B), dim3(TH_T), sizeof(ThSmem), s, a, p, blocks1);
+    hipLaunchKernelGGL(th_fwd2_cast_kernel, dim3(gemm_blocks + cast_blocks), dim3(TH_T), sizeof(ThSmem), s, a, c, gemm_blocks,
+                       cast_bx, vf->seed_bump);
+  } else {
+    hipLaunchKernelGGL(th_fwd1_kernel, dim3(blocks1), dim3(TH_T), sizeof(ThSmem), s, a);
+    hipLaunchKernelGGL(th_fwd2_kernel, dim3(gemm_blocks), dim3(TH_T), sizeof(ThSmem), s, a);
+  }
   hipLaunchKernelGGL(th_fwd3_kernel, dim3((N * M + 3) / 4), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }

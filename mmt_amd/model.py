@@ -21,6 +21,7 @@ anything else raises NotImplementedError instead of silently taking a slow path.
 """
 import collections
 import ctypes
+import os
 import re
 import types
 
@@ -29,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, ops
-from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, MmtVideoSrc, check
+from ._lib import MmtExpertIO, MmtTextHeads, MmtTextHeadsOpts, MmtVideoFront, MmtVideoSrc, check
 from .bert import BertModel, EngineBatch
 from .feature_store import RaggedFeatures
 from .flat import FlatParams
@@ -248,6 +249,7 @@ class _VideoPlan:
     self.rows = bsz * self.seq
     self.rows_alloc = ops.pad_rows(self.rows)
     self.generation = 0
+    self.front_done = -1  # generation whose plan / cast launches rode along with the text heads (CENet._video_front)
     i32 = dict(device=device, dtype=torch.int32)
     self.counts = torch.zeros(bsz, **i32)
     self.cu = torch.zeros(bsz + 1, **i32)
@@ -497,12 +499,13 @@ class CENet(nn.Module):
     vb = self.vid_bert
     bump = vb._seed_dev if (plan.bump_seed and vb._seed_dev is not None) else None
     vb._seed_bumped = bump is not None
-    check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
-                           ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
-                           ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
-                           ops._p(bump), ctypes.byref(plan.src), stream), 'mmt_video_plan')
-    if not plan.precast:
-      check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
+    if plan.front_done != plan.generation:  # (else: plan and cast rode along with the text heads' launches, _video_front)
+      check(L.mmt_video_plan(io, m, plan.batch, plan.tokens, int(self.pack_tokens), max_pos, ops._p(plan.counts),
+                             ops._p(plan.cu), ops._p(plan.n_rows), ops._p(plan.slot), ops._p(plan.row_index),
+                             ops._p(plan.type_ids), ops._p(plan.pos_ids), ops._p(plan.mask_bias), ops._p(plan.agg_row),
+                             ops._p(bump), ctypes.byref(plan.src), stream), 'mmt_video_plan')
+      if not plan.precast:
+        check(L.mmt_video_cast(io, m, plan.batch, plan.tokens, ctypes.byref(plan.src), stream), 'mmt_video_cast')
     # wide experts are cut along K into chunks of <= KSPLIT columns (own tiles, partial products summed by the scatter
     # kernel): the launch lasts as long as its longest K loop, and rgb / scene have 2048 / 2208 input channels
     items, index = [], []
@@ -520,6 +523,23 @@ class CENet(nn.Module):
     check(L.mmt_video_scatter(io, m, plan.batch, plan.tokens, d, ops._p(plan.n_rows), ops._p(plan.row_index),
                               ctypes.byref(plan.src), ops._p(feats), stream), 'mmt_video_scatter')
     return feats
+
+  def _video_front(self, plan):
+    """The plan (+ cast) launches of this forward as a descriptor the text heads' first two launches carry as extra blocks
+    (MmtVideoFront, texthead2.hip): two dependent launches less per step."""
+    vb = self.vid_bert
+    bump = vb._seed_dev if (plan.bump_seed and vb._seed_dev is not None) else None
+    f = MmtVideoFront()
+    f.experts = ctypes.addressof(plan.io)
+    f.M, f.B, f.T, f.pack = len(self.modalities), plan.batch, plan.tokens, int(self.pack_tokens)
+    f.max_pos, f.do_cast = self.vid_bert_params['max_position_embeddings'] - 1, int(not plan.precast)
+    for name, t in (('counts', plan.counts), ('cu_seqlens', plan.cu), ('n_rows_dev', plan.n_rows), ('slot', plan.slot),
+                    ('row_index', plan.row_index), ('type_ids', plan.type_ids), ('pos_ids', plan.pos_ids),
+                    ('mask_bias', plan.mask_bias), ('agg_row', plan.agg_row)):
+      setattr(f, name, t.data_ptr())
+    f.seed_bump = bump.data_ptr() if bump is not None else None
+    f.src = ctypes.addressof(plan.src)
+    return f
 
   def _video_tokens_backward(self, plan, dfeat, side_stream=None):
     """side_stream: the ReduceDim weight gradients (the last kernel of the backward; only the optimizer reads them) go
@@ -543,8 +563,35 @@ class CENet(nn.Module):
       ops.wgrad_grouped(items, plan.src_rows, item_rows_dev=plan.src_cnt)
     return grads
 
-  def video_embeddings(self, features, features_t, features_ind, features_maxpool):
-    """(B, M, d) L2-normalised expert embeddings of the video side (model.py:426-437, 485-587, 621-625)."""
+  def video_embeddings(self, features, features_t, features_ind, features_maxpool, plan=None):
+    """(B, M, d) L2-normalised expert embeddings of the video side (model.py:426-437, 485-587, 621-625).
+    plan: what `_video_prepare` returned for these inputs (forward() prepares it early, so that the text heads' launches
+    can carry the plan and the cast)."""
+    if plan is None:
+      plan = self._video_prepare(features, features_t, features_ind, features_maxpool)
+    mods, bsz, dev = self.modalities, plan.batch, plan.slot.device
+    feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
+    batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
+                        plan.rows, bsz, plan.seq, cu_seqlens=plan.cu,
+                        row_index=plan.row_index if self.pack_tokens else None,  # dense rows ARE the original coordinates
+                        n_rows_dev=plan.n_rows if self.pack_tokens else None,
+                        out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
+    last = self.vid_bert.run_engine(batch, feats)
+    # handles for callers that drive the backward of this forward stage by stage (train_step.GraphedTrainStep)
+    self._stages = dict(plan=plan, feats=feats, batch=batch, last=last) if last.requires_grad else None
+    if self.vid_bert.compact_output(batch, plan.rows_alloc):  # the engine returned just the AGG rows, in agg_row order
+      if plan.compact_rows is None:
+        plan.compact_rows = torch.arange(bsz * len(mods), device=dev, dtype=torch.int32)
+      vid = _ReadoutFn.apply(last, plan.compact_rows, bsz * len(mods), True, self._stages)
+    else:
+      vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods), False, self._stages)
+    vid = vid.view(bsz, len(mods), self.same_dim)
+    if self._stages is not None:
+      self._stages['vid_embds'] = vid
+    return vid
+
+  def _video_prepare(self, features, features_t, features_ind, features_maxpool):
+    """Host side of the video forward: checks the inputs, binds them to the (B, T) plan's expert table.  No launches."""
     mods = self.modalities
     ragged = features if isinstance(features, RaggedFeatures) else None
     if ragged is not None:
@@ -601,25 +648,7 @@ class CENet(nn.Module):
     plan.precast = ragged is not None
     # (grad mode is off inside autograd.Function.forward: decide here whether this forward draws a fresh dropout seed)
     plan.bump_seed = self.vid_bert.training and torch.is_grad_enabled()
-    feats = _VideoTokensFn.apply(self, plan, *self._reduce_params())
-    batch = EngineBatch(None, plan.type_ids, plan.pos_ids if self.pos_enc != 'none' else None, plan.mask_bias,
-                        plan.rows, bsz, plan.seq, cu_seqlens=plan.cu,
-                        row_index=plan.row_index if self.pack_tokens else None,  # dense rows ARE the original coordinates
-                        n_rows_dev=plan.n_rows if self.pack_tokens else None,
-                        out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
-    last = self.vid_bert.run_engine(batch, feats)
-    # handles for callers that drive the backward of this forward stage by stage (train_step.GraphedTrainStep)
-    self._stages = dict(plan=plan, feats=feats, batch=batch, last=last) if last.requires_grad else None
-    if self.vid_bert.compact_output(batch, plan.rows_alloc):  # the engine returned just the AGG rows, in agg_row order
-      if plan.compact_rows is None:
-        plan.compact_rows = torch.arange(bsz * len(mods), device=dev, dtype=torch.int32)
-      vid = _ReadoutFn.apply(last, plan.compact_rows, bsz * len(mods), True, self._stages)
-    else:
-      vid = _ReadoutFn.apply(last, plan.agg_row, bsz * len(mods), False, self._stages)
-    vid = vid.view(bsz, len(mods), self.same_dim)
-    if self._stages is not None:
-      self._stages['vid_embds'] = vid
-    return vid
+    return plan
 
   # ---- text heads (native) -------------------------------------------------------------------------
   def _text_head_params(self):
@@ -665,6 +694,10 @@ class CENet(nn.Module):
     return o
 
   _th_key = None
+  _pending_front = None  # video plan whose plan / cast launches the next text-heads forward carries along
+  _th_front = None
+  # lab switch (same-box A/B): MMT_FRONT_FUSE=0 keeps the plan and the cast as launches of their own
+  front_fuse = os.environ.get('MMT_FRONT_FUSE', '1') != '0'
 
   def _text_heads_forward(self, text, text_moe, caps, moe_drop_p=0.0):
     n, k = text.shape
@@ -699,6 +732,11 @@ class CENet(nn.Module):
     tw = torch.empty(n // caps, caps, m, device=text.device, dtype=torch.float32) if self.txt_wgh == 'emb' else None
     h = self._text_heads_struct(None)
     self._th_opts = self._text_heads_opts(moe_drop_p, nbt)
+    front_plan, self._pending_front = self._pending_front, None
+    if front_plan is not None and fast:
+      self._th_front = self._video_front(front_plan)  # (kept alive: the opts hold its address)
+      self._th_opts.video_front = ctypes.addressof(self._th_front)
+      front_plan.front_done = front_plan.generation
     check(L.mmt_text_heads_fwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), n, caps, m, d, k, use_bn, int(self.training), ops._p(ws),
                                ops._p(embds), ops._p(tw), ctypes.byref(self._th_opts), ops._stream()), 'mmt_text_heads_fwd')
     if tw is None:
@@ -723,6 +761,7 @@ class CENet(nn.Module):
     dmoe_fused = torch.empty_like(text) if (fused_drop and need_dtext and has_moe) else None
     bwd_opts = MmtTextHeadsOpts.from_buffer_copy(opts)
     bwd_opts.num_batches_tracked = None
+    bwd_opts.video_front = None
     check(L.mmt_text_heads_bwd(ctypes.byref(h), ops._p(text), ops._p(text_moe), ctypes.c_void_p(w1_all), n, caps, m, d, k,
                                int(self.txt_pro == 'gbn'), int(training), ops._p(self._th_ws[(n, text.device)]),
                                ops._p(de.contiguous()), ops._p(self._th_tw) if has_moe else None,
@@ -774,7 +813,9 @@ class CENet(nn.Module):
     m = len(self.modalities)
     text = self.text_features(token_ids, dev)                                   # (B*C, text_dim)
     self._prepare(dev)
+    plan = self._video_prepare(features, features_t, features_ind, features_maxpool)
     side = None
+    self._pending_front = None
     if self._native_text_heads:
       # The text heads are ~15 tiny latency-bound launches that are independent of the video encoder until the
       # similarity: they run on a side stream (fork/join, also under graph capture) and hide under the encoder's GEMMs;
@@ -795,14 +836,17 @@ class CENet(nn.Module):
             text_moe = _MoeDropoutFn.apply(text, self.moe_txt_dropout.p, self.vid_bert._seed_dev)
           else:
             text_moe = self.moe_txt_dropout(text)
+        if self.front_fuse and side is None:
+          self._pending_front = plan  # (taken up only by the small-batch text-head kernels)
         text_embds, text_weights = _TextHeadsFn.apply(self, text, text_moe, c, moe_drop_p, *self._text_head_params())
+        self._pending_front = None
     else:
       text_embd = [self.text_GU[mod](text).view(b, c, -1) for mod in self.modalities]  # model.py:413-417
       tv = text.view(b, c, -1)
       text_weights = self.compute_weights_from_emb(tv) if self.txt_wgh == 'emb' else torch.ones(b, c, m, device=dev)
       text_weights = F.normalize(text_weights, p=1, dim=-1)                       # model.py:618
       text_embds = torch.stack([F.normalize(t, dim=-1) for t in text_embd], 1)    # (B,M,C,d) model.py:623
-    vid_embds = self.video_embeddings(features, features_t, features_ind, features_maxpool)
+    vid_embds = self.video_embeddings(features, features_t, features_ind, features_maxpool, plan=plan)
     if side is not None:
       cur.wait_stream(side)
       for t in (text_embds, text_weights):

@@ -25,7 +25,7 @@ def _free_port():
   return p
 
 
-def _build(dev, txt_pro='gem', dropout=0.0, layers=None):
+def _build(dev, txt_pro='gem', dropout=0.0, layers=None, front_fuse=None):
   from mmt_amd import synthetic
   from mmt_amd.model import CENet
   from tests.test_host_cpu import _fake_txt_bert
@@ -41,6 +41,8 @@ def _build(dev, txt_pro='gem', dropout=0.0, layers=None):
                 txt_bert=_fake_txt_bert(), pack_tokens=True)
   sd = synthetic.make_state_dict(21, {k: tuple(v.shape) for k, v in model.state_dict().items()})
   model.load_state_dict(sd)
+  if front_fuse is not None:
+    model.front_fuse = front_fuse
   return model.to(dev).train()
 
 
@@ -148,6 +150,21 @@ def test_forked_step_graph_equals_the_serial_chain(fork):
   assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
   assert torch.equal(a['grad'], b['grad'])
   assert torch.equal(a['master'], b['master'])
+  for k in a['buffers']:
+    assert torch.equal(a['buffers'][k], b['buffers'][k]), k
+
+
+def test_plan_and_cast_riding_with_the_text_heads_change_nothing():
+  """CENet.front_fuse: the video token plan and the feature cast as extra blocks of the text heads' first two launches
+  (MmtVideoFront) against the same step with launches of their own -- identical losses, gradients, weights, BatchNorm
+  statistics and dropout seed trajectory (the seed bump moves from the plan kernel to the second fused launch)."""
+  dev = torch.device('cuda', 0)
+  kw = dict(txt_pro='gbn', dropout=0.1, layers=2, steps=4)
+  a, b = _run(0, 1, dev, front_fuse=False, **kw), _run(0, 1, dev, front_fuse=True, **kw)
+  assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
+  assert torch.equal(a['grad'], b['grad'])
+  assert torch.equal(a['master'], b['master'])
+  assert a['seed'] == b['seed']
   for k in a['buffers']:
     assert torch.equal(a['buffers'][k], b['buffers'][k]), k
 
