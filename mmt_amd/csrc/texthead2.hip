@@ -171,7 +171,8 @@ __global__ __launch_bounds__(TH_T) void th_fwd1_kernel(ThArgs a) {
   th_fwd1_block(a, (int)blockIdx.x, *(ThSmem*)th_smem_raw);
 }
 
-static_assert(sizeof(ThArgs) + sizeof(VideoPlanArgs) + 64 <= 4096 && sizeof(ThArgs) + sizeof(VideoCastArgs) + 64 <= 4096,
+struct CastSplit { int32_t begin[MMT_MAX_EXPERTS + 1]; };  // cast blocks of expert e: [begin[e], begin[e + 1]), ~ its width
+static_assert(sizeof(ThArgs) + sizeof(VideoPlanArgs) + 64 <= 4096 && sizeof(ThArgs) + sizeof(VideoCastArgs) + sizeof(CastSplit) + 64 <= 4096,
               "kernel arguments: 4 KiB");
 // The same launch carrying the video side's token plan as B extra blocks (4 of their 16 waves work, video_front.h).
 __global__ __launch_bounds__(TH_T) void th_fwd1_plan_kernel(ThArgs a, VideoPlanArgs p, int th_blocks) {
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(TH_T) void th_fwd2_kernel(ThArgs a) {
 
 // The same launch carrying the video side's feature cast (cast_bx blocks per expert) and the per-step bump of the
 // dropout seed (the text heads read the seed in their FIRST launch, the encoder after this one).
-__global__ __launch_bounds__(TH_T) void th_fwd2_cast_kernel(ThArgs a, VideoCastArgs c, int th_blocks, int cast_bx,
+__global__ __launch_bounds__(TH_T) void th_fwd2_cast_kernel(ThArgs a, VideoCastArgs c, int th_blocks, CastSplit cs, int M,
                                                             uint32_t* seed_bump) {
   extern __shared__ __attribute__((aligned(16))) unsigned char th_smem_raw[];
   if (blockIdx.x == 0 && threadIdx.x == 0 && seed_bump) *seed_bump += 1u;
@@ -261,7 +262,11 @@ __global__ __launch_bounds__(TH_T) void th_fwd2_cast_kernel(ThArgs a, VideoCastA
     return;
   }
   const int r = (int)blockIdx.x - th_blocks;
-  video_cast_block(c, r / cast_bx, r % cast_bx, cast_bx, (int)threadIdx.x, TH_T);
+  int ex = 0;
+#pragma unroll 1
+  for (int q = 1; q < M; ++q)
+    if (r >= cs.begin[q]) ex = q;
+  video_cast_block(c, ex, r - cs.begin[ex], cs.begin[ex + 1] - cs.begin[ex], (int)threadIdx.x, TH_T);
 }
 
 // one wave per (n, m): e = o / max(|o|, 1e-12) -> (B, M, C, d)
@@ -551,17 +556,24 @@ int mmt_text_heads_fwd_small(const MmtTextHeads* h, const float* text, const flo
       return e;
     if ((size_t)vf->M * vf->T * sizeof(float) > sizeof(ThSmem)) return MMT_ERR_ARG;
     VideoCastArgs c = {};
+    CastSplit cs = {};
     int cast_blocks = 0;
-    // cast blocks per expert: with the text heads' blocks, two 1024-thread blocks per CU at most (they all carry the
-    // text heads' 78 KiB of dynamic LDS)
-    const int cast_bx = 56;
     if (vf->do_cast) {
       if (int e = video_cast_args(c, vf->experts, vf->M, vf->B, vf->T, vf->src)) return e;
-      cast_blocks = cast_bx * vf->M;
+      // ~400 cast blocks (with the text heads' blocks: two 1024-thread blocks per CU, all carrying the text heads' 78 KiB
+      // of dynamic LDS), shared out by input width: rgb / scene (2048 / 2208 channels) get 16x the blocks of audio (128)
+      int64_t wsum = 0;
+      for (int i = 0; i < vf->M; ++i) wsum += vf->experts[i].Dpad;
+      for (int i = 0; i < vf->M; ++i) {
+        cs.begin[i] = cast_blocks;
+        const int64_t share = (400 * (int64_t)vf->experts[i].Dpad + wsum - 1) / wsum;
+        cast_blocks += (int)(share < 1 ? 1 : share);
+      }
+      cs.begin[vf->M] = cast_blocks;
     }
     hipLaunchKernelGGL(th_fwd1_plan_kernel, dim3(blocks1 + vf->B), dim3(TH_T), sizeof(ThSmem), s, a, p, blocks1);
     hipLaunchKernelGGL(th_fwd2_cast_kernel, dim3(gemm_blocks + cast_blocks), dim3(TH_T), sizeof(ThSmem), s, a, c, gemm_blocks,
-                       cast_bx, vf->seed_bump);
+                       cs, vf->M, vf->seed_bump);
   } else {
     hipLaunchKernelGGL(th_fwd1_kernel, dim3(blocks1), dim3(TH_T), sizeof(ThSmem), s, a);
     hipLaunchKernelGGL(th_fwd2_kernel, dim3(gemm_blocks), dim3(TH_T), sizeof(ThSmem), s, a);

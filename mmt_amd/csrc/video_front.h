@@ -159,23 +159,46 @@ __device__ __forceinline__ void video_cast_block(const VideoCastArgs& c, const i
   const int rows = src.src_cnt[ex];
   const int32_t* __restrict__ xs = src.xsrc + (int64_t)ex * B * T;
   const int64_t n = (int64_t)rows * (e.Dpad / 4);
-  for (int64_t i = bx * (int64_t)nthreads + tid; i < n; i += (int64_t)nbx * nthreads) {
-    const int r = (int)(i / (e.Dpad / 4)), c = (int)(i % (e.Dpad / 4)) * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* srcp = r < B ? e.maxpool + (int64_t)r * e.D : e.feat + (int64_t)xs[r - B] * e.D;
-    if (c + 3 < e.D && !(e.D & 3)) {
-      const f32x4 q = *(const f32x4*)(srcp + c);
-      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-    } else {
+  const int64_t stride = (int64_t)nbx * nthreads;
+  const bool vec = !(e.D & 3);
+  // four elements per pass, their (dependent) row lookups and then their feature loads in flight together: a thread that
+  // walks its elements one by one spends a lookup + a load round trip on each
+  for (int64_t i0 = bx * (int64_t)nthreads + tid; i0 < n; i0 += 4 * stride) {
+    int r[4], cc[4];
+    int64_t srow[4];
+    bool ok[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (c + k < e.D) v[k] = srcp[c + k];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * stride;
+      ok[u] = i < n;
+      const int64_t ii = ok[u] ? i : 0;
+      r[u] = (int)(ii / (e.Dpad / 4));
+      cc[u] = (int)(ii % (e.Dpad / 4)) * 4;
+      srow[u] = r[u] < B ? -1 : (int64_t)xs[r[u] - B];
     }
-    u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-    *(u32x2*)((bf16_t*)e.x + (int64_t)r * e.Dpad + c) = o;
+    f32x4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* srcp = r[u] < B ? e.maxpool + (int64_t)r[u] * e.D : e.feat + srow[u] * e.D;
+      q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) {
+        if (vec && cc[u] + 3 < e.D) {
+          q[u] = *(const f32x4*)(srcp + cc[u]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (cc[u] + k < e.D) q[u][k] = srcp[cc[u] + k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) {
+        u32x2 o = {pack_bf2(q[u][0], q[u][1]), pack_bf2(q[u][2], q[u][3])};
+        *(u32x2*)((bf16_t*)e.x + (int64_t)r[u] * e.Dpad + cc[u]) = o;
+      }
   }
 }
-
 
 static inline int make_table(const MmtExpertIO* experts, int M, ExpertTable& tab) {
   if (!experts || M <= 0 || M > MMT_MAX_EXPERTS) return MMT_ERR_ARG;

@@ -17,7 +17,7 @@ rows = c.execute('select name, start, end, grid_x, workgroup_x, %s from kernels 
 # A step OPENS with the first text-head kernel (th_fwd1_kernel: once per step in every mode; the video plan kernel when
 # the text heads run elsewhere).  (Up to r02 every step opened with the device-to-device copy of the minibatch; with
 # input slots there is no such copy.)
-starts = [i for i, r in enumerate(rows) if 'th_fwd1_kernel' in r[0]] or [i for i, r in enumerate(rows) if 'video_plan_kernel' in r[0]]
+starts = [i for i, r in enumerate(rows) if 'th_fwd1' in r[0]] or [i for i, r in enumerate(rows) if 'video_plan_kernel' in r[0]]
 if len(starts) < 3:
   sys.exit('fewer than three steps in the trace')
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
