@@ -39,6 +39,8 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
   assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
   assert ctypes.sizeof(_lib.MmtBertBatch) == 104  # + side_stream (r03)
+  assert ctypes.sizeof(_lib.MmtVideoFront) == 8 + 6 * 4 + 11 * 8  # experts | M B T pack max_pos do_cast | 11 pointers
+  assert ctypes.sizeof(_lib.MmtTextHeadsOpts) == 16 + 4 * 8          # + video_front (r03)
 
 
 def test_product_path_refuses_cpu_tensors():
