@@ -733,6 +733,13 @@ class GraphedTrainStep:
     else:
       _copy_tree(static, minibatch)
 
+  def wait_upload(self, slot):
+    """Host-side wait until the last `upload` into `slot` has left its pinned source buffer (before the loader refills
+    that buffer)."""
+    ev = self._slot_ev[slot] if self._slot_ev is not None else None
+    if ev is not None and ev['ready'] is not None:
+      ev['ready'].synchronize()
+
   def upload(self, minibatch, slot):
     """Start copying a HOST (pinned) FlatMinibatch straight into the input buffers of `slot` on a copy stream; the next
     `step(slot)` waits for it, and the upload itself waits until the previous `step(slot)` has been issued AND has run.
