@@ -266,21 +266,38 @@ __global__ __launch_bounds__(TH_T) void th_fwd2_cast_kernel(ThArgs a, VideoCastA
 #pragma unroll 1
   for (int q = 1; q < M; ++q)
     if (r >= cs.begin[q]) ex = q;
-  video_cast_block(c, ex, r - cs.begin[ex], cs.begin[ex + 1] - cs.begin[ex], (int)threadIdx.x, TH_T);
+  video_cast_block(c, ex, r - cs.begin[ex], cs.begin[ex + 1] - cs.begin[ex], (int)threadIdx.x, TH_T, 0, 2);  // first half
 }
 
 // one wave per (n, m): e = o / max(|o|, 1e-12) -> (B, M, C, d)
-__global__ __launch_bounds__(256) void th_fwd3_kernel(ThArgs a) {
+__device__ __forceinline__ void th_fwd3_block(const ThArgs& a, const int bid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ct = a.d / 32;
   const ThWs w = th_layout(a.ws, a.N, a.M, a.d);
-  const int r = blockIdx.x * 4 + wave;
+  const int r = bid * 4 + wave;
   if (r >= a.N * a.M) return;
   const int n = r / a.M, m = r % a.M;
   const float ss = wave_sum(lane < ct ? w.part[(int64_t)r * ct + lane] : 0.f);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
   const int64_t src = (int64_t)r * a.d, dst = (((int64_t)(n / a.C) * a.M + m) * a.C + n % a.C) * a.d;
   for (int c = lane * 4; c < a.d; c += 256) *(f32x4*)(a.text_embds + dst + c) = *(const f32x4*)(w.o + src + c) * inv;
+}
+
+__global__ __launch_bounds__(256) void th_fwd3_kernel(ThArgs a) { th_fwd3_block(a, (int)blockIdx.x); }
+
+// The third launch carrying the second half of the feature cast: 256-thread blocks without LDS, i.e. as many per CU as the
+// stand-alone cast had (the blocks riding in the second launch inherit its 78 KiB of LDS: two per CU).
+__global__ __launch_bounds__(256) void th_fwd3_cast_kernel(ThArgs a, VideoCastArgs c, int th_blocks, CastSplit cs, int M) {
+  if ((int)blockIdx.x < th_blocks) {
+    th_fwd3_block(a, (int)blockIdx.x);
+    return;
+  }
+  const int r = (int)blockIdx.x - th_blocks;
+  int ex = 0;
+#pragma unroll 1
+  for (int q = 1; q < M; ++q)
+    if (r >= cs.begin[q]) ex = q;
+  video_cast_block(c, ex, r - cs.begin[ex], cs.begin[ex + 1] - cs.begin[ex], (int)threadIdx.x, 256, 1, 2);  // second half
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -574,6 +591,13 @@ int mmt_text_heads_fwd_small(const MmtTextHeads* h, const float* text, const flo
     hipLaunchKernelGGL(th_fwd1_plan_kernel, dim3(blocks1 + vf->B), dim3(TH_T), sizeof(ThSmem), s, a, p, blocks1);
     hipLaunchKernelGGL(th_fwd2_cast_kernel, dim3(gemm_blocks + cast_blocks), dim3(TH_T), sizeof(ThSmem), s, a, c, gemm_blocks,
                        cs, vf->M, vf->seed_bump);
+    if (cast_blocks) {  // second half of the cast: 4x the blocks (a quarter of the threads each)
+      CastSplit c3 = cs;
+      for (int i = 0; i <= vf->M; ++i) c3.begin[i] = cs.begin[i] * 4;
+      hipLaunchKernelGGL(th_fwd3_cast_kernel, dim3((N * M + 3) / 4 + 4 * cast_blocks), dim3(256), 0, s, a, c, (N * M + 3) / 4, c3,
+                         vf->M);
+      return (int)hipGetLastError();
+    }
   } else {
     hipLaunchKernelGGL(th_fwd1_kernel, dim3(blocks1), dim3(TH_T), sizeof(ThSmem), s, a);
     hipLaunchKernelGGL(th_fwd2_kernel, dim3(gemm_blocks), dim3(TH_T), sizeof(ThSmem), s, a);

@@ -150,20 +150,23 @@ __device__ __forceinline__ void video_plan_block(const VideoPlanArgs& p, const i
 // live count exit, the weight gradient zeroes the ragged tail of its last 64-row unit).
 struct VideoCastArgs { CastExperts tab; int B, T; MmtVideoSrc src; };
 // Block bx of nbx (of nthreads threads each) working on expert ex.
+// part / parts: this launch handles the part-th of `parts` equal slices of every expert's elements (the cast can be spread
+// over two launches that carry it as a rider).
 __device__ __forceinline__ void video_cast_block(const VideoCastArgs& c, const int ex, const int bx, const int nbx,
-                                                 const int tid, const int nthreads) {
+                                                 const int tid, const int nthreads, const int part = 0, const int parts = 1) {
   struct { const float *feat, *maxpool; void* x; int D, Dpad; } e = {c.tab.feat[ex], c.tab.maxpool[ex], c.tab.x[ex],
                                                                      c.tab.D[ex], c.tab.Dpad[ex]};
   const int B = c.B, T = c.T;
   const MmtVideoSrc src = c.src;
   const int rows = src.src_cnt[ex];
   const int32_t* __restrict__ xs = src.xsrc + (int64_t)ex * B * T;
-  const int64_t n = (int64_t)rows * (e.Dpad / 4);
+  const int64_t n_all = (int64_t)rows * (e.Dpad / 4);
+  const int64_t lo = n_all * part / parts, n = n_all * (part + 1) / parts;  // elements [lo, n)
   const int64_t stride = (int64_t)nbx * nthreads;
   const bool vec = !(e.D & 3);
   // four elements per pass, their (dependent) row lookups and then their feature loads in flight together: a thread that
   // walks its elements one by one spends a lookup + a load round trip on each
-  for (int64_t i0 = bx * (int64_t)nthreads + tid; i0 < n; i0 += 4 * stride) {
+  for (int64_t i0 = lo + bx * (int64_t)nthreads + tid; i0 < n; i0 += 4 * stride) {
     int r[4], cc[4];
     int64_t srow[4];
     bool ok[4];
