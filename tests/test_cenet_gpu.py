@@ -464,9 +464,11 @@ def test_similarity_large_batch_gemm_path(nv, c):
     assert err < 1e-4 * max(1.0, b.grad.abs().max().item()), (nm, err)
 
 
-@pytest.mark.parametrize('name,tol', [('tiny', 1e-2), ('configA', 1e-2), ('configB', 5e-2)])
+# bounds = 1.5 x what was measured on MI355X (r03: worst parameter 0.0080 / 0.0087 / 0.0328 -- a query / key projection of
+# an upper layer --, whole gradient buffer as one vector 0.0038 / 0.0053 / 0.0099, median parameter 0.0036 / 0.0053 / 0.0099)
+@pytest.mark.parametrize('name,tol,tol_all', [('tiny', 1.2e-2, 6e-3), ('configA', 1.3e-2, 8e-3), ('configB', 5e-2, 1.5e-2)])
 @pytest.mark.parametrize('pack', [False, True])
-def test_every_parameter_gradient_matches_oracle_autograd(name, tol, pack):
+def test_every_parameter_gradient_matches_oracle_autograd(name, tol, tol_all, pack):
   """The WHOLE gradient, parameter by parameter, against autograd through the CPU oracle (itself pinned to the reference by
   tests/golden) -- not a few probes.  Objective: sum(sims * R) with a fixed random R: max-margin is piecewise linear in the
   sims, so bf16-level differences flip hinges and a comparison under it measures hinge flips (1.5 % on EVERY parameter,
@@ -517,6 +519,9 @@ def test_every_parameter_gradient_matches_oracle_autograd(name, tol, pack):
     assert float((gv - rv).abs().max() / rv.abs().max()) <= max(tol, 0.15), (gv, rv)
   got, want = torch.cat(got), torch.cat(want)
   total = float((got - want).norm() / want.norm())
-  assert total <= 0.8 * tol, total  # the flat gradient buffer as one vector
+  assert total <= tol_all, total  # the flat gradient buffer as one vector
   med = float(np.median(list(rels.values())))
-  assert med <= 0.8 * tol, med
+  assert med <= tol_all, med
+  worst = max((k for k in rels if k not in moe_bias), key=rels.get)
+  print('gradient parity %s pack=%s: worst parameter %s rel %.4f | whole buffer %.4f | median %.4f' %
+        (name, pack, worst, rels[worst], total, med))
