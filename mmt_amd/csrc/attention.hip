@@ -116,6 +116,18 @@ __device__ __forceinline__ void store_block16(bf16_t* ob, const f32x4* o, float 
   __builtin_amdgcn_s_waitcnt(0xc07f);  // the corner may be reused by the caller
 }
 
+#ifdef MMT_GEMM2_INSTR
+// lab build only (python -m mmt_amd.build --instr; tools/attn_budget.py): per-block phase timestamps of the backward kernel
+__device__ long long* g_attn_dbg = nullptr;
+extern "C" int mmt_debug_set_attn_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &p, sizeof(p)); }
+#define ATT_BLK() ((int64_t)blockIdx.x * 16)
+#define ATT_MARK(k) do { if (g_attn_dbg && threadIdx.x == 0) g_attn_dbg[ATT_BLK() + (k)] = clock64(); } while (0)
+#define ATT_SET(k, v) do { if (g_attn_dbg && threadIdx.x == 0) g_attn_dbg[ATT_BLK() + (k)] = (long long)(v); } while (0)
+#else
+#define ATT_MARK(k) do {} while (0)
+#define ATT_SET(k, v) do {} while (0)
+#endif
+
 struct AttnArgs {
   const bf16_t* qkv; int64_t ld;       // [rows, 3d]
   const int32_t* cu; int S_dense;      // cu nullable => dense b*S_dense
@@ -125,7 +137,7 @@ struct AttnArgs {
   const bf16_t* dctx;                  // [rows, d] bwd
   bf16_t* dqkv;                        // [rows, 3d] bwd out
   float* delta;                        // [rows, H] bwd scratch: rowsum(dO * O)
-  int H, d; float scale;
+  int H, d, B; float scale;
   uint32_t drop_key, thr16; float drop_scale; int S4;
   const uint32_t* seed_dev;
   // Query subset (last encoder layer: only the rows that are read out need a context vector).  qsel[b*nq + i] is
@@ -162,10 +174,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 64 * 2 + 2 * 64 * 2];
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][64]
   int* kpos_s = (int*)(bias_s + 2 * 64);              // [2][64] original positions of the tile's keys
-  const int b = blockIdx.z, h = blockIdx.y;
+  // 1-D grid, (sample, head) fastest: consecutive block ids -- which the dispatcher deals out to the 8 XCDs in turn -- are the
+  // same query tile of different (sample, head) pairs.  With (q tile, head, sample) as grid (x, y, z) every XCD received ONE
+  // (q tile, head mod ..) combination, and under token packing the later q tiles are mostly empty: half the XCDs idled.
+  const int nbh = a.H * a.B, bh = (int)blockIdx.x % nbh;
+  const int b = bh / a.H, h = bh % a.H;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
-  const int q0 = blockIdx.x * (16 * NW);
+  const int q0 = ((int)blockIdx.x / nbh) * (16 * NW);
   const int nqs = a.qsel ? a.nq : Sb;  // queries of this sample
   if (q0 >= nqs || Sb <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -270,11 +286,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
 //   dA^T[key][q] = V . dO^T ; dS = P o (keep*dA*sc - delta) ; dQ^T[d][q] += K^T . dS^T
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* smem, int bx) {
+__device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* smem, int bx, int b, int h) {
   float* bias_s = (float*)(smem + 2 * 2 * 64 * DH);
   int* kpos_s = (int*)(bias_s + 2 * 64);
   const bool dense_keys = a.row_index == nullptr;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int q0 = bx * 64;
@@ -332,10 +347,13 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* sme
     }
   };
   stage(0, 0);
+  ATT_MARK(1); ATT_SET(5, nkt); ATT_SET(6, 0); ATT_SET(7, Sb);
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (kt == 0) ATT_MARK(2);
+    if (kt == 1) ATT_MARK(8);
     if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
     const bf16_t* Ks = smem + cur * (2 * 64 * DH);
     const bf16_t* Vs = Ks + 64 * DH;
@@ -370,6 +388,7 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* sme
     }
   }
   __syncthreads();  // stage buffers idle: each wave transposes its block in its own corner
+  ATT_MARK(3);
   store_block16<DH>(smem + wave * 16 * (DH + 8), o, a.scale, lane, [&](int r) -> bf16_t* {
     const int qr = q0 + wave * 16 + r;
     if (qr >= nqs) return nullptr;
@@ -384,9 +403,8 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, bf16_t* sme
 //   dV^T[d][key] += dO^T . A ; dK^T[d][key] += Q^T . dS     (a = transpose reads of the dO / Q tiles)
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* smem, int bx) {
+__device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* smem, int bx, int b, int h) {
   float* aux_s = (float*)(smem + 2 * 2 * 64 * DH);  // [2][3][64]: lse2, delta, rowkey(bits)
-  const int b = blockIdx.z, h = blockIdx.y;
   const int off = a.cu ? a.cu[b] : b * a.S_dense;
   const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int k0 = bx * 64;
@@ -455,10 +473,13 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* sm
     }
   };
   stage(0, 0);
+  ATT_MARK(1); ATT_SET(5, nqt); ATT_SET(6, 1); ATT_SET(7, Sb);
   for (int qt = 0; qt < nqt; ++qt) {
     const int cur = qt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (qt == 0) ATT_MARK(2);
+    if (qt == 1) ATT_MARK(8);
     if (qt + 1 < nqt) stage(qt + 1, cur ^ 1);
     const bf16_t* Qs = smem + cur * (2 * 64 * DH);
     const bf16_t* dOs = Qs + 64 * DH;
@@ -502,6 +523,7 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* sm
     }
   }
   __syncthreads();  // stage buffers idle: each wave transposes its blocks in its own corner
+  ATT_MARK(3);
   auto krow_ptr = [&](int r, int section) -> bf16_t* {
     const int kl = k0 + wave * 16 + r;
     return kl < Sb ? a.dqkv + (int64_t)(off + kl) * a.ld + section * a.d + h * DH : nullptr;
@@ -511,15 +533,31 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, bf16_t* sm
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, ONE launch: blocks [0, q_tiles) of grid.x take the dQ role, blocks [q_tiles, q_tiles + key_tiles) the dK/dV
-// role.  The two roles are independent (the dK/dV blocks form delta themselves), so the whole backward of a layer's
+// backward, ONE launch, 1-D grid of (q_tiles + k_tiles) slots x (sample, head) pairs, the pair index fastest (see the
+// forward kernel: consecutive ids go to different XCDs, so every XCD gets the same mix of live and empty tiles).  Slots
+// alternate between the two roles, the longer dK/dV role first: slot 2 i = dK/dV of key tile i, slot 2 i + 1 = dQ of query
+// tile i.  The two roles are independent (the dK/dV blocks form delta themselves), so the whole backward of a layer's
 // attention is one node of the step graph and its two halves share the CUs instead of running back to back.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, int q_tiles) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, int q_tiles, int k_tiles) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 64 * DH + 2 * 3 * 64 * 2];
-  if ((int)blockIdx.x < q_tiles) attn_bwd_dq_block<DH>(a, smem, (int)blockIdx.x);
-  else attn_bwd_dkv_block<DH>(a, smem, (int)blockIdx.x - q_tiles);
+  ATT_MARK(0);
+  const int nbh = a.H * a.B, bh = (int)blockIdx.x % nbh, slot = (int)blockIdx.x / nbh;
+  const int b = bh / a.H, h = bh % a.H;
+  const int m = min(q_tiles, k_tiles);
+  int role, tile;  // role 0 = dK/dV, 1 = dQ
+  if (slot < 2 * m) { role = slot & 1; tile = slot >> 1; }
+  else { role = q_tiles > k_tiles ? 1 : 0; tile = slot - m; }
+  if (role) attn_bwd_dq_block<DH>(a, smem, tile, b, h);
+  else attn_bwd_dkv_block<DH>(a, smem, tile, b, h);
+#ifdef MMT_GEMM2_INSTR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_MARK(4);
+  ATT_SET(9, __builtin_amdgcn_s_getreg((31 << 11) | 20));
+  ATT_SET(10, __builtin_amdgcn_s_getreg((31 << 11) | 4));
+  ATT_SET(11, wall_clock64());
+#endif
 }
 
 // test helper: materialise the attention dropout keep-mask, uint8 [B,H,S,S] (dense layout only)
@@ -550,11 +588,11 @@ static int launch_fwd(const AttnArgs& a, int nq, int H, int B, bool dh128, hipSt
     waves = e ? atoi(e) : 8;
   }
   if (waves == 8 && nq > 64) {
-    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 8>), dim3((nq + 127) / 128, H, B), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), dim3((nq + 127) / 128, H, B), dim3(512), 0, s, a);
+    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 8>), dim3(((nq + 127) / 128) * H * B), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), dim3(((nq + 127) / 128) * H * B), dim3(512), 0, s, a);
   } else {
-    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), dim3((nq + 63) / 64, H, B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), dim3((nq + 63) / 64, H, B), dim3(256), 0, s, a);
+    if (dh128) hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), dim3(((nq + 63) / 64) * H * B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), dim3(((nq + 63) / 64) * H * B), dim3(256), 0, s, a);
   }
   return (int)hipGetLastError();
 }
@@ -567,15 +605,16 @@ static int launch_bwd(const AttnArgs& a, int tq, int tk, int H, int B, bool dh12
     const char* e = getenv("MMT_ATTN_BWD_SPLIT");
     split = e ? atoi(e) : 0;
   }
-  auto go = [&](int gx, int q_tiles) {
-    if (dh128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(gx, H, B), dim3(256), 0, s, a, q_tiles);
-    else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(gx, H, B), dim3(256), 0, s, a, q_tiles);
+  auto go = [&](int q_tiles, int k_tiles) {
+    const int gx = (q_tiles + k_tiles) * H * B;
+    if (dh128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(gx), dim3(256), 0, s, a, q_tiles, k_tiles);
+    else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(gx), dim3(256), 0, s, a, q_tiles, k_tiles);
   };
   if (split) {
-    go(tq, tq);
-    go(tk, 0);
+    go(tq, 0);
+    go(0, tk);
   } else {
-    go(tq + tk, tq);
+    go(tq, tk);
   }
   return (int)hipGetLastError();
 }
@@ -587,7 +626,7 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
   if (!mask_bias || !ctx || !lse) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
-  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.B = B; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   return launch_fwd(a, S, H, B, d == H * 128, (hipStream_t)stream);
@@ -602,7 +641,7 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
-  a.delta = delta; a.H = H; a.d = d; a.scale = scale;
+  a.delta = delta; a.H = H; a.d = d; a.B = B; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   const int tiles = (S + 63) / 64;
@@ -619,7 +658,7 @@ extern "C" int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   if (!mask_bias || !ctx || !lse || !qsel || nq <= 0) return MMT_ERR_ARG;
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
-  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.scale = scale;
+  a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = lse; a.H = H; a.d = d; a.B = B; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;
@@ -635,7 +674,7 @@ extern "C" int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, con
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = 3 * (int64_t)d; a.cu = cu_seqlens; a.S_dense = S; a.mask_bias = mask_bias;
   a.ctx = (bf16_t*)ctx; a.ldc = d; a.lse = (float*)lse; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
-  a.delta = delta; a.H = H; a.d = d; a.scale = scale;
+  a.delta = delta; a.H = H; a.d = d; a.B = B; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
   a.qsel = qsel; a.nq = nq;

@@ -892,16 +892,28 @@ static int wide192_tile(int M, int N, bool packed) {
     forced3072 = a ? atoi(a) : 0;
     forced1536 = b ? atoi(b) : 0;
     if (f && atof(f) > 0.0) live_fraction = atof(f);
-    enabled = en ? atoi(en) : 0;  // whole-step A/B on one box (r02): 1.473 ms off vs 1.485 ms on -- the per-kernel lab win does not carry
+    enabled = en ? atoi(en) : 0;  // the r02 one-block-per-CU tiles 15 / 16 (whole-step A/B: 1.473 ms off vs 1.485 ms on); MMT_TILE_192=3: tile 20 below
   }
   if (N == 3072 && forced3072) return forced3072;
   if (N == 1536 && forced1536) return forced1536;
-  if (!enabled) return 0;
   const int est = packed ? (int)(M * live_fraction) : M;
   const int cols = N / 192;
   const int big = ((est + 255) / 256) * cols, mid = ((est + 127) / 128) * cols;
-  if (big > 128 && big <= 256) return 15;   // 256x192, one block per CU, one round
-  if (mid > 128 && mid <= 256) return 16;   // 128x192
+  if (enabled == 1) {
+    if (big > 128 && big <= 256) return 15;   // 256x192, one block per CU, one round
+    if (mid > 128 && mid <= 256) return 16;   // 128x192
+    return 0;
+  }
+  // r04 (tools/gemm2_budget.py): a launch of these GEMMs lasts as long as the blocks one residency slot runs back to back
+  // (two slots per CU; blocks resident together move in lock-step through K-loop and epilogue).  3 639 live rows x N = 3072
+  // are 696 tiles of 128x128 on 512 slots: two blocks deep; the same rows are 464 tiles of 128x192 -- every tile resident at
+  // once (tile 20 = tile 16 with a two-deep ring, 80 KiB: two blocks per CU).  Measured: the block gets 1.37x longer (its
+  // GELU sweep is VALU-bound and scales with the tile), FFN-up 29.5 -> 27.6 us, the dGELU variant 30.5 -> 34.6 us (its
+  // registers allow one block per CU), whole step 1.302 -> 1.339 ms: opt-in only (MMT_TILE_192=3).
+  if (enabled == 3) {
+    const int sq = ((est + 127) / 128) * (N / 128);
+    if (sq > 512 && mid <= 512) return 20;
+  }
   return 0;
 }
 

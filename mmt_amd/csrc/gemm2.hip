@@ -126,6 +126,9 @@ __device__ __forceinline__ void gemm2_body(
   // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
   // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
   constexpr bool STAG = !PH && NW == 8 && NS >= 3;
+#ifdef MMT_GEMM2_INSTR
+  const long long t_entry = clock64(), w_entry = wall_clock64();  // shader clock (per CU, for durations) and the chip-wide 100 MHz counter
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;
 
@@ -397,6 +400,10 @@ __device__ __forceinline__ void gemm2_body(
       }
   }
   __syncthreads();  // every wave is done with the stage buffers
+#ifdef MMT_GEMM2_INSTR
+  long long e_head = clock64() - t_loop_end, e_stage = 0, e_sweep = 0;
+  tp = clock64();
+#endif
 #pragma unroll
   for (int ch = 0; ch < BM / CH; ++ch) {
     if ((wm * WTM) / CH == ch && kg == 0) {  // this wave's rows belong to chunk ch
@@ -427,6 +434,7 @@ __device__ __forceinline__ void gemm2_body(
       }
     }
     __syncthreads();
+    TICK(e_stage);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       const int lcol = cb * CB + cg * 4;  // column inside the tile
@@ -504,12 +512,20 @@ __device__ __forceinline__ void gemm2_body(
       }
     }
     __syncthreads();
+    TICK(e_sweep);
   }
 #ifdef MMT_GEMM2_INSTR
   if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
-    long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 8;
+    long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 16;
     dbgbuf[0] = t_wait; dbgbuf[1] = t_bar; dbgbuf[2] = t_issue; dbgbuf[3] = t_comp;
-    dbgbuf[4] = t_loop_end - t0; dbgbuf[5] = clock64() - t_loop_end; dbgbuf[6] = t0; dbgbuf[7] = KT;
+    dbgbuf[4] = t_loop_end - t0; dbgbuf[5] = clock64() - t_loop_end; dbgbuf[7] = KT;
+    dbgbuf[8] = t0 - t_entry; dbgbuf[9] = e_head; dbgbuf[10] = e_stage; dbgbuf[11] = e_sweep; dbgbuf[12] = w_entry;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's stores have left the wave
+    dbgbuf[6] = clock64() - t_entry;  // whole block, shader cycles
+    dbgbuf[13] = wall_clock64();
+    // where the block ran: XCC_ID (hwreg 20) and HW_ID (hwreg 4: cu_id [11:8], sh_id [12], se_id [15:13])
+    dbgbuf[14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    dbgbuf[15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
 #endif
 }
@@ -785,6 +801,8 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
       if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;
+    case 20: if (N % 192 == 0) G2(128, 192, 4, 2, 2); break;  // 8 waves on 128x192 (wave 32x96), in phase, TWO-deep ring:
+                                                              // 80 KiB of LDS = two blocks per CU (tile 16's three stages allow one)
     case 19:  // 2 x 4 waves on 128x128, PHASED (wave tile 64x64)
       if (N % 128 == 0) return launch2<128, 128, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;

@@ -91,7 +91,7 @@ def main():
   for tile in tiles:
     if tile < 3 or args.nocheck:
       continue
-    for (M, N, K) in ([(300, 384, 128), (777, 576, 192), (1000, 768, 64)] if tile in (15, 16, 17) else
+    for (M, N, K) in ([(300, 384, 128), (777, 576, 192), (1000, 768, 64)] if tile in (15, 16, 17, 20) else
                       [(300, 256, 128), (777, 512, 192), (1000, 768, 64)]):
       errs = check(tile, M, N, K)
       ok = errs[0] < 0.1 and errs[1] < 0.05 and errs[2] < 2e-3 and errs[3] < 2e-2 and errs[4] < 2e-2
@@ -134,7 +134,7 @@ def main():
       cs = torch.zeros((rows + 127) // 128, N, device=dev)
       fns, used = [], []
       for tile in tiles:
-        if (tile in (4, 6) and N % 256) or (tile in (15, 16, 17) and N % 192):
+        if (tile in (4, 6) and N % 256) or (tile in (15, 16, 17, 20) and N % 192):
           continue
         kw = dict(bias=bias, res=res, out2=out2, aux=aux, tile=tile)
         if epi == 'BIAS_DROP_RES':
