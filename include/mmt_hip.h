@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 1
+#define MMT_ABI_VERSION 2  /* r04: MmtEpilogue.dot_*, MmtBertBatch / MmtTextHeadsOpts as of r03, mmt_attn_bwd*_ex, delta [rows, d/64] */
 #define MMT_ROW_ALIGN 256
 
 #define MMT_ERR_ARG (-1)    /* unsupported shape / null pointer */
@@ -62,6 +62,13 @@ typedef struct MmtEpilogue {
   uint32_t drop_thr16;      /* keep iff u16 >= thr16; 0 disables dropout                        */
   float drop_scale;         /* 1 / (1 - thr16/65536)                                            */
   int32_t reserved;         /* 0 = auto tile; 1 = force 128x128; 2 = force 128x64 (tests/tuning)       */
+  /* MMT_EPI_BF16 only, nullable: dot_out[row, n / 64] = sum over the 64 output columns of group n / 64 of
+   * out(bf16)[row, n] * dot_src(bf16)[row, n] -- with out = dO = dA . Wo and dot_src = O (the attention context) these are
+   * the "delta" sums of the attention backward (rowsum(dO * O) per head = DH / 64 groups), formed while dO is still in
+   * registers instead of by re-reading dO and O (model/bert.py:141-168 backward).  dot_out: fp32 [M, N / 64]. */
+  const void* dot_src;
+  int64_t lddot;
+  float* dot_out;
 } MmtEpilogue;
 
 /* C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous bf16, fp32 accumulate on MFMA).
@@ -251,19 +258,30 @@ int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_b
                  int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
                  float drop_scale, const uint32_t* seed_dev,
                  const int32_t* row_index, void* stream);
-/* Backward of the above (autograd of bert.py:141-168): dqkv bf16 [rows, 3d]; delta fp32 [rows,H] scratch. */
+/* Backward of the above (autograd of bert.py:141-168): dqkv bf16 [rows, 3d].
+ * delta fp32 [rows, d/64]: sums of dctx * ctx over the 64-column groups of a row (delta of head h = its DH/64 groups).
+ * mmt_attn_bwd forms them itself (scratch, one extra launch); mmt_attn_bwd_ex(delta_ready = 1) takes them as INPUT --
+ * the epilogue of the GEMM that produced dctx writes them (MmtEpilogue.dot_src / dot_out). */
+int mmt_attn_bwd_ex(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
+                    const float* lse, const void* dctx, void* dqkv, float* delta, int delta_ready, int B, int S, int H,
+                    int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                    const uint32_t* seed_dev, const int32_t* row_index, void* stream);
 int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                  const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H, int d,
                  float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
                  const uint32_t* seed_dev,
                  const int32_t* row_index, void* stream);
 /* Query-subset attention (last encoder layer: only the rows that are read out need a context vector): queries are the
- * rows qsel[b*nq + i]; ctx / lse / dctx / delta are compact [B*nq, .]; qkv / dqkv keep the full layout.  dqkv must be
+ * rows qsel[b*nq + i]; ctx / lse / dctx / delta are compact [B*nq, .] (delta: [B*nq, d/64]); qkv / dqkv keep the full layout.  dqkv must be
  * zero on entry in the Q section of the non-selected rows. */
 int mmt_attn_fwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
                       void* ctx, float* lse, int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16,
                       float drop_scale, const uint32_t* seed_dev,
                  const int32_t* row_index, void* stream);
+int mmt_attn_bwd_rows_ex(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
+                         const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta, int delta_ready,
+                         int B, int S, int H, int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                         const uint32_t* seed_dev, const int32_t* row_index, void* stream);
 int mmt_attn_bwd_rows(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const int32_t* qsel, int nq,
                       const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H,
                       int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,

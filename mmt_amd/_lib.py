@@ -15,7 +15,8 @@ c_int, c_i64, c_u32, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
 class MmtEpilogue(ctypes.Structure):
   _fields_ = [('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('out2', c_vp), ('ldout2', c_i64),
               ('aux', c_vp), ('ldaux', c_i64), ('colsum', c_vp), ('row_index', c_vp), ('seed_dev', c_vp),
-              ('drop_key', c_u32), ('drop_thr16', c_u32), ('drop_scale', c_f32), ('reserved', ctypes.c_int32)]
+              ('drop_key', c_u32), ('drop_thr16', c_u32), ('drop_scale', c_f32), ('reserved', ctypes.c_int32),
+              ('dot_src', c_vp), ('lddot', c_i64), ('dot_out', c_vp)]
 
 
 class MmtPackItem(ctypes.Structure):
@@ -165,6 +166,10 @@ SIGNATURES = {
                              c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
                              c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
+    'mmt_attn_bwd_ex': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_f32,
+                                c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
+    'mmt_attn_bwd_rows_ex': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                     c_int, c_f32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_fwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,
                                   c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_bwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
@@ -249,7 +254,7 @@ def lib():
       fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
       fn.restype = res
       fn.argtypes = args
-    if handle.mmt_abi_version() != 1:
+    if handle.mmt_abi_version() != 2:
       raise RuntimeError('libmmt_hip.so ABI mismatch')
     _lib = handle
   return _lib

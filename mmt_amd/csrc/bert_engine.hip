@@ -60,7 +60,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   w->dz = (float*)take(R * d * 4); w->dA = (float*)take(R * d * 4);
   w->dy_[0] = take(R * d * 2); w->dy2_[0] = take(R * d * 2); w->dhpre_[0] = take(R * I * 2); w->dctx = take(R * d * 2);
   w->dqkv_[0] = take(R * 3 * d * 2);
-  w->delta = (float*)take(R * H * 4);
+  w->delta = (float*)take(R * (d / 64) * 4);  // dO * O sums per 64-column group (attention backward)
   size_t ln_nb = ((size_t)R + 15) / 16;  // blocks of mmt_ln_bwd: rows/16, or rows/4 when rows <= 2048
   const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
   if (ln_nb < small_nb) ln_nb = small_nb;
@@ -77,7 +77,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
     t.mean1 = (float*)take(C * 4); t.rstd1 = (float*)take(C * 4); t.a32 = (float*)take(C * d * 4);
     t.z2 = (float*)take(C * d * 4); t.mean2 = (float*)take(C * 4); t.rstd2 = (float*)take(C * 4);
     t.dcur = (float*)take(C * d * 4); t.dz = (float*)take(C * d * 4); t.dA = (float*)take(C * d * 4);
-    t.delta = (float*)take(C * H * 4); t.rowidx = (int32_t*)take(C * 4);
+    t.delta = (float*)take(C * (d / 64) * 4); t.rowidx = (int32_t*)take(C * 4);
     t.wslab = (float*)take((size_t)TAIL_WSPLIT * 3 * d * d * 4); t.bslab = (float*)take((size_t)TAIL_WSPLIT * 3 * d * 4);
     t.slabs = (float*)take((size_t)mmt_gemm_nt_splitk_workspace_floats((int)C, (int)d, (int)I) * 4);
   }
@@ -349,13 +349,15 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       e = {};
       // (K = hidden: 8..16 K-steps -- one pass on 16+ tiles costs what the split-K slab kernel alone does, and the
       // slab-reducing epilogue launch goes away)
+      // (the GEMM that forms dO also leaves rowsum(dO * O) per 64 columns = the attention backward's delta, in t.delta)
+      e.dot_src = t.ctx; e.lddot = d; e.dot_out = t.delta;
       if (d <= 512) TRY(mmt_gemm_nt_bf16(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, nullptr, stream));
       else TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));
       // dQ exists for the read-out rows only (the dq kernel zero-fills the rest of the Q section); the residual
       // gradient t.dz likewise: the input-gradient GEMM runs without residual and t.dz is scatter-added afterwards
-      TRY(mmt_attn_bwd_rows(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
-                            dqkv, t.delta, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
-                            b->seed_dev, b->row_index, stream));
+      TRY(mmt_attn_bwd_rows_ex(L.qkv, b->cu_seqlens, b->mask_bias, b->out_rows, b->n_out_per_sample, t.ctx, t.lse, t.dctx,
+                               dqkv, t.delta, 1, b->batch, b->seq, m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa,
+                               b->seed_dev, b->row_index, stream));
       if (fork_w) TRY(mmt_stream_fork(stream, side));  // every operand of the layer's weight gradients exists now
       {
         MmtWgradGroup g = {};
@@ -411,10 +413,11 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
     add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
     e = {};
+    e.dot_src = L.ctx; e.lddot = d; e.dot_out = w.delta;  // rowsum(dO * O) per 64 columns, while dO is in registers
     TRY(mmt_gemm_nt_bf16(dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
-    TRY(mmt_attn_bwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, b->batch, b->seq,
-                     m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    TRY(mmt_attn_bwd_ex(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, 1, b->batch, b->seq,
+                        m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
     if (fork_w) {
       // --- weight + bias gradients on the side stream, under the input-gradient GEMM below and the layers that follow ---
       TRY(mmt_stream_fork(stream, side));

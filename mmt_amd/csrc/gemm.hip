@@ -967,6 +967,8 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
   // few rows (the compact last layer): the 8-wave staggered tile has the shortest per-block latency
   if (e.reserved == 0 && M < 512 && N >= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
     return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (EPI == MMT_EPI_BF16 && e.dot_out)  // the row-dot sums live in gemm2's LDS-staged epilogue only
+    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if (N % 128 == 0 && e.reserved == 1) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   return launch_nt<128, 64, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
 }
@@ -982,7 +984,9 @@ extern "C" int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
   if (epi) e = *epi;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
-    case MMT_EPI_BF16: return dispatch_tile<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
+    case MMT_EPI_BF16:
+      if (e.dot_out && !e.dot_src) return MMT_ERR_ARG;
+      return dispatch_tile<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);
     case MMT_EPI_BIAS_BF16:
       if (!e.bias) return MMT_ERR_ARG;
       return dispatch_tile<MMT_EPI_BIAS_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, n_rows_dev, s);

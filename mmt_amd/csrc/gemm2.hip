@@ -378,7 +378,7 @@ __device__ __forceinline__ void gemm2_body(
   constexpr int SW = CH / RG, NPF = (BM / CH) * SW * NCB;
   constexpr bool PF_FITS = NPF <= 8;  // (the 256-row lab tiles would spend > 64 registers on it: they keep the in-sweep loads)
   constexpr bool PF_RES = PF_FITS && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32);
-  constexpr bool PF_AUX = PF_FITS && EPI == MMT_EPI_DGELU;
+  constexpr bool PF_AUX = PF_FITS && (EPI == MMT_EPI_DGELU || EPI == MMT_EPI_BF16);  // (BF16: dot_src, when dot_out is set)
   f32x4 pf_res[PF_RES ? NPF : 1];
   u32x2 pf_aux[PF_AUX ? NPF : 1];
   int pf_orow[PF_RES && EPI == MMT_EPI_BIAS_DROP_RES ? (BM / CH) * SW : 1];
@@ -394,8 +394,11 @@ __device__ __forceinline__ void gemm2_body(
         for (int cb = 0; cb < NCB; ++cb) {
           const int col = n0 + cb * CB + cg * 4;
           if constexpr (PF_RES) pf_res[(ch * SW + sw) * NCB + cb] = *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-          if constexpr (PF_AUX)
+          if constexpr (PF_AUX && EPI == MMT_EPI_DGELU)
             pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+          if constexpr (PF_AUX && EPI == MMT_EPI_BF16) {
+            if (epi.dot_out) pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.dot_src + (int64_t)row * epi.lddot + col);
+          }
         }
       }
   }
@@ -449,6 +452,19 @@ __device__ __forceinline__ void gemm2_body(
           if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            if constexpr (EPI == MMT_EPI_BF16) {
+              if (epi.dot_out) {  // sums of out * dot_src over each 64-column group of the row: 16 neighbouring lanes x 4 columns
+                static_assert(CG % 16 == 0, "a 64-column group is 16 lanes of one row");
+                u32x2 c;
+                if constexpr (PF_AUX) c = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
+                else c = *(const u32x2*)((const bf16_t*)epi.dot_src + (int64_t)row * epi.lddot + col);
+                float part = bf2f((bf16_t)(o[0] & 0xffff)) * bf2f((bf16_t)(c[0] & 0xffff)) + bf2f((bf16_t)(o[0] >> 16)) * bf2f((bf16_t)(c[0] >> 16)) +
+                             bf2f((bf16_t)(o[1] & 0xffff)) * bf2f((bf16_t)(c[1] & 0xffff)) + bf2f((bf16_t)(o[1] >> 16)) * bf2f((bf16_t)(c[1] >> 16));
+                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
+                if ((cg & 15) == 0) epi.dot_out[(int64_t)row * (N >> 6) + (col >> 6)] = part;
+              }
+            }
           } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
@@ -589,6 +605,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     if constexpr (EPI == MMT_EPI_BF16) {
       u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+      if (epi.dot_out) {  // (N % 64 == 0: the 16 lanes of a 64-column group share the row and run the loop together)
+        const u32x2 c = *(const u32x2*)((const bf16_t*)epi.dot_src + (int64_t)row * epi.lddot + col);
+        float part = bf2f((bf16_t)(o[0] & 0xffff)) * bf2f((bf16_t)(c[0] & 0xffff)) + bf2f((bf16_t)(o[0] >> 16)) * bf2f((bf16_t)(c[0] >> 16)) +
+                     bf2f((bf16_t)(o[1] & 0xffff)) * bf2f((bf16_t)(c[1] & 0xffff)) + bf2f((bf16_t)(o[1] >> 16)) * bf2f((bf16_t)(c[1] >> 16));
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
+        if ((threadIdx.x & 15) == 0) epi.dot_out[(int64_t)row * (N >> 6) + (col >> 6)] = part;
+      }
     } else {
       *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
     }

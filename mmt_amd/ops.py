@@ -254,7 +254,7 @@ def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, dr
   R, d3 = qkv.shape
   d = d3 // 3
   dqkv = torch.zeros_like(qkv)
-  delta = torch.zeros(R, H, device=qkv.device, dtype=torch.float32)
+  delta = torch.zeros(R, d // 64, device=qkv.device, dtype=torch.float32)  # scratch: dO * O sums per 64 columns
   thr, sc = dropout_params(drop_p)
   check(_lib.lib().mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
                                 _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _p(row_index), _stream()), 'mmt_attn_bwd')

@@ -32,9 +32,9 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
     assert name in _lib.SIGNATURES, 'no ctypes signature for ' + name
     assert len(_lib.SIGNATURES[name][1]) == nargs, 'arity mismatch for ' + name
   assert set(_lib.SIGNATURES) == set(decl)
-  assert _lib.lib().mmt_abi_version() == 1
+  assert _lib.lib().mmt_abi_version() == 2
   # struct layouts agree with the C side (sizes are what the kernels are compiled against)
-  assert ctypes.sizeof(_lib.MmtEpilogue) == 96
+  assert ctypes.sizeof(_lib.MmtEpilogue) == 120  # + dot_src / lddot / dot_out (r04)
   assert ctypes.sizeof(_lib.MmtPackItem) == 48
   assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8

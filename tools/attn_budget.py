@@ -28,7 +28,7 @@ ctx = torch.zeros(R, d, device=dev, dtype=torch.bfloat16)
 lse = torch.zeros(R, H, device=dev)
 dctx = (torch.randn(R, d, device=dev) * 0.1).to(torch.bfloat16)
 dqkv = torch.zeros_like(qkv)
-delta = torch.zeros(R, H, device=dev)
+delta = torch.zeros(R, d // 64, device=dev)
 thr, sc = ops.dropout_params(0.1)
 L = _lib.lib()
 Ld = ctypes.CDLL(_lib.LIB_PATH)
@@ -39,12 +39,14 @@ def fwd():
   _lib.check(L.mmt_attn_fwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), B, S, H, d, scale, 7, thr, sc, None, None, _stream()), 'f')
 
 
-def bwd():
-  _lib.check(L.mmt_attn_bwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), B, S, H, d, scale,
-                            7, thr, sc, None, None, _stream()), 'b')
+def bwd():  # (the delta sums are in place after the first plain call: the kernel alone, as the engine launches it)
+  _lib.check(L.mmt_attn_bwd_ex(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), 1, B, S, H, d,
+                               scale, 7, thr, sc, None, None, _stream()), 'b')
 
 
 fwd()
+_lib.check(L.mmt_attn_bwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), B, S, H, d, scale,
+                          7, thr, sc, None, None, _stream()), 'b0')
 for _ in range(3):
   bwd()
 torch.cuda.synchronize()
@@ -57,6 +59,8 @@ torch.cuda.synchronize()
 print('attention backward, %d live rows (lengths %d..%d): %.1f us per launch (eager, back to back)' %
       (rows, lens.min(), lens.max(), s.elapsed_time(e) / 20 * 1e3))
 nblk = 8 * H * B
+if '--fwd' in sys.argv:
+  bwd = fwd
 dbg = torch.zeros(nblk, 16, device=dev, dtype=torch.int64)
 Ld.mmt_debug_set_attn_buffer(ctypes.c_void_p(dbg.data_ptr()))
 bwd()
@@ -80,7 +84,7 @@ print('%d blocks: %d live, %d exit at once (no tile for them); kernel span (max 
 print('live blocks per XCC: ' + ' '.join('%d:%d' % (c, int((live & (xcc == c)).sum())) for c in range(8)) +
       ' | last exit per XCC (cycles): ' + ' '.join('%d:%.0f' % (c, x[ran & (xcc == c), 4].max().item()) for c in range(8)
                                                      if (ran & (xcc == c)).any()))
-for role, name in ((0, 'dQ   '), (1, 'dK/dV')):
+for role, name in ((0, 'dQ   '), (1, 'dK/dV'), (2, 'fwd  ')):
   for it in (1, 2, 3, 4):
     y = x[live & (x[:, 6] == role) & (x[:, 5] == it)]
     if not len(y):

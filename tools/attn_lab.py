@@ -41,7 +41,7 @@ def case(B, S, drop_p):
   lse = torch.zeros(R, H, device=dev)
   dctx = (torch.randn(R, d, device=dev) * 0.1).to(torch.bfloat16)
   dqkv = torch.zeros_like(qkv)
-  delta = torch.zeros(R, H, device=dev)
+  delta = torch.zeros(R, d // 64, device=dev)
   thr, sc = ops.dropout_params(drop_p)
   L = _lib.lib()
   scale = 128 ** -0.5
