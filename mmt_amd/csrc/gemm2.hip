@@ -375,6 +375,13 @@ __device__ __forceinline__ void gemm2_body(
   // Second operands of the epilogue (residual rows, GELU pre-activations, original row numbers of the dropout key) for
   // the WHOLE tile go out now, all at once: fetched inside the sweep, each sits behind the previous row's store -- a
   // chain of (BM / RG) global round trips per thread at the end of every tile.
+  // Element offsets of this thread's first swept row (m0 + rg, column n0 + 4 cg) in every matrix the epilogue touches: row
+  // m0 + rg + dr is that + dr * ld with dr a compile-time constant of the unrolled sweep -- a scalar multiply and one 64-bit
+  // add instead of a 64-bit row x ld product per access (two quarter-rate v_mul_lo_u32 + v_mad_u64_u32: a fifth of the
+  // sweep's instruction slots, tools/gemm2_budget.py r04).
+  const int64_t rb = m0 + rg, cb0 = n0 + cg * 4;
+  const int64_t off_c = rb * ldc + cb0, off_res = rb * epi.ldres + cb0, off_aux = rb * epi.ldaux + cb0,
+                off_o2 = rb * epi.ldout2 + cb0, off_dot = rb * epi.lddot + cb0;
   constexpr int SW = CH / RG, NPF = (BM / CH) * SW * NCB;
   constexpr bool PF_FITS = NPF <= 8;  // (the 256-row lab tiles would spend > 64 registers on it: they keep the in-sweep loads)
   constexpr bool PF_RES = PF_FITS && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32);
@@ -387,17 +394,26 @@ __device__ __forceinline__ void gemm2_body(
     for (int ch = 0; ch < BM / CH; ++ch)
 #pragma unroll
       for (int sw = 0; sw < SW; ++sw) {
-        const int row = min(m0 + ch * CH + sw * RG + rg, M - 1);
+        const int dr = ch * CH + sw * RG;
+        const bool in = m0 + dr + rg < M;  // rows past the matrix read its last row (never used)
+        const int row = in ? m0 + dr + rg : M - 1;
         if constexpr (PF_RES && EPI == MMT_EPI_BIAS_DROP_RES)
           pf_orow[ch * SW + sw] = (epi.drop_thr16 && epi.row_index) ? epi.row_index[row] : row;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-          const int col = n0 + cb * CB + cg * 4;
-          if constexpr (PF_RES) pf_res[(ch * SW + sw) * NCB + cb] = *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-          if constexpr (PF_AUX && EPI == MMT_EPI_DGELU)
-            pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+          if constexpr (PF_RES) {
+            const int64_t o = in ? off_res + (int64_t)dr * epi.ldres + cb * CB : (int64_t)(M - 1) * epi.ldres + cb0 + cb * CB;
+            pf_res[(ch * SW + sw) * NCB + cb] = *(const f32x4*)(epi.res + o);
+          }
+          if constexpr (PF_AUX && EPI == MMT_EPI_DGELU) {
+            const int64_t o = in ? off_aux + (int64_t)dr * epi.ldaux + cb * CB : (int64_t)(M - 1) * epi.ldaux + cb0 + cb * CB;
+            pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + o);
+          }
           if constexpr (PF_AUX && EPI == MMT_EPI_BF16) {
-            if (epi.dot_out) pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.dot_src + (int64_t)row * epi.lddot + col);
+            if (epi.dot_out) {
+              const int64_t o = in ? off_dot + (int64_t)dr * epi.lddot + cb * CB : (int64_t)(M - 1) * epi.lddot + cb0 + cb * CB;
+              pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.dot_src + o);
+            }
           }
         }
       }
@@ -446,18 +462,20 @@ __device__ __forceinline__ void gemm2_body(
       for (int r0 = 0; r0 < CH; r0 += RG) {
         const int r = r0 + rg;
         const int row = m0 + ch * CH + r;
+        const int dr = ch * CH + r0;  // (compile-time after unrolling)
+        const int64_t o_c = off_c + (int64_t)dr * ldc + cb * CB;
         if (row < M) {
           f32x4 v = *(const f32x4*)(st + r * P + lcol);
           v += bias4[cb];
           if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            *(u32x2*)((bf16_t*)Cout + o_c) = o;
             if constexpr (EPI == MMT_EPI_BF16) {
               if (epi.dot_out) {  // sums of out * dot_src over each 64-column group of the row: 16 neighbouring lanes x 4 columns
                 static_assert(CG % 16 == 0, "a 64-column group is 16 lanes of one row");
                 u32x2 c;
                 if constexpr (PF_AUX) c = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
-                else c = *(const u32x2*)((const bf16_t*)epi.dot_src + (int64_t)row * epi.lddot + col);
+                else c = *(const u32x2*)((const bf16_t*)epi.dot_src + off_dot + (int64_t)dr * epi.lddot + cb * CB);
                 float part = bf2f((bf16_t)(o[0] & 0xffff)) * bf2f((bf16_t)(c[0] & 0xffff)) + bf2f((bf16_t)(o[0] >> 16)) * bf2f((bf16_t)(c[0] >> 16)) +
                              bf2f((bf16_t)(o[1] & 0xffff)) * bf2f((bf16_t)(c[1] & 0xffff)) + bf2f((bf16_t)(o[1] >> 16)) * bf2f((bf16_t)(c[1] >> 16));
                 part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
@@ -467,12 +485,12 @@ __device__ __forceinline__ void gemm2_body(
             }
           } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            *(u32x2*)((bf16_t*)Cout + o_c) = o;
             // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
             const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
             const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
             u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
-            *(u32x2*)((bf16_t*)epi.out2 + (int64_t)row * epi.ldout2 + col) = g;
+            *(u32x2*)((bf16_t*)epi.out2 + off_o2 + (int64_t)dr * epi.ldout2 + cb * CB) = g;
           } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
             if (epi.drop_thr16) {
               int orow;
@@ -484,28 +502,28 @@ __device__ __forceinline__ void gemm2_body(
               for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
             }
             if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
-            else v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+            else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
+            *(f32x4*)((float*)Cout + o_c) = v;
           } else if constexpr (EPI == MMT_EPI_DGELU) {
             u32x2 a;
             if constexpr (PF_AUX) a = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
-            else a = *(const u32x2*)((const bf16_t*)epi.aux + (int64_t)row * epi.ldaux + col);
+            else a = *(const u32x2*)((const bf16_t*)epi.aux + off_aux + (int64_t)dr * epi.ldaux + cb * CB);
             v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
             v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
             v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
             v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + (int64_t)row * ldc + col) = o;
+            *(u32x2*)((bf16_t*)Cout + o_c) = o;
             if (row < nrows) {
               csum[cb][0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[cb][1] += bf2f((bf16_t)(o[0] >> 16));
               csum[cb][2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[cb][3] += bf2f((bf16_t)(o[1] >> 16));
             }
           } else if constexpr (EPI == MMT_EPI_ADD_F32) {
             if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
-            else v += *(const f32x4*)(epi.res + (int64_t)row * epi.ldres + col);
-            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+            else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
+            *(f32x4*)((float*)Cout + o_c) = v;
           } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
-            *(f32x4*)((float*)Cout + (int64_t)row * ldc + col) = v;
+            *(f32x4*)((float*)Cout + o_c) = v;
           }
         }
       }
