@@ -242,7 +242,7 @@ int mmt_table_grad(const float* g, const int32_t* ids, int rows, int d, int voca
 int mmt_table_grad_partials(const float* g, const int32_t* ids, int rows, int d, int vocab,
                             const int32_t* n_rows_dev, float* scratch, void* stream);
 /* both tables of the video BERT (ids1 nullable) as one-hot x gradient products on the exact-fp32 matrix cores, one launch;
- * same scratch layout as mmt_table_grad_partials ([chunks][vocab][d]); d % 128 == 0 */
+ * same scratch layout as mmt_table_grad_partials ([chunks][vocab][d]); d % 128 == 0, vocabularies of at most 128 rows */
 int mmt_table_grad_partials_pair(const float* g, const int32_t* ids0, int vocab0, float* scratch0, const int32_t* ids1,
                                  int vocab1, float* scratch1, int rows, int d, const int32_t* n_rows_dev, void* stream);
 int mmt_table_grad_chunks(void);
@@ -427,16 +427,26 @@ int mmt_retrieval_ranks(const float* sims, const uint8_t* qmask, int NQ, int NV,
  * (host orchestration: mmt_amd/large_sim.py).
  *   mmt_ls_fold_bf16: out16[r, m*d+c] = bf16(w[r,m] x[r,m,c]), rows R..Rpad zero.
  *   mmt_ls_finish   : S[t,v] /= sum_m tw[t,m] vw[v,m] (0 -> 1e-5), in place.
- *   mmt_ls_counts   : rowcnt[t], colcnt[c] += (zeroed by the caller), un-normalised hinge sums loss_part[t].
- *   mmt_ls_grad     : G16[t,v] = bf16((dL/dS)/den) from the global counts; gs[t,m] = sum_v G' S vw[v,m].
+ *   mmt_ls_diag     : diag_local[t] = S[t, r0+t] / den from the RAW numerators (before the division below).
+ *   mmt_ls_counts_ex: rowcnt[t] +=, colcnt[c] += (both zeroed by the caller), un-normalised hinge sums per column block
+ *                     loss_part[t, cb], cb < mmt_ls_col_blocks(n); finish = 1 also divides the raw numerators (one sweep).
+ *   mmt_ls_counts   : the same with finish = 0.
+ *   mmt_ls_grad     : G16[t,v] = bf16((dL/dS)/den) from the global counts; gs_part[t,cb,m] = sum over column block cb of
+ *                     G' S vw[v,m].
+ * n, ld, ldg multiples of 4.
  *   mmt_ls_unfold   : dx[r,m,:] = w[r,m] P[r,m*d:], dw[r,m] = <x[r,m], P[r,m]> - gsub[r,m]. */
 int mmt_ls_fold_bf16(const float* x, const float* w, int R, int Rpad, int M, int d, void* out16, void* stream);
 int mmt_ls_finish(float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, void* stream);
+int mmt_ls_col_blocks(int n);
+int mmt_ls_diag(const float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, int r0, float* diag_local,
+                void* stream);
+int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int M, int finish, int b, int n,
+                     int r0, float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part, void* stream);
 int mmt_ls_counts(const float* S, int64_t ld, const float* diag, int b, int n, int r0, float margin, int32_t* rowcnt,
                   int32_t* colcnt, float* loss_part, void* stream);
 int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const int32_t* rowcnt,
                 const int32_t* colcnt_total, int b, int n, int M, int r0, float margin, float inv_norm, void* G16,
-                int64_t ldg, float* gs, void* stream);
+                int64_t ldg, float* gs_part, void* stream);
 int mmt_ls_unfold(const float* P, int64_t ldp, const float* x, const float* w, const float* gsub, int R, int M, int d,
                   float* dx, float* dw, void* stream);
 

@@ -207,6 +207,9 @@ SIGNATURES = {
     'mmt_retrieval_ranks': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_fold_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_ls_finish': (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'mmt_ls_col_blocks': (c_int, [c_int]),
+    'mmt_ls_diag': (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_ls_counts_ex': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_counts': (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_grad': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64,
                             c_vp, c_vp]),

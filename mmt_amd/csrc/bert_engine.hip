@@ -65,7 +65,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   const size_t small_nb = ((size_t)R + 3) / 4 < 512 ? ((size_t)R + 3) / 4 : 512;
   if (ln_nb < small_nb) ln_nb = small_nb;
   for (int i = 0; i < 2 * m->layers + 1; ++i) w->ln_partials[i] = (float*)take(ln_nb * 3 * d * 4);
-  const int pos_v = m->max_pos > 64 ? 0 : m->max_pos;  // larger position tables take mmt_table_grad_direct (no scratch)
+  const int pos_v = m->max_pos > 128 ? 0 : m->max_pos;  // larger position tables take mmt_table_grad_direct (no scratch)
   const int vmax = m->type_vocab > pos_v ? m->type_vocab : pos_v;
   {  // tail buffers: B*M read-out rows are at most a quarter of the token rows for T >= 3 (else: full path)
     const size_t C = (size_t)mmt_bert_tail_capacity(R);
@@ -452,9 +452,9 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   add_job(w.ln_partials[0], ln_blocks, 3, 2, d, m->g_emb_ln_g, m->g_emb_ln_b);
   if (fork_r) TRY(mmt_stream_fork(stream, side));
   const int chunks = mmt_table_grad_chunks();
-  const bool pos_partials = b->pos_ids && m->max_pos <= 64;
+  const bool pos_partials = b->pos_ids && m->max_pos <= 128;  // (one-hot MFMA products up to 4 vocabulary tiles of 32)
   // token-type table (+ the temporal-position table when it is small) as one-hot MFMA products, ONE launch for both
-  if (m->type_vocab <= 64) {
+  if (m->type_vocab <= 128) {
     TRY(mmt_table_grad_partials_pair(dfeatures, b->type_ids, m->type_vocab, w.table_scratch[0],
                                      pos_partials ? b->pos_ids : nullptr, m->max_pos, w.table_scratch[1], rows, d, nr, rstream));
   } else {  // large token-type vocabularies: the scan kernel

@@ -31,88 +31,202 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
   }
 }
 
-// in place: S[t][v] = num[t][v] / den(t, v)
-__global__ __launch_bounds__(256) void ls_finish_kernel(float* __restrict__ S, int64_t ld, const float* __restrict__ tw,
-                                                        const float* __restrict__ vw, int b, int n, int M) {
-  const int t = blockIdx.y;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= n) return;
-  float den = 0.f;
-  for (int m = 0; m < M; ++m) den += tw[(int64_t)t * M + m] * vw[(int64_t)v * M + m];
-  if (den == 0.f) den = 1e-5f;
-  S[(int64_t)t * ld + v] /= den;
+// ---- the passes over the b x n row block (r04) --------------------------------------------------------------------
+// One block = TR rows x up to LS_CPB columns; a thread owns 4 consecutive columns of every 1024-column chunk it sweeps and
+// all TR rows of them: 16-byte loads of S (a 4 KiB row segment per block and load), the column data (video weights,
+// diagonal) read ONCE per chunk into registers and reused for TR rows, the row data (text weights, s_rr) in LDS.  The r01-r03
+// kernels walked a row per block with 4-byte loads and re-read vw[c][0..M) + diag[c] for every element (0.42 TB/s on the
+// gradient pass; profiles/r03_pmc_config4.txt).  Per-row sums over the block's columns are reduced once per block and
+// written as per-column-block partials (fixed order downstream => deterministic); the integer counts use atomics.
+#define LS_CHUNK 1024
+#define LS_CPB 8192  // columns per block (8 chunks)
+static inline int ls_col_blocks(int n) { return (n + LS_CPB - 1) / LS_CPB; }
+extern "C" int mmt_ls_col_blocks(int n) { return n > 0 ? ls_col_blocks(n) : MMT_ERR_ARG; }
+
+template <int MM>
+__device__ __forceinline__ void ls_load_cols(const float* __restrict__ vw, const float* __restrict__ diag, int c0, int n, int M,
+                                             float (&vwc)[4][MM], f32x4& dg) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) vwc[j][m] = (m < M && c0 + j < n) ? vw[(int64_t)(c0 + j) * M + m] : 0.f;
+  dg = diag ? *(const f32x4*)(diag + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// pass 1: block per local row t (global row r = r0 + t)
-__global__ __launch_bounds__(256) void ls_counts_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
-                                                        int b, int n, int r0, float margin, int32_t* __restrict__ rowcnt,
-                                                        int32_t* __restrict__ colcnt, float* __restrict__ loss_part) {
-  __shared__ float redf[4];
-  __shared__ int redi[4];
-  const int t = blockIdx.x, r = r0 + t, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float srr = diag[r];
-  float acc = 0.f;
-  int cnt = 0;
-  for (int c = threadIdx.x; c < n; c += 256) {
-    if (c == r) continue;
-    const float s = S[(int64_t)t * ld + c];
-    const float h1 = margin - srr + s, h2 = margin - diag[c] + s;
-    acc += fmaxf(h1, 0.f) + fmaxf(h2, 0.f);
-    cnt += h1 > 0.f;
-    if (h2 > 0.f) atomicAdd(colcnt + c, 1);
+// raw numerators -> similarities (MODE 1, in place) and / or pass 1 (MODE 2: counts; MODE 3: both in one sweep).
+//   rowcnt[t] = #{c != r : m - s_rr + s_rc > 0},  colcnt[c] += [m - s_cc + s_rc > 0],  loss_part[t][cb] = hinge sums
+template <int TR, int MM, int MODE>
+__global__ __launch_bounds__(256) void ls_sweep_kernel(float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
+                                                       const float* __restrict__ tw, const float* __restrict__ vw, int b, int n,
+                                                       int M, int r0, float margin, int32_t* __restrict__ rowcnt,
+                                                       int32_t* __restrict__ colcnt, float* __restrict__ loss_part) {
+  constexpr bool FIN = MODE & 1, CNT = MODE & 2;
+  __shared__ float tws[TR][MM];
+  __shared__ float srr_s[TR];
+  __shared__ float redf[4][TR];
+  __shared__ int redi[4][TR];
+  const int cb = blockIdx.x, ncb = gridDim.x, t0 = blockIdx.y * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if constexpr (FIN) {
+    for (int e = tid; e < TR * MM; e += 256) {
+      const int r = e / MM, m = e % MM;
+      tws[r][m] = (t0 + r < b && m < M) ? tw[(int64_t)(t0 + r) * M + m] : 0.f;
+    }
   }
-  acc = wave_sum(acc);
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if (lane == 0) { redf[wave] = acc; redi[wave] = cnt; }
+  if (CNT && tid < TR) srr_s[tid] = t0 + tid < b ? diag[r0 + t0 + tid] : 0.f;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    loss_part[t] = redf[0] + redf[1] + redf[2] + redf[3];
-    rowcnt[t] = redi[0] + redi[1] + redi[2] + redi[3];
+  float acc[TR];
+  int cnt[TR];
+#pragma unroll
+  for (int r = 0; r < TR; ++r) { acc[r] = 0.f; cnt[r] = 0; }
+  const int c_end = min(n, (cb + 1) * LS_CPB);
+  for (int c0 = cb * LS_CPB + tid * 4; c0 < c_end; c0 += LS_CHUNK) {
+    float vwc[4][MM];
+    f32x4 dg;
+    ls_load_cols<MM>(FIN ? vw : nullptr, CNT ? diag : nullptr, c0, FIN ? n : 0, M, vwc, dg);
+    f32x4 sv[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+      sv[r] = t0 + r < b ? *(const f32x4*)(S + (int64_t)(t0 + r) * ld + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      if (t0 + r >= b) continue;  // (block-uniform)
+      f32x4 s = sv[r];
+      if constexpr (FIN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float den = 0.f;
+#pragma unroll
+          for (int m = 0; m < MM; ++m) den += tws[r][m] * vwc[j][m];
+          if (den == 0.f) den = 1e-5f;
+          s[j] /= den;
+        }
+        *(f32x4*)(S + (int64_t)(t0 + r) * ld + c0) = s;
+      }
+      if constexpr (CNT) {
+        const int rg = r0 + t0 + r;
+        const float srr = srr_s[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c0 + j == rg) continue;
+          const float h1 = margin - srr + s[j], h2 = margin - dg[j] + s[j];
+          acc[r] += fmaxf(h1, 0.f) + fmaxf(h2, 0.f);
+          cnt[r] += h1 > 0.f;
+          cc[j] += h2 > 0.f;
+        }
+      }
+    }
+    if constexpr (CNT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (cc[j]) atomicAdd(colcnt + c0 + j, cc[j]);
+    }
   }
+  if constexpr (CNT) {
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      const float a = wave_sum(acc[r]);
+      int c = cnt[r];
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if (lane == 0) { redf[wave][r] = a; redi[wave][r] = c; }
+    }
+    __syncthreads();
+    if (tid < TR && t0 + tid < b) {
+      loss_part[(int64_t)(t0 + tid) * ncb + cb] = (redf[0][tid] + redf[1][tid]) + (redf[2][tid] + redf[3][tid]);
+      atomicAdd(rowcnt + t0 + tid, redi[0][tid] + redi[1][tid] + redi[2][tid] + redi[3][tid]);
+    }
+  }
+}
+
+// diag_local[t] = S[t][r0 + t] / den(t, r0 + t) from the RAW numerators (before mmt_ls_counts_ex(finish = 1) divides them)
+__global__ __launch_bounds__(256) void ls_diag_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ tw,
+                                                      const float* __restrict__ vw, int b, int M, int r0,
+                                                      float* __restrict__ diag_local) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= b) return;
+  float den = 0.f;
+  for (int m = 0; m < M; ++m) den += tw[(int64_t)t * M + m] * vw[(int64_t)(r0 + t) * M + m];
+  if (den == 0.f) den = 1e-5f;
+  diag_local[t] = S[(int64_t)t * ld + r0 + t] / den;
 }
 
 // pass 2: G'[t][v] (bf16) = g(t, v) / den(t, v) with g = ((h1 > 0) + (h2 > 0)) / norm off the diagonal and
-// -(rowcnt[t] + colcnt[r]) / norm on it; gs[t][m] = sum_v G'[t][v] S[t][v] vw[v][m]
-__global__ __launch_bounds__(256) void ls_grad_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
-                                                      const float* __restrict__ tw, const float* __restrict__ vw,
-                                                      const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ colcnt,
-                                                      int b, int n, int M, int r0, float margin, float inv_norm,
-                                                      bf16_t* __restrict__ G16, int64_t ldg, float* __restrict__ gs) {
-  __shared__ float red[4][LS_MAXM];
-  const int t = blockIdx.x, r = r0 + t, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float srr = diag[r];
-  float twr[LS_MAXM], acc[LS_MAXM];
-#pragma unroll
-  for (int m = 0; m < LS_MAXM; ++m) { twr[m] = m < M ? tw[(int64_t)t * M + m] : 0.f; acc[m] = 0.f; }
-  for (int c = threadIdx.x; c < n; c += 256) {
-    const float s = S[(int64_t)t * ld + c];
-    float g;
-    if (c == r) g = -(float)(rowcnt[t] + colcnt[r]) * inv_norm;
-    else g = ((margin - srr + s > 0.f ? 1.f : 0.f) + (margin - diag[c] + s > 0.f ? 1.f : 0.f)) * inv_norm;
-    float den = 0.f;
-#pragma unroll
-    for (int m = 0; m < LS_MAXM; ++m)
-      if (m < M) den += twr[m] * vw[(int64_t)c * M + m];
-    const bool zero = den == 0.f;
-    if (zero) den = 1e-5f;
-    const float gp = g / den;
-    G16[(int64_t)t * ldg + c] = f2bf(gp);
-    if (!zero) {  // the 1e-5 branch carries no normaliser gradient (model.py:816)
-      const float gps = bf2f(f2bf(gp)) * s;
-#pragma unroll
-      for (int m = 0; m < LS_MAXM; ++m)
-        if (m < M) acc[m] += gps * vw[(int64_t)c * M + m];
-    }
+// -(rowcnt[t] + colcnt[r]) / norm on it; gs_part[t][cb][m] = sum over the block's columns of G'[t][v] S[t][v] vw[v][m]
+template <int TR, int MM>
+__global__ __launch_bounds__(256) void ls_grad2_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
+                                                       const float* __restrict__ tw, const float* __restrict__ vw,
+                                                       const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ colcnt,
+                                                       int b, int n, int M, int r0, float margin, float inv_norm,
+                                                       bf16_t* __restrict__ G16, int64_t ldg, float* __restrict__ gs_part) {
+  __shared__ float tws[TR][MM];
+  __shared__ float srr_s[TR], gdiag_s[TR];
+  __shared__ float red[4][TR][MM];
+  const int cb = blockIdx.x, ncb = gridDim.x, t0 = blockIdx.y * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < TR * MM; e += 256) {
+    const int r = e / MM, m = e % MM;
+    tws[r][m] = (t0 + r < b && m < M) ? tw[(int64_t)(t0 + r) * M + m] : 0.f;
   }
-#pragma unroll
-  for (int m = 0; m < LS_MAXM; ++m) {
-    if (m < M) {
-      const float v = wave_sum(acc[m]);
-      if (lane == 0) red[wave][m] = v;
-    }
+  if (tid < TR && t0 + tid < b) {
+    srr_s[tid] = diag[r0 + t0 + tid];
+    gdiag_s[tid] = -(float)(rowcnt[t0 + tid] + colcnt[r0 + t0 + tid]) * inv_norm;
   }
   __syncthreads();
-  if (threadIdx.x < M) gs[(int64_t)t * M + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  float acc[TR][MM];
+#pragma unroll
+  for (int r = 0; r < TR; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const int c_end = min(n, (cb + 1) * LS_CPB);
+  for (int c0 = cb * LS_CPB + tid * 4; c0 < c_end; c0 += LS_CHUNK) {
+    float vwc[4][MM];
+    f32x4 dg;
+    ls_load_cols<MM>(vw, diag, c0, n, M, vwc, dg);
+    f32x4 sv[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+      sv[r] = t0 + r < b ? *(const f32x4*)(S + (int64_t)(t0 + r) * ld + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      if (t0 + r >= b) continue;  // (block-uniform)
+      const int rg = r0 + t0 + r;
+      const float srr = srr_s[r];
+      u32x2 o;
+      float gpb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = sv[r][j];
+        float g;
+        if (c0 + j == rg) g = gdiag_s[r];
+        else g = ((margin - srr + s > 0.f ? 1.f : 0.f) + (margin - dg[j] + s > 0.f ? 1.f : 0.f)) * inv_norm;
+        float den = 0.f;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) den += tws[r][m] * vwc[j][m];
+        const bool zero = den == 0.f;
+        if (zero) den = 1e-5f;
+        const bf16_t gb = f2bf(g / den);
+        gpb[j] = zero ? 0.f : bf2f(gb) * s;  // the 1e-5 branch carries no normaliser gradient (model.py:816)
+        if (j & 1) o[j >> 1] |= (unsigned)gb << 16; else o[j >> 1] = gb;
+      }
+      *(u32x2*)(G16 + (int64_t)(t0 + r) * ldg + c0) = o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] += gpb[j] * vwc[j][m];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TR; ++r)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const float v = wave_sum(acc[r][m]);
+      if (lane == 0) red[wave][r][m] = v;
+    }
+  __syncthreads();
+  for (int e = tid; e < TR * MM; e += 256) {
+    const int r = e / MM, m = e % MM;
+    if (t0 + r < b && m < M)
+      gs_part[((int64_t)(t0 + r) * ncb + cb) * M + m] = (red[0][r][m] + red[1][r][m]) + (red[2][r][m] + red[3][r][m]);
+  }
 }
 
 // dX[r][m][:] = w[r][m] * P[r][m*d + :]; dw[r][m] = <X[r][m], P[r][m]> - gsub[r][m]   (one wave per (r, m))
@@ -143,28 +257,60 @@ extern "C" int mmt_ls_fold_bf16(const float* x, const float* w, int R, int Rpad,
   return (int)hipGetLastError();
 }
 
+template <int MODE>
+static int ls_sweep(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int b, int n, int M, int r0,
+                    float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part, hipStream_t s) {
+  if ((n & 3) || (ld & 3) || ((uintptr_t)S & 15)) return MMT_ERR_ALIGN;
+  if (M <= 8)
+    hipLaunchKernelGGL((ls_sweep_kernel<16, 8, MODE>), dim3(ls_col_blocks(n), (b + 15) / 16), dim3(256), 0, s, S, ld, diag, tw, vw, b, n,
+                       M, r0, margin, rowcnt, colcnt, loss_part);
+  else
+    hipLaunchKernelGGL((ls_sweep_kernel<8, 16, MODE>), dim3(ls_col_blocks(n), (b + 7) / 8), dim3(256), 0, s, S, ld, diag, tw, vw, b, n,
+                       M, r0, margin, rowcnt, colcnt, loss_part);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mmt_ls_finish(float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, void* stream) {
   if (!S || !tw || !vw || b <= 0 || n <= 0 || M <= 0 || M > LS_MAXM) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(ls_finish_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, S, ld, tw, vw, b, n, M);
+  return ls_sweep<1>(S, ld, nullptr, tw, vw, b, n, M, 0, 0.f, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mmt_ls_diag(const float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, int r0,
+                           float* diag_local, void* stream) {
+  if (!S || !tw || !vw || !diag_local || b <= 0 || M <= 0 || M > LS_MAXM || r0 < 0 || r0 + b > n) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(ls_diag_kernel, dim3((b + 255) / 256), dim3(256), 0, (hipStream_t)stream, S, ld, tw, vw, b, M, r0, diag_local);
   return (int)hipGetLastError();
 }
 
-// colcnt must be zero on entry (it accumulates); loss_part [b] holds the UN-normalised hinge sums of the local rows
+// rowcnt and colcnt must be zero on entry (they accumulate); loss_part [b, mmt_ls_col_blocks(n)] holds the UN-normalised
+// hinge sums of the local rows per column block.  finish = 1: S holds the raw numerators of the similarity GEMM on entry
+// and the similarities on return (tw / vw / M needed) -- the division and pass 1 in ONE sweep over the block.
+extern "C" int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int M, int finish,
+                                int b, int n, int r0, float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part,
+                                void* stream) {
+  if (!S || !diag || !rowcnt || !colcnt || !loss_part || b <= 0 || n <= 1 || r0 < 0 || r0 + b > n) return MMT_ERR_ARG;
+  if (finish && (!tw || !vw || M <= 0 || M > LS_MAXM)) return MMT_ERR_ARG;
+  if (finish) return ls_sweep<3>(S, ld, diag, tw, vw, b, n, M, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
+  return ls_sweep<2>(S, ld, diag, nullptr, nullptr, b, n, 0, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
+}
 extern "C" int mmt_ls_counts(const float* S, int64_t ld, const float* diag, int b, int n, int r0, float margin,
                              int32_t* rowcnt, int32_t* colcnt, float* loss_part, void* stream) {
-  if (!S || !diag || !rowcnt || !colcnt || !loss_part || b <= 0 || n <= 1 || r0 < 0 || r0 + b > n) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(ls_counts_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, S, ld, diag, b, n, r0, margin, rowcnt,
-                     colcnt, loss_part);
-  return (int)hipGetLastError();
+  return mmt_ls_counts_ex((float*)S, ld, diag, nullptr, nullptr, 0, 0, b, n, r0, margin, rowcnt, colcnt, loss_part, stream);
 }
 
+// gs_part: [b, mmt_ls_col_blocks(n), M] partial sums (the caller adds the column blocks up, in order)
 extern "C" int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw,
                            const int32_t* rowcnt, const int32_t* colcnt_total, int b, int n, int M, int r0, float margin,
-                           float inv_norm, void* G16, int64_t ldg, float* gs, void* stream) {
-  if (!S || !diag || !tw || !vw || !rowcnt || !colcnt_total || !G16 || !gs || b <= 0 || n <= 1 || M <= 0 || M > LS_MAXM)
+                           float inv_norm, void* G16, int64_t ldg, float* gs_part, void* stream) {
+  if (!S || !diag || !tw || !vw || !rowcnt || !colcnt_total || !G16 || !gs_part || b <= 0 || n <= 1 || M <= 0 || M > LS_MAXM)
     return MMT_ERR_ARG;
-  hipLaunchKernelGGL(ls_grad_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, S, ld, diag, tw, vw, rowcnt, colcnt_total,
-                     b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs);
+  if ((n & 3) || (ld & 3) || (ldg & 3) || ((uintptr_t)S & 15) || ((uintptr_t)G16 & 7)) return MMT_ERR_ALIGN;
+  if (M <= 8)
+    hipLaunchKernelGGL((ls_grad2_kernel<16, 8>), dim3(ls_col_blocks(n), (b + 15) / 16), dim3(256), 0, (hipStream_t)stream, S, ld, diag, tw,
+                       vw, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs_part);
+  else
+    hipLaunchKernelGGL((ls_grad2_kernel<8, 16>), dim3(ls_col_blocks(n), (b + 7) / 8), dim3(256), 0, (hipStream_t)stream, S, ld, diag, tw,
+                       vw, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs_part);
   return (int)hipGetLastError();
 }
 

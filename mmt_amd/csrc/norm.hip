@@ -413,6 +413,9 @@ __global__ __launch_bounds__(256) void table_grad_kernel(
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct TablePair { const int32_t* ids[2]; float* partial[2]; int vocab[2]; };
 #define TG_ROWS 64  // rows per burst: [64][128] fp32 = 32 KiB of LDS, one memory round trip
+// NU = vocabulary tiles of 32 per table: 2 (tables of <= 64 rows: MSRVTT's 32 temporal positions, 19 token types) or 4
+// (<= 128: ActivityNet's 102 positions -- r03 sent those to the row-scanning kernel below, 666 us per step at S = 708).
+template <int NU>
 __global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __restrict__ g, TablePair tp, int rows, int d,
                                                               const int32_t* __restrict__ n_rows_dev) {
   __shared__ __attribute__((aligned(16))) float gt[TG_ROWS][128 + 4];
@@ -423,11 +426,11 @@ __global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __res
   const int per = (nrows + TABLE_CHUNKS - 1) / TABLE_CHUNKS;
   const int r_begin = chunk * per, r_end = min(nrows, r_begin + per);
   const int ntab = tp.ids[1] ? 2 : 1;
-  f32x16_t acc[2][2];  // [table][vocabulary tile of 32]: vocab <= 64
+  f32x16_t acc[2][NU];  // [table][vocabulary tile of 32]
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
   for (int r0 = r_begin; r0 < r_end; r0 += TG_ROWS) {
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __res
     for (int t = 0; t < 2; ++t) {
       if (t >= ntab) continue;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         if (u * 32 >= tp.vocab[t]) continue;
         const int myv = u * 32 + l31;
 #pragma unroll 8
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void table_grad_mfma_kernel(const float* __res
   for (int t = 0; t < 2; ++t) {
     if (t >= ntab) continue;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {  // lane holds column cb + 32 wave + l31, vocabulary rows (r & 3) + 8 (r >> 2) + 4 h
         const int v = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -715,11 +718,15 @@ extern "C" int mmt_table_grad_chunks(void) { return TABLE_CHUNKS; }
 extern "C" int mmt_table_grad_partials_pair(const float* g, const int32_t* ids0, int vocab0, float* scratch0,
                                             const int32_t* ids1, int vocab1, float* scratch1, int rows, int d,
                                             const int32_t* n_rows_dev, void* stream) {
-  if (!g || !ids0 || !scratch0 || rows <= 0 || vocab0 <= 0 || vocab0 > 64 || d % 128) return MMT_ERR_ARG;
-  if (ids1 && (!scratch1 || vocab1 <= 0 || vocab1 > 64)) return MMT_ERR_ARG;
+  if (!g || !ids0 || !scratch0 || rows <= 0 || vocab0 <= 0 || vocab0 > 128 || d % 128) return MMT_ERR_ARG;
+  if (ids1 && (!scratch1 || vocab1 <= 0 || vocab1 > 128)) return MMT_ERR_ARG;
   TablePair tp = {{ids0, ids1}, {scratch0, scratch1}, {vocab0, vocab1}};
-  hipLaunchKernelGGL(table_grad_mfma_kernel, dim3(d / 128, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, tp,
-                     rows, d, n_rows_dev);
+  if (vocab0 <= 64 && (!ids1 || vocab1 <= 64))
+    hipLaunchKernelGGL(table_grad_mfma_kernel<2>, dim3(d / 128, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, tp, rows, d,
+                       n_rows_dev);
+  else
+    hipLaunchKernelGGL(table_grad_mfma_kernel<4>, dim3(d / 128, TABLE_CHUNKS), dim3(256), 0, (hipStream_t)stream, g, tp, rows, d,
+                       n_rows_dev);
   return (int)hipGetLastError();
 }
 

@@ -50,19 +50,24 @@ class RowBlock:
           'mmt_ls_fold_bf16')
     self.S = torch.empty(bp, n, device=self.dev, dtype=torch.float32)
     ops.gemm_nt(self.t16, self.v16, self.S, 'F32', m=b)
-    check(L.mmt_ls_finish(ops._p(self.S), n, ops._p(self.tw), ops._p(self.vw_all), b, n, m, ops._stream()), 'mmt_ls_finish')
-    self.diag_local = self.S[:b].diagonal(self.r0).contiguous()  # s_rr of the local rows (a b-element gather)
+    # S holds the raw numerators until phase_counts divides them in its own sweep; the diagonal needs b divisions now
+    self.diag_local = torch.empty(b, device=self.dev, dtype=torch.float32)
+    check(L.mmt_ls_diag(ops._p(self.S), n, ops._p(self.tw), ops._p(self.vw_all), b, n, m, self.r0, ops._p(self.diag_local),
+                        ops._stream()), 'mmt_ls_diag')
     return self.diag_local
 
   # ---- phase B: hinge counts (needs the global diagonal) -------------------------------------------
   def phase_counts(self, diag_all):
     L, b, n = self.L, self.b, self.n
     self.diag_all = _f32(diag_all)
-    self.rowcnt = torch.empty(b, device=self.dev, dtype=torch.int32)
+    self.rowcnt = torch.zeros(b, device=self.dev, dtype=torch.int32)
     self.colcnt = torch.zeros(n, device=self.dev, dtype=torch.int32)
-    self.loss_part = torch.empty(b, device=self.dev, dtype=torch.float32)
-    check(L.mmt_ls_counts(ops._p(self.S), n, ops._p(self.diag_all), b, n, self.r0, self.margin, ops._p(self.rowcnt),
-                          ops._p(self.colcnt), ops._p(self.loss_part), ops._stream()), 'mmt_ls_counts')
+    part = torch.empty(b, L.mmt_ls_col_blocks(n), device=self.dev, dtype=torch.float32)
+    # numerators -> similarities and pass 1 (hinge sums and counts) in ONE sweep over the row block
+    check(L.mmt_ls_counts_ex(ops._p(self.S), n, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), self.m, 1, b, n,
+                             self.r0, self.margin, ops._p(self.rowcnt), ops._p(self.colcnt), ops._p(part), ops._stream()),
+          'mmt_ls_counts_ex')
+    self.loss_part = part.sum(1)  # per row, column blocks in order
     return self.colcnt, self.loss_part.sum() / self.norm
 
   # ---- phase C: gradients of the local texts, contribution to every video ----------------------------
@@ -71,10 +76,11 @@ class RowBlock:
     md, bp = m * d, self.t16.shape[0]
     colcnt_total = colcnt_total.to(device=self.dev, dtype=torch.int32).contiguous()
     g16 = torch.zeros(bp, n, device=self.dev, dtype=torch.bfloat16)
-    gs = torch.empty(b, m, device=self.dev, dtype=torch.float32)
+    gs_part = torch.empty(b, L.mmt_ls_col_blocks(n), m, device=self.dev, dtype=torch.float32)
     check(L.mmt_ls_grad(ops._p(self.S), n, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), ops._p(self.rowcnt),
-                        ops._p(colcnt_total), b, n, m, self.r0, self.margin, 1.0 / self.norm, ops._p(g16), n, ops._p(gs),
+                        ops._p(colcnt_total), b, n, m, self.r0, self.margin, 1.0 / self.norm, ops._p(g16), n, ops._p(gs_part),
                         ops._stream()), 'mmt_ls_grad')
+    gs = gs_part.sum(1)
     v16t = self.v16.t().contiguous()                       # [M*d, n]: B operand of P = G' V'
     p = torch.empty(bp, md, device=self.dev, dtype=torch.float32)
     ops.gemm_nt(g16, v16t, p, 'F32', m=b)

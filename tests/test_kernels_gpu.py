@@ -506,7 +506,7 @@ def test_standalone_dropout_keep_rate_and_backward_mask():
 
 
 @pytest.mark.parametrize('rows,d,v0,v1,live', [(3583, 512, 19, 32, None), (700, 256, 19, 32, 333), (900, 1024, 40, 64, 801),
-                                                (257, 512, 19, 0, None)])
+                                                (257, 512, 19, 0, None), (2300, 512, 19, 102, 2101), (500, 256, 128, 65, None)])
 def test_table_grad_pair_on_matrix_cores(rows, d, v0, v1, live):
   """Embedding-table gradients (token types + temporal positions, model/bert.py:87-105 backward) as one-hot products on the
   fp32 MFMA, both tables in one launch: against index_add_ in fp64."""
