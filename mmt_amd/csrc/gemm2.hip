@@ -14,35 +14,9 @@
 //     8-16 B/lane access instead of a 32-byte-per-row scatter.
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
+#include "gemm_epi.h"
 
 #define BK 64
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// erf-form GELU (model/bert.py:37-53) via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the
-// bf16 rounding of the stored activations).  One exp serves Phi(x) and phi(x).
-__device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-  const float e = __expf(-0.5f * x * x);
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(t, p, 1.421413741f);
-  p = fmaf(t, p, -0.284496736f);
-  p = fmaf(t, p, 0.254829592f);
-  const float half_erfc = 0.5f * t * p * e;  // 0.5 * erfc(|x|/sqrt2)
-  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
-  pdf = 0.39894228040143268f * e;
-}
-__device__ __forceinline__ float gelu2(float x) {
-  float c, p;
-  gelu_cdf_pdf(x, c, p);
-  return x * c;
-}
-__device__ __forceinline__ float gelu2_grad(float x) {
-  float c, p;
-  gelu_cdf_pdf(x, c, p);
-  return fmaf(x, p, c);
-}
-
 template <int ROWS, int NW>
 __device__ __forceinline__ void stage2(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
                                        bf16_t* lds_tile, int wave, int lane) {
@@ -113,15 +87,6 @@ __device__ __forceinline__ void gemm2_body(
   constexpr int GW = WGM * WGN;  // waves that tile the output once
   constexpr int NW = PH ? 2 * GW : GW, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
   static_assert(!PH || NS == 4, "the phased loop runs on a four-deep ring");
-  constexpr int P = BN + 4;        // fp32 pitch of the epilogue image
-  // the epilogue sweeps the image in column blocks of CB columns: the whole width when the thread count divides into
-  // whole rows of it, 64-column blocks otherwise (BN = 192: 3 blocks of 16 lanes x 16 B per row)
-  constexpr int CB = (NT * 4) % BN == 0 ? BN : 64;
-  constexpr int NCB = BN / CB;     // column blocks
-  constexpr int CG = CB / 4;       // 4-column groups per row of a column block
-  constexpr int RG = NT / CG;      // rows covered per sweep of the block
-  constexpr int CH = BM < 64 ? BM : 64;  // rows per epilogue chunk
-  static_assert(BN % CB == 0 && NT % CG == 0 && CH % RG == 0, "epilogue geometry");
   // 8-wave blocks run as two groups in opposite phase (waves w and w+4 share a SIMD): group 0 issues the next
   // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
   // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
@@ -355,199 +320,14 @@ __device__ __forceinline__ void gemm2_body(
   const long long t_loop_end = clock64();
 #endif
 
-  // ---- epilogue: 64 rows at a time through a row-major fp32 LDS image -------------------------------
-  float* st = (float*)smem_raw;
-  float* red = st + CH * P;  // [RG][BN] column-sum scratch (DGELU)
-  const int cg = tid % CG, rg = tid / CG;
-  f32x4 bias4[NCB];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) {
-    bias4[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_BIAS_DROP_RES ||
-                  EPI == MMT_EPI_BIAS_F32)
-      bias4[cb] = *(const f32x4*)(epi.bias + n0 + cb * CB + cg * 4);
-  }
-  unsigned dkey = 0;
-  if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
-  float csum[NCB][4];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) csum[cb][0] = csum[cb][1] = csum[cb][2] = csum[cb][3] = 0.f;
-  // Second operands of the epilogue (residual rows, GELU pre-activations, original row numbers of the dropout key) for
-  // the WHOLE tile go out now, all at once: fetched inside the sweep, each sits behind the previous row's store -- a
-  // chain of (BM / RG) global round trips per thread at the end of every tile.
-  // Element offsets of this thread's first swept row (m0 + rg, column n0 + 4 cg) in every matrix the epilogue touches: row
-  // m0 + rg + dr is that + dr * ld with dr a compile-time constant of the unrolled sweep -- a scalar multiply and one 64-bit
-  // add instead of a 64-bit row x ld product per access (two quarter-rate v_mul_lo_u32 + v_mad_u64_u32: a fifth of the
-  // sweep's instruction slots, tools/gemm2_budget.py r04).
-  const int64_t rb = m0 + rg, cb0 = n0 + cg * 4;
-  const int64_t off_c = rb * ldc + cb0, off_res = rb * epi.ldres + cb0, off_aux = rb * epi.ldaux + cb0,
-                off_o2 = rb * epi.ldout2 + cb0, off_dot = rb * epi.lddot + cb0;
-  constexpr int SW = CH / RG, NPF = (BM / CH) * SW * NCB;
-  constexpr bool PF_FITS = NPF <= 8;  // (the 256-row lab tiles would spend > 64 registers on it: they keep the in-sweep loads)
-  constexpr bool PF_RES = PF_FITS && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32);
-  constexpr bool PF_AUX = PF_FITS && (EPI == MMT_EPI_DGELU || EPI == MMT_EPI_BF16);  // (BF16: dot_src, when dot_out is set)
-  f32x4 pf_res[PF_RES ? NPF : 1];
-  u32x2 pf_aux[PF_AUX ? NPF : 1];
-  int pf_orow[PF_RES && EPI == MMT_EPI_BIAS_DROP_RES ? (BM / CH) * SW : 1];
-  if constexpr (PF_RES || PF_AUX) {
-#pragma unroll
-    for (int ch = 0; ch < BM / CH; ++ch)
-#pragma unroll
-      for (int sw = 0; sw < SW; ++sw) {
-        const int dr = ch * CH + sw * RG;
-        const bool in = m0 + dr + rg < M;  // rows past the matrix read its last row (never used)
-        const int row = in ? m0 + dr + rg : M - 1;
-        if constexpr (PF_RES && EPI == MMT_EPI_BIAS_DROP_RES)
-          pf_orow[ch * SW + sw] = (epi.drop_thr16 && epi.row_index) ? epi.row_index[row] : row;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          if constexpr (PF_RES) {
-            const int64_t o = in ? off_res + (int64_t)dr * epi.ldres + cb * CB : (int64_t)(M - 1) * epi.ldres + cb0 + cb * CB;
-            pf_res[(ch * SW + sw) * NCB + cb] = *(const f32x4*)(epi.res + o);
-          }
-          if constexpr (PF_AUX && EPI == MMT_EPI_DGELU) {
-            const int64_t o = in ? off_aux + (int64_t)dr * epi.ldaux + cb * CB : (int64_t)(M - 1) * epi.ldaux + cb0 + cb * CB;
-            pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + o);
-          }
-          if constexpr (PF_AUX && EPI == MMT_EPI_BF16) {
-            if (epi.dot_out) {
-              const int64_t o = in ? off_dot + (int64_t)dr * epi.lddot + cb * CB : (int64_t)(M - 1) * epi.lddot + cb0 + cb * CB;
-              pf_aux[(ch * SW + sw) * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.dot_src + o);
-            }
-          }
-        }
-      }
-  }
-  __syncthreads();  // every wave is done with the stage buffers
+  // ---- epilogue: 64 rows at a time through a row-major fp32 LDS image (gemm_epi.h) -----------------------------
 #ifdef MMT_GEMM2_INSTR
-  long long e_head = clock64() - t_loop_end, e_stage = 0, e_sweep = 0;
-  tp = clock64();
+  long long eticks[3] = {0, 0, 0};
+  gemm_tile_epilogue<BM, BN, WGM, WGN, NT, EPI, PH>(acc, smem_raw, m0, n0, M, N, nrows, Cout, ldc, epi, wm, wn, kg, tid, eticks);
+  const long long e_head = eticks[2] - t_loop_end, e_stage = eticks[0], e_sweep = eticks[1];
+#else
+  gemm_tile_epilogue<BM, BN, WGM, WGN, NT, EPI, PH>(acc, smem_raw, m0, n0, M, N, nrows, Cout, ldc, epi, wm, wn, kg, tid, nullptr);
 #endif
-#pragma unroll
-  for (int ch = 0; ch < BM / CH; ++ch) {
-    if ((wm * WTM) / CH == ch && kg == 0) {  // this wave's rows belong to chunk ch
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *(f32x4*)(st + ((wm * WTM) % CH + i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh) = v;
-          }
-    }
-    if constexpr (PH) {  // the other group's partial tile (odd K-steps) is added into the image: even + odd, fixed order
-      __syncthreads();
-      if ((wm * WTM) / CH == ch && kg == 1) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float* dst = st + ((wm * WTM) % CH + i * 32 + l31) * P + wn * WTN + j * 32 + 8 * q + 4 * lh;
-              f32x4 v = *(const f32x4*)dst;
-              v += (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              *(f32x4*)dst = v;
-            }
-      }
-    }
-    __syncthreads();
-    TICK(e_stage);
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      const int lcol = cb * CB + cg * 4;  // column inside the tile
-      const int col = n0 + lcol;
-#pragma unroll
-      for (int r0 = 0; r0 < CH; r0 += RG) {
-        const int r = r0 + rg;
-        const int row = m0 + ch * CH + r;
-        const int dr = ch * CH + r0;  // (compile-time after unrolling)
-        const int64_t o_c = off_c + (int64_t)dr * ldc + cb * CB;
-        if (row < M) {
-          f32x4 v = *(const f32x4*)(st + r * P + lcol);
-          v += bias4[cb];
-          if constexpr (EPI == MMT_EPI_BF16 || EPI == MMT_EPI_BIAS_BF16) {
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + o_c) = o;
-            if constexpr (EPI == MMT_EPI_BF16) {
-              if (epi.dot_out) {  // sums of out * dot_src over each 64-column group of the row: 16 neighbouring lanes x 4 columns
-                static_assert(CG % 16 == 0, "a 64-column group is 16 lanes of one row");
-                u32x2 c;
-                if constexpr (PF_AUX) c = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
-                else c = *(const u32x2*)((const bf16_t*)epi.dot_src + off_dot + (int64_t)dr * epi.lddot + cb * CB);
-                float part = bf2f((bf16_t)(o[0] & 0xffff)) * bf2f((bf16_t)(c[0] & 0xffff)) + bf2f((bf16_t)(o[0] >> 16)) * bf2f((bf16_t)(c[0] >> 16)) +
-                             bf2f((bf16_t)(o[1] & 0xffff)) * bf2f((bf16_t)(c[1] & 0xffff)) + bf2f((bf16_t)(o[1] >> 16)) * bf2f((bf16_t)(c[1] >> 16));
-                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
-                if ((cg & 15) == 0) epi.dot_out[(int64_t)row * (N >> 6) + (col >> 6)] = part;
-              }
-            }
-          } else if constexpr (EPI == MMT_EPI_BIAS_GELU) {
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + o_c) = o;
-            // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
-            const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
-            const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
-            u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
-            *(u32x2*)((bf16_t*)epi.out2 + off_o2 + (int64_t)dr * epi.ldout2 + cb * CB) = g;
-          } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
-            if (epi.drop_thr16) {
-              int orow;
-              if constexpr (PF_RES) orow = pf_orow[ch * SW + r0 / RG];
-              else orow = epi.row_index ? epi.row_index[row] : row;
-              bool k[4];
-              keep4(dkey, (unsigned long long)orow * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
-            }
-            if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
-            else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
-            *(f32x4*)((float*)Cout + o_c) = v;
-          } else if constexpr (EPI == MMT_EPI_DGELU) {
-            u32x2 a;
-            if constexpr (PF_AUX) a = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
-            else a = *(const u32x2*)((const bf16_t*)epi.aux + off_aux + (int64_t)dr * epi.ldaux + cb * CB);
-            v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
-            v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
-            v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
-            v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16_t*)Cout + o_c) = o;
-            if (row < nrows) {
-              csum[cb][0] += bf2f((bf16_t)(o[0] & 0xffff)); csum[cb][1] += bf2f((bf16_t)(o[0] >> 16));
-              csum[cb][2] += bf2f((bf16_t)(o[1] & 0xffff)); csum[cb][3] += bf2f((bf16_t)(o[1] >> 16));
-            }
-          } else if constexpr (EPI == MMT_EPI_ADD_F32) {
-            if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
-            else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
-            *(f32x4*)((float*)Cout + o_c) = v;
-          } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
-            *(f32x4*)((float*)Cout + o_c) = v;
-          }
-        }
-      }
-    }
-    if constexpr (EPI == MMT_EPI_DGELU) {
-      if (epi.colsum && BM >= 128 && (ch & 1)) {  // one partial row of column sums per 128 output rows
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          *(f32x4*)(red + rg * BN + cb * CB + cg * 4) = (f32x4){csum[cb][0], csum[cb][1], csum[cb][2], csum[cb][3]};
-          csum[cb][0] = csum[cb][1] = csum[cb][2] = csum[cb][3] = 0.f;
-        }
-        __syncthreads();
-        const int half_row = m0 / 128 + (ch >> 1);
-        if (tid < BN && half_row * 128 < M) {
-          float s = 0.f;
-#pragma unroll
-          for (int g = 0; g < RG; ++g) s += red[g * BN + tid];
-          epi.colsum[(int64_t)half_row * N + n0 + tid] = s;
-        }
-      }
-    }
-    __syncthreads();
-    TICK(e_sweep);
-  }
 #ifdef MMT_GEMM2_INSTR
   if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
     long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 16;
@@ -853,9 +633,14 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
   return MMT_ERR_ARG;
 }
 
-// tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved)
+int mmt_gemm3_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
+
+// tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved); 21 = the 256x256 eight-phase kernel
+// of gemm3.hip
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  if ((tile & 0xff) == 21) return mmt_gemm3_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   switch (epilogue) {
     case MMT_EPI_BF16: return pick2<MMT_EPI_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     case MMT_EPI_BIAS_BF16: return pick2<MMT_EPI_BIAS_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

@@ -1,0 +1,266 @@
+// 256 x 256 bf16 MFMA NT GEMM for LARGE problems (gfx950):  C[M,N] = A[M,K] . B[N,K]^T (+ the fused epilogues of gemm2).
+//
+// Where the problem offers at least two rounds of 256 x 256 tiles (the 8192 x 65536 x 7168 products of the 64k-pair loss,
+// configs[4]'s FFN GEMMs at batch 128), the 128-row tiles of gemm2.hip are bound by what a CU can pull out of L2 per MAC
+// (128 x 128 stalls at ~35 % of the MFMA peak).  A 256 x 256 tile moves a quarter of the bytes per MAC;
+// what it needs in return is a schedule that keeps 8 waves' worth of accumulators (the whole register file) fed without
+// ever draining the LDS-DMA queue.  Structure (cdna guide section 5, "the 256^2 8-phase template", re-derived for
+// mfma_f32_32x32x16 and this library's swizzle):
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 fragments of 32 x 32 (128 accumulator registers per lane), one
+//     block per CU; waves w and w + 4 share a SIMD and form two GROUPS (wm = 0 / 1) that run ONE BARRIER APART: while one
+//     group's SIMD slots run a segment of 8 MFMAs (256 cycles), the other group issues its fragment reads and LDS-DMA.
+//   * a K-tile (64 deep) is FOUR phases, one 64 x 32 quadrant of the wave tile each, in the order (top,left) (top,right)
+//     (bottom,right) (bottom,left): phase 1 reads the top A fragments and the left B fragments, phase 2 the right B
+//     fragments, phase 3 the bottom A fragments, phase 4 nothing (the left B fragments stay in registers).
+//   * LDS = 2 buffers x [A 256 x 64 | B 256 x 64] bf16 = 128 KiB, each buffer cut into four 16 KiB half-tiles by WHEN
+//     their rows are read: A-top (the first 64 rows of either wave row), B-left, B-right, A-bottom -- last read in phase
+//     1, 1, 2, 3.  Every phase requests ONE half-tile (2 LDS-DMA instructions per wave), always into a half-tile whose
+//     last read lies at least two phases back (the groups are a barrier apart):
+//         phase 1: B-right of K-tile t+1      phase 2: A-bottom of t+1      phase 3: A-top of t+2      phase 4: B-left of t+2
+//     so every request has FIVE phases (~2.5 k cycles) to land, four half-tiles are in flight at any time, and the DMA queue
+//     is never drained: s_waitcnt vmcnt(8) in front of the first barrier of phases 1, 2 and 4 is all the waiting there is.
+//   * fragment reads are inline asm with immediate offsets (one base register per operand and k-chunk), waited for with
+//     lgkmcnt(0) AFTER the barrier, so that the reads' latency overlaps the barrier wait.
+// Epilogue: gemm_epi.h (the LDS-staged row-major sweep shared with gemm2.hip).
+#include "mmt_common.h"
+#include "../../include/mmt_hip.h"
+#include "gemm_epi.h"
+#include <type_traits>
+
+#define G3_BUF 65536   // bytes per LDS buffer: [A 256 x 128 B | B 256 x 128 B]
+#define G3_BOFF 32768  // B tile inside a buffer
+
+#define G3_RD(dst, base, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(base))
+#define G3_TIE(x) asm volatile("" : "+v"(x))
+
+template <int N> __device__ __forceinline__ void g3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void g3_vmwait_rt(int n) {  // (wave-uniform n from {0, 2, 4, 6, 8})
+  if (n >= 8) g3_vmwait<8>();
+  else if (n == 6) g3_vmwait<6>();
+  else if (n == 4) g3_vmwait<4>();
+  else if (n == 2) g3_vmwait<2>();
+  else g3_vmwait<0>();
+}
+__device__ __forceinline__ void g3_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm3_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                    int64_t ldb, void* __restrict__ Cout, int64_t ldc, int M, int N, int K,
+                                                    MmtEpilogue epi, const int32_t* __restrict__ n_rows_dev) {
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;  // waves 0-3 / 4-7 share the SIMDs pairwise: the two groups of the schedule
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tiles_n = N / BN;
+  const int nrows = n_rows_dev ? *n_rows_dev : M;
+  const int bid = (int)blockIdx.x;
+  const int live_tiles = min((int)gridDim.x, ((min(nrows, M) + BM - 1) / BM) * tiles_n);
+  if (bid >= live_tiles) {  // dead tile (token packing): nothing to compute
+    if constexpr (EPI == MMT_EPI_DGELU) {
+      if (epi.colsum) {
+        const int dm0 = (bid / tiles_n) * BM, dn0 = (bid % tiles_n) * BN;
+        for (int h = 0; h < BM / 128; ++h)
+          if (dm0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(dm0 / 128 + h) * N + dn0 + tid] = 0.f;
+      }
+    }
+    return;
+  }
+  // XCD-aware order over the LIVE tiles (see gemm2.hip): bands of 8 tile rows, column by column inside a band
+  const int id = xcd_remap(bid, live_tiles);
+  int tm, tn;
+  {
+    constexpr int GROUP = 8;
+    const int tile_rows = live_tiles / tiles_n;
+    const int band = id / (GROUP * tiles_n), first = band * GROUP;
+    const int rows_here = min(GROUP, tile_rows - first);
+    const int within = id - band * GROUP * tiles_n;
+    tm = first + within % rows_here;
+    tn = within / rows_here;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int KT = K >> 6;
+
+  // ---- LDS-DMA sources: this wave moves row groups g = 2 wave, 2 wave + 1 (8 rows x 128 B each) of every half-tile ----
+  //   A-top    rows  8 (g & 7) + 128 (g >> 3)          A-bottom  the same + 64
+  //   B-left   rows  8 (g & 3) +  64 (g >> 2)          B-right   the same + 32
+  // LDS image lane-linear, chunk c of row r at chunk c ^ ((r >> 1) & 7): the swizzle goes onto the SOURCE address.
+  // Requests are MUBUF loads with the LDS flag (buffer_load_dwordx4 ... offen lds): a 128-bit descriptor per operand based
+  // at the tile's first row, a 32-bit per-lane byte offset fixed for the whole loop, the K-tile as the SCALAR offset -- no
+  // per-request vector arithmetic at all (global_load_lds needs a 64-bit per-lane address: two VALU ops + its register pair).
+  unsigned oat[2], oab[2], obl[2], obr[2];  // per-lane byte offsets from the tile's first row
+  unsigned lat[2], lab[2], lbl[2], lbr[2];  // LDS byte offsets inside a buffer (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int g = wave * 2 + i;
+    const int ra = 8 * (g & 7) + 128 * (g >> 3), rb = 8 * (g & 3) + 64 * (g >> 2);
+    const int sub = lane >> 3, ch = lane & 7;
+    auto off = [&](int64_t ld, int row0, int row_max, int r) {  // rows past the matrix re-read its last row
+      const int c = ch ^ ((r >> 1) & 7);
+      return (unsigned)((int64_t)(min(row0 + r, row_max) - row0) * ld * 2 + c * 16);
+    };
+    oat[i] = off(lda, m0, M - 1, ra + sub);       lat[i] = (unsigned)ra * 128;
+    oab[i] = off(lda, m0, M - 1, ra + 64 + sub);  lab[i] = (unsigned)(ra + 64) * 128;
+    obl[i] = off(ldb, n0, N - 1, rb + sub);       lbl[i] = G3_BOFF + (unsigned)rb * 128;
+    obr[i] = off(ldb, n0, N - 1, rb + 32 + sub);  lbr[i] = G3_BOFF + (unsigned)(rb + 32) * 128;
+  }
+  const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (int64_t)n0 * ldb), 0, 0x7fffffff, 0x00020000);
+  auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, auto& o, auto& l, int tile) {  // half-tile of K-tile `tile` -> buffer tile & 1
+    unsigned char* base = smem_raw + (tile & 1) * G3_BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(base + l[i]), 16, (int)o[i], tile * 128, 0, 0);
+  };
+
+  // ---- fragment addresses: row 32 i + l31 of the wave's rows, 16-byte chunk (2 kk + lh) ^ ((row >> 1) & 7) ----
+  const unsigned sw = (unsigned)((l31 >> 1) & 7);
+  const unsigned a_base = (unsigned)(uintptr_t)LDS_PTR(smem_raw) + (unsigned)((wm * 128 + l31) * 128) + ((lh ^ sw) << 4);
+  const unsigned b_base = (unsigned)(uintptr_t)LDS_PTR(smem_raw) + G3_BOFF + (unsigned)((wn * 64 + l31) * 128) + ((lh ^ sw) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: K-tile 0 complete, A-top and B-left of K-tile 1 ----
+  dma(ra_desc, oat, lat, 0); dma(rb_desc, obl, lbl, 0); dma(rb_desc, obr, lbr, 0); dma(ra_desc, oab, lab, 0);
+  if (KT > 1) { dma(ra_desc, oat, lat, 1); dma(rb_desc, obl, lbl, 1); g3_vmwait<8>(); }
+  else g3_vmwait<4>();
+  g3_barrier();              // A-top(0), B-left(0) of every wave have landed
+  if (wm == 1) g3_barrier(); // group 1 runs one barrier behind group 0 from here on
+
+  // fa: A fragments of the current row pair; fr: right B fragments; fl[2]: left B fragments of the current / next K-tile
+  // (phase 4 reads nothing for its own quadrant, so it fetches the NEXT tile's left B fragments: 8 / 4 / 8 / 4 reads per phase)
+  u32x4 fa[2][4], fl[2][4], fr[4];
+#define G3_MFMA(I, J, BF, AF) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF), __builtin_bit_cast(bf16x8_t, AF), acc[I][J], 0, 0, 0)
+#ifdef MMT_GEMM2_INSTR
+  long long g3t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, g3p = clock64();
+  const long long g3t0 = g3p;
+  int g3ph = 0;
+#define G3_TICK(k) do { const long long n_ = clock64(); g3t[g3ph * 4 + (k)] += n_ - g3p; g3p = n_; } while (0)
+#else
+#define G3_TICK(k) do {} while (0)
+#endif
+#define G3_SEG_BEGIN() do { G3_TICK(0); g3_barrier(); G3_TICK(1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_setprio(1); } while (0)
+#define G3_SEG_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); G3_TICK(2); g3_barrier(); G3_TICK(3); } while (0)
+  {  // left B fragments of K-tile 0 (landed: the prologue's wait)
+    const unsigned xb0 = b_base;
+    G3_RD(fl[0][0], xb0, 0); G3_RD(fl[0][1], xb0 ^ 32u, 0); G3_RD(fl[0][2], xb0 ^ 64u, 0); G3_RD(fl[0][3], xb0 ^ 96u, 0);
+  }
+  // One K-tile; CUR = which fl set holds this tile's left B fragments (the loop body is instantiated for both parities so
+  // that the register sets are compile-time).
+  auto ktile = [&](int t, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
+    const unsigned bo = (unsigned)(t & 1) * G3_BUF, bn = G3_BUF - bo;
+    const unsigned xa0 = a_base + bo, xa1 = xa0 ^ 32u, xa2 = xa0 ^ 64u, xa3 = xa0 ^ 96u;
+    const unsigned xb0 = b_base + bo, xb1 = xb0 ^ 32u, xb2 = xb0 ^ 64u, xb3 = xb0 ^ 96u;
+    const unsigned yb0 = b_base + bn, yb1 = yb0 ^ 32u, yb2 = yb0 ^ 64u, yb3 = yb0 ^ 96u;  // the next K-tile's buffer
+    const bool last = t + 1 >= KT, last2 = t + 2 >= KT;
+    // ---- phase 1: quadrant (top, left) ----
+#ifdef MMT_GEMM2_INSTR
+    g3ph = 0;
+#endif
+    G3_RD(fa[0][0], xa0, 0); G3_RD(fa[0][1], xa1, 0); G3_RD(fa[0][2], xa2, 0); G3_RD(fa[0][3], xa3, 0);
+    G3_RD(fa[1][0], xa0, 4096); G3_RD(fa[1][1], xa1, 4096); G3_RD(fa[1][2], xa2, 4096); G3_RD(fa[1][3], xa3, 4096);
+    if (!last) dma(rb_desc, obr, lbr, t + 1);
+    g3_vmwait_rt(last ? 2 : 8);  // B-right of THIS tile (requested five phases ago) has landed: read in phase 2
+    G3_SEG_BEGIN();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_TIE(fl[CUR][kk]); G3_TIE(fa[0][kk]); G3_TIE(fa[1][kk]); }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_MFMA(0, 0, fl[CUR][kk], fa[0][kk]); G3_MFMA(1, 0, fl[CUR][kk], fa[1][kk]); }
+    G3_SEG_END();
+    // ---- phase 2: quadrant (top, right) ----
+#ifdef MMT_GEMM2_INSTR
+    g3ph = 1;
+#endif
+    G3_RD(fr[0], xb0, 4096); G3_RD(fr[1], xb1, 4096); G3_RD(fr[2], xb2, 4096); G3_RD(fr[3], xb3, 4096);
+    if (!last) dma(ra_desc, oab, lab, t + 1);
+    g3_vmwait_rt(last ? 0 : 8);  // A-bottom of this tile has landed: read in phase 3
+    G3_SEG_BEGIN();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) G3_TIE(fr[kk]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_MFMA(0, 1, fr[kk], fa[0][kk]); G3_MFMA(1, 1, fr[kk], fa[1][kk]); }
+    G3_SEG_END();
+    // ---- phase 3: quadrant (bottom, right) ----
+#ifdef MMT_GEMM2_INSTR
+    g3ph = 2;
+#endif
+    G3_RD(fa[0][0], xa0, 8192); G3_RD(fa[0][1], xa1, 8192); G3_RD(fa[0][2], xa2, 8192); G3_RD(fa[0][3], xa3, 8192);
+    G3_RD(fa[1][0], xa0, 12288); G3_RD(fa[1][1], xa1, 12288); G3_RD(fa[1][2], xa2, 12288); G3_RD(fa[1][3], xa3, 12288);
+    if (!last2) dma(ra_desc, oat, lat, t + 2);
+    g3_vmwait_rt(last ? 0 : (last2 ? 4 : 6));  // A-top and B-left of the NEXT tile have landed: read in phase 4 / its phase 1
+    G3_SEG_BEGIN();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_TIE(fa[0][kk]); G3_TIE(fa[1][kk]); }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_MFMA(2, 1, fr[kk], fa[0][kk]); G3_MFMA(3, 1, fr[kk], fa[1][kk]); }
+    G3_SEG_END();
+    // ---- phase 4: quadrant (bottom, left): its fragments are in registers; the NEXT tile's left B fragments are read ----
+#ifdef MMT_GEMM2_INSTR
+    g3ph = 3;
+#endif
+    if (!last) { G3_RD(fl[NXT][0], yb0, 0); G3_RD(fl[NXT][1], yb1, 0); G3_RD(fl[NXT][2], yb2, 0); G3_RD(fl[NXT][3], yb3, 0); }
+    if (!last2) dma(rb_desc, obl, lbl, t + 2);
+    G3_SEG_BEGIN();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { G3_MFMA(2, 0, fl[CUR][kk], fa[0][kk]); G3_MFMA(3, 0, fl[CUR][kk], fa[1][kk]); }
+    G3_SEG_END();
+  };
+  for (int t = 0; t < KT; t += 2) {
+    ktile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < KT) ktile(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (wm == 0) g3_barrier();  // group 0 catches up with the extra barrier group 1 took
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef MMT_GEMM2_INSTR
+  if (epi.row_index == nullptr && epi.seed_dev != nullptr && (tid == 0 || tid == 256)) {  // lab: seed_dev doubles as the debug buffer
+    long long* d = (long long*)epi.seed_dev + ((int64_t)bid * 2 + wm) * 20;
+    for (int k = 0; k < 16; ++k) d[k] = g3t[k];
+    d[16] = clock64() - g3t0; d[17] = KT; d[18] = g3t0;
+  }
+#endif
+  gemm_tile_epilogue<256, 256, 2, 4, 512, EPI, false>(acc, smem_raw, m0, n0, M, N, nrows, Cout, ldc, epi, wm, wn, 0, tid, nullptr);
+}
+
+template <int EPI>
+static int launch3(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  constexpr int lds = 2 * G3_BUF;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)gemm3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MMT_ERR_ARG;
+    configured = true;
+  }
+  const int grid = ((M + 255) / 256) * (N / 256);
+  hipLaunchKernelGGL((gemm3_kernel<EPI>), dim3(grid), dim3(512), lds, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K,
+                     e, nr);
+  return (int)hipGetLastError();
+}
+
+// tile 21 of mmt_gemm2_dispatch: N % 256 == 0, K % 64 == 0, A / B rows readable up to round_up(M, 1) (rows are clamped)
+int mmt_gemm3_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  if (N % 256 || K % 64) return MMT_ERR_ARG;
+  switch (epilogue) {
+    case MMT_EPI_BF16: return launch3<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_BF16: return launch3<MMT_EPI_BIAS_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_GELU: return launch3<MMT_EPI_BIAS_GELU>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_DROP_RES: return launch3<MMT_EPI_BIAS_DROP_RES>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_DGELU: return launch3<MMT_EPI_DGELU>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_ADD_F32: return launch3<MMT_EPI_ADD_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_F32: return launch3<MMT_EPI_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_F32: return launch3<MMT_EPI_BIAS_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
+  return MMT_ERR_ARG;
+}

@@ -111,6 +111,14 @@ def test_gemm_nt_192_wide_tiles(tile, M, N, K):
   _wide_tile_case(tile, M, N, K)
 
 
+@pytest.mark.parametrize('M,N,K', [(300, 256, 64), (777, 512, 128), (640, 256, 192), (3583, 3072, 512), (7168, 1536, 512),
+                                   (2100, 1024, 1024)])
+def test_gemm_nt_256x256_eight_phase_tile(M, N, K):
+  """gemm3.hip (tile 21): 256x256 tiles, 8 waves in two groups a barrier apart, four phases per K-tile, LDS-DMA ring that
+  is never drained; K-tile counts 1, 2, 3, 8, 16 exercise the prologue / tail wait counts.  Every epilogue."""
+  _wide_tile_case(21, M, N, K)
+
+
 def _wide_tile_case(tile, M, N, K):
   from mmt_amd import ops
   R = ops.pad_rows(M)
