@@ -930,6 +930,27 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
   //   * short batches (M <= 1024: the text tower's ~560..960 token rows): too few 128x128 tiles for 256 CUs; the
   //     128x64 8-wave tile wins everywhere (tools/gemm_lab.py --text: 10.3 vs 13.2 us FFN-up at 560 live rows).
   if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  // r04: the 256x256 eight-phase kernel (gemm3.hip, tile 21) where the problem fills the chip with such tiles for long enough:
+  // at least ~one round of them (220 of 256 CUs) with K >= 1024, or 160 with K >= 3072 (at K = 512 -- 8 K-tiles -- prologue
+  // and epilogue eat the gain: configs[3] 3.00 -> 3.26 ms with it).  Measured (tools/gemm3_lab.py,
+  // tools/gemm_lab.py --tiles 14,21): 1.34 vs 0.94 PFLOP/s at 8192 x 65536 x 7168, 146 vs 206 us at 14464 x 1024 x 6144,
+  // 192 vs 238 us at 14464 x 6144 x 1024; at the headline's 3 639 live rows (180 tiles x 8 K-tiles) it LOSES 30.7 vs 27.7 us.
+  // MMT_TILE_BIG=0 switches it off (same-box A/B).
+  {
+    static int big = -1;
+    static double big_frac = 0.52;
+    if (big < 0) {
+      const char* b = getenv("MMT_TILE_BIG");
+      const char* lf = getenv("MMT_LIVE_FRACTION");
+      if (lf && atof(lf) > 0.0) big_frac = atof(lf);
+      big = b ? atoi(b) : 1;
+    }
+    if (big && e.reserved == 0 && N % 256 == 0 && M > 1024) {
+      const int est = nr ? (int)(M * big_frac) : M;
+      const long t21 = (long)((est + 255) / 256) * (N / 256);
+      if ((t21 >= 220 && K >= 1024) || (t21 >= 160 && K >= 48 * 64)) return mmt_gemm2_dispatch(21, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    }
+  }
   // lab switches (same-box A/B): MMT_TILE_NARROW = tile for the packed N < 1024 GEMMs, MMT_TILE_WIDE = tile for N >= 1024
   static int narrow = -1, wide = -1;
   if (narrow < 0) {

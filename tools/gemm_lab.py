@@ -134,7 +134,7 @@ def main():
       cs = torch.zeros((rows + 127) // 128, N, device=dev)
       fns, used = [], []
       for tile in tiles:
-        if (tile in (4, 6) and N % 256) or (tile in (15, 16, 17, 20) and N % 192):
+        if (tile in (4, 6, 21) and N % 256) or (tile in (15, 16, 17, 20) and N % 192):
           continue
         kw = dict(bias=bias, res=res, out2=out2, aux=aux, tile=tile)
         if epi == 'BIAS_DROP_RES':
