@@ -324,10 +324,16 @@ def main():
   ap.add_argument('--grad-algo', choices=['allreduce', 'rs_ag'], default='allreduce',
                   help='N > 1: every gradient span as one all-reduce (RCCL picks ring / tree) or as reduce-scatter + '
                        'all-gather (the decomposition a direct full-mesh exchange over all xGMI links maps to)')
+  ap.add_argument('--shard-optimizer', action='store_true',
+                  help='N > 1 with --grad-algo rs_ag: Adam on the 1/N shard the reduce-scatter leaves on each rank, all-gather '
+                       'of the updated weights instead of the reduced gradients (GraphedTrainStep(shard_optimizer=True))')
+  ap.add_argument('--fill', type=float, default=None,
+                  help='mean fraction of valid feature tokens in the synthetic minibatches (default: SURVEY 8d, U{0..30} '
+                       'valid tokens per expert = 0.5); the headline number is quoted at the default')
   ap.add_argument('--fork', type=int, default=None,
                   help='bit mask of the work that leaves the main stream for a parallel branch of the step graph '
                        '(mmt_amd.train_step.FORK_*: 1 weight gradients, 2 ... in two early launches, 4 LN/table reductions, '
-                       '16 per-region Adam, 32 text heads, 64 ReduceDim weight gradients); 0 = one serial chain; default: all but 2')
+                       '16 per-region Adam, 32 text heads, 64 ReduceDim weight gradients); default 0 = one serial chain (forked graphs measured slower, DESIGN section 7)')
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
@@ -339,6 +345,13 @@ def main():
       ap.error('--ragged-inputs carries live rows only: it cannot feed the dense (unpacked) step')
     args.no_dense = True
 
+  if args.capture_collectives and args.gpus > 1 and not os.environ.get('MMT_ALLOW_CAPTURED_COLLECTIVES'):
+    # captured collectives have only ever run on a 1-rank communicator (which short-circuits RCCL's kernels): a multi-GPU
+    # run must not pick an unvalidated path by accident
+    raise SystemExit('--capture-collectives is validated on a 1-rank RCCL group only; refusing --gpus %d (set '
+                     'MMT_ALLOW_CAPTURED_COLLECTIVES=1 to try it on a multi-GPU box)' % args.gpus)
+  if args.shard_optimizer and args.grad_algo != 'rs_ag':
+    ap.error('--shard-optimizer needs --grad-algo rs_ag')
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     # bare `python bench.py --gpus N`: this process becomes the launcher -- N ranks of this same command, one per GPU,
     # rendezvous on 127.0.0.1 (what `python -m torch.distributed.run --nproc-per-node N` would set up); rank 0 prints
@@ -380,7 +393,8 @@ def main():
   NBATCH = 8 if args.config == 1 else 4
   batches, input_bytes = [], []
   for i in range(NBATCH):
-    mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS, max_pos=MAX_POS)
+    mb, text = synthetic.make_batch(1000 + 17 * rank + i, BATCH, synthetic.MSRVTT_MODALITIES, TOKENS, max_pos=MAX_POS,
+                                    fill=args.fill)
     mb['text'] = text.view(-1, 768)
     if args.ragged_inputs:
       rag = RaggedFeatures.from_dense(mb['features'], mb['features_t'], mb['features_ind'], mb['features_maxpool'],
@@ -416,7 +430,7 @@ def main():
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
                               capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
-                              input_slots=slots, bind_inputs=bind)
+                              input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer)
     runner.measure_exposed = world > 1 or args.force_collectives
     nonlocal slots_used
     slots_used = slots
@@ -541,6 +555,7 @@ def main():
                    'video_input_bytes_per_step': int(sum(input_bytes) / len(input_bytes)),
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
                    'grad_wire_dtype': args.grad_dtype, 'grad_algo': args.grad_algo,
+                   'optimizer_sharded': bool(args.shard_optimizer and world > 1), 'fill_arg': args.fill,
                    # mean ms per step between the end of the last backward stage and the last gradient reduction having
                    # landed (HIP events on the compute stream): what the staged overlap did not hide; null at N = 1
                    'exposed_collective_ms_rank0': exposed_ms,

@@ -562,7 +562,10 @@ typedef struct MmtBertBatch {
   /* second hipStream_t of the caller (nullable = no forking).  The engine orders the two streams with events
    * (mmt_stream_fork), which become graph edges under stream capture: the forked kernels then sit on a parallel branch
    * of the captured step.  Without MMT_FORK_JOIN the work on `side_stream` is still pending when the call returns: the
-   * caller joins (mmt_stream_fork(side_stream, stream)) before anything on `stream` consumes a parameter gradient. */
+   * caller joins (mmt_stream_fork(side_stream, stream)) before anything on `stream` consumes a parameter gradient.
+   * Under stream CAPTURE, MMT_FORK_WGRAD without MMT_FORK_JOIN is only valid when all layer ranges of one backward are
+   * captured into the SAME graph: the "weight gradients of layer l + 2 are done" events a range waits for must have been
+   * recorded in the capture that waits (ranges captured as separate graphs pass MMT_FORK_JOIN on every call). */
   void* side_stream;
 } MmtBertBatch;
 

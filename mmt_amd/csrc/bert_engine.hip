@@ -130,19 +130,32 @@ int tail_rows(const MmtBertBatch* b, const Ws& w) {
 // ---- forked launches (MmtBertBatch.fork) ----
 // "weight gradients of layer l have been issued" events, one per layer parity and workspace: layer l-2 overwrites the
 // buffers layer l's weight gradients read, so `stream` waits for that event first.
-struct DoneEvents { const void* ws; hipEvent_t ev[2]; };
+struct DoneEvents { const void* ws; hipEvent_t ev[2]; unsigned long long cap[2]; };  // cap: capture the record happened in (0: none)
 DoneEvents g_done[16];
 int g_done_n = 0;
 std::mutex g_done_mu;
+unsigned long long capture_id(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(s, &st, &id) != hipSuccess || st != hipStreamCaptureStatusActive) return 0;
+  return id;
+}
+DoneEvents* done_entry(const void* ws);
 hipEvent_t* done_events(const void* ws) {
+  DoneEvents* e = done_entry(ws);
+  return e ? e->ev : nullptr;
+}
+DoneEvents* done_entry(const void* ws) {
   std::lock_guard<std::mutex> lock(g_done_mu);
   for (int i = 0; i < g_done_n; ++i)
-    if (g_done[i].ws == ws) return g_done[i].ev;
+    if (g_done[i].ws == ws) return &g_done[i];
   DoneEvents& e = g_done[g_done_n < 16 ? g_done_n++ : 15];  // (more than 16 live workspaces: the last slot is recycled)
   e.ws = ws;
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 2; ++p) {
     if (!e.ev[p] && hipEventCreateWithFlags(&e.ev[p], hipEventDisableTiming) != hipSuccess) return nullptr;
-  return e.ev;
+    e.cap[p] = 0;
+  }
+  return &e;
 }
 
 }  // namespace
@@ -289,8 +302,10 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   const bool fork_r = fork & MMT_FORK_REDUCE, join = fork & MMT_FORK_JOIN;
   void* wstream = fork_w ? side : stream;   // weight gradients
   void* rstream = fork_r ? side : stream;   // LayerNorm / table reductions
-  hipEvent_t* done = fork_w ? done_events(ws) : nullptr;
-  if (fork_w && !done) return MMT_ERR_ARG;
+  DoneEvents* done_e = fork_w ? done_entry(ws) : nullptr;
+  if (fork_w && !done_e) return MMT_ERR_ARG;
+  hipEvent_t* done = done_e ? done_e->ev : nullptr;
+  unsigned long long* done_cap = done_e ? done_e->cap : nullptr;
 
   // LayerNorm gamma/beta and embedding-table partial sums stay in per-site buffers; ONE batched reduction at the end
   MmtColReduceJob jobs[2 * 64 + 5];
@@ -321,6 +336,8 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     // the weight gradients of layer l + 2 read the buffers this layer is about to overwrite (only an issue when they
     // were forked and not joined since: with MMT_FORK_JOIN every range call ends with the side stream drained)
     if (fork_w && !join && l + 2 <= m->layers - 1) {
+      // under capture the event must have been recorded in THIS capture (ranges captured as separate graphs: MMT_FORK_JOIN)
+      if (capture_id((hipStream_t)stream) != done_cap[par]) return MMT_ERR_ARG;
       if (hipStreamWaitEvent((hipStream_t)stream, done[par], 0) != hipSuccess) return MMT_ERR_ARG;
     }
     if (nc && l == m->layers - 1) {
@@ -373,7 +390,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         g.item[3].out = P.g_wo;   g.item[3].bias_out = P.g_bo; g.item[3].reserved = nc;
         TRY(mmt_wgrad_grouped(&g, wstream));
         TRY(mmt_reduce_slabs_pair(t.wslab, (int64_t)3 * d * d, P.g_wqkv, t.bslab, (int64_t)3 * d, P.g_bqkv, TAIL_WSPLIT, wstream));
-        if (fork_w && hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG;
+        if (fork_w) { if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG; done_cap[par] = capture_id((hipStream_t)side); }
       }
       e = {};
       float* dnext = w.dA;
@@ -430,6 +447,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         TRY(mmt_wgrad_grouped(&g, side));
       }
       if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG;
+      done_cap[par] = capture_id((hipStream_t)side);
     }
     e = {};
     e.res = w.dz; e.ldres = d;

@@ -98,6 +98,23 @@ extern "C" int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int co
 }
 
 // ---- fused Adam over a flat fp32 buffer (torch.optim.Adam semantics, train.py:100) --------------
+// The update of four elements, shared by the plain kernel (one span: a data-parallel rank's shard) and the fused one
+// (whole buffer + bf16 shadows): every multiply-add is an explicit fma and every product an explicit multiply, so that
+// both kernels round identically whatever the compiler would contract -- a sharded step must reproduce the full one bit
+// for bit (tests/test_dp_gpu.py).
+__device__ __forceinline__ void adam_update4(f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, float beta1, float beta2,
+                                             float eps, float weight_decay, float step_size, float inv_sqrt_bc2) {
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gg = __builtin_fmaf(weight_decay, pv[k], gv[k]);
+    mv[k] = __builtin_fmaf(beta1, mv[k], __fmul_rn(omb1, gg));
+    vv[k] = __builtin_fmaf(beta2, vv[k], __fmul_rn(__fmul_rn(omb2, gg), gg));
+    const float denom = __builtin_fmaf(sqrtf(vv[k]), inv_sqrt_bc2, eps);
+    pv[k] = __builtin_fmaf(-step_size, __fdiv_rn(mv[k], denom), pv[k]);
+  }
+}
+
 // p, m, v updated in place from g; `step_dev` holds the 1-based step count on the device (graph safe).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
@@ -110,14 +127,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float gg = gv[k] + weight_decay * pv[k];
-      mv[k] = beta1 * mv[k] + (1.0f - beta1) * gg;
-      vv[k] = beta2 * vv[k] + (1.0f - beta2) * gg * gg;
-      const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
-      pv[k] -= step_size * (mv[k] / denom);
-    }
+    adam_update4(pv, gv, mv, vv, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2);
     ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
   }
 }
@@ -143,19 +153,6 @@ extern "C" int mmt_adam_step(float* params, const float* grads, float* exp_avg, 
 // host side); the first-block prefix of every segment travels by value so a block finds its segment without a
 // dependent chain of loads.
 struct AdamSegIndex { int32_t n; int32_t begin[MMT_ADAM_SEG_MAX + 1]; };
-
-__device__ __forceinline__ void adam_update4(f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, float beta1, float beta2,
-                                             float eps, float weight_decay, float step_size, float inv_sqrt_bc2) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float gg = gv[k] + weight_decay * pv[k];
-    mv[k] = beta1 * mv[k] + (1.0f - beta1) * gg;
-    vv[k] = beta2 * vv[k] + (1.0f - beta2) * gg * gg;
-    const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
-    pv[k] -= step_size * (mv[k] / denom);
-  }
-}
-
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          const MmtAdamSeg* __restrict__ segs, AdamSegIndex idx, float lr,

@@ -112,24 +112,74 @@ class WireBuffer:
       buf = self._bufs[key] = torch.zeros(numel, device=span.device, dtype=dtype)
     return buf
 
+  def _shard_geometry(self, n, world):
+    per = -(-n // (4 * world)) * 4  # elements per rank, a multiple of 4 (16-byte aligned shard starts)
+    return per
+
+  def reduce_scatter(self, span, group, async_op=True):
+    """First half of 'rs_ag' on its own: -> (work, shard, send buffer, lo, cnt).  Once `work` has completed, `shard` (wire
+    dtype, `per` elements, persistent per span) holds the SUM over ranks of span[lo : lo + per], lo = rank * per; its first
+    cnt elements lie inside the span (the tail of the last rank's shard is padding).  `shard_f32` widens a bf16 shard."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    wire = self.dtype if self.dtype not in (None, torch.float32) else None
+    n = span.numel()
+    per = self._shard_geometry(n, world)
+    dt = wire or torch.float32
+    if wire is None and n == per * world:
+      buf = span
+    else:
+      buf = self._buf(span, per * world, dt)  # (the tail beyond n is zero on every rank: the sums there stay zero)
+      buf[:n].copy_(span)
+    key = ('shard', span.data_ptr(), per, dt)
+    shard = self._bufs.get(key)  # this rank's reduced shard: its own buffer (no send / receive aliasing)
+    if shard is None:
+      shard = self._bufs[key] = torch.empty(per, device=span.device, dtype=dt)
+    work = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    lo = rank * per
+    return work, shard, buf, lo, max(0, min(per, n - lo))
+
+  def shard_f32(self, span, shard):
+    """The reduced shard as fp32 (a persistent widened copy when the wire is bf16); call after the collective completed."""
+    if shard.dtype == torch.float32:
+      return shard
+    key = ('shard32', span.data_ptr(), shard.numel())
+    out = self._bufs.get(key)
+    if out is None:
+      out = self._bufs[key] = torch.empty(shard.numel(), device=shard.device, dtype=torch.float32)
+    out.copy_(shard)
+    return out
+
+  def all_gather_span(self, span, group, async_op=True):
+    """span (fp32 view of a flat buffer) holds valid values in this rank's shard [rank * per, ...) only: all-gather the
+    shards so that every rank holds the whole span.  -> (work, finish)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = span.numel()
+    per = self._shard_geometry(n, world)
+    if n == per * world:
+      mine = span[rank * per:(rank + 1) * per]
+      if dist.get_backend(group) == 'nccl':
+        return dist.all_gather_into_tensor(span, mine, group=group, async_op=async_op), (lambda: None)
+      mine = mine.clone()  # (gloo: no in-place form)
+      return dist.all_gather_into_tensor(span, mine, group=group, async_op=async_op), (lambda: None)
+    buf = self._buf(span, per * world, torch.float32)
+    key = ('wshard', span.data_ptr(), per)
+    mine = self._bufs.get(key)
+    if mine is None:
+      mine = self._bufs[key] = torch.zeros(per, device=span.device, dtype=torch.float32)
+    lo = rank * per
+    cnt = max(0, min(per, n - lo))
+    if cnt:
+      mine[:cnt].copy_(span[lo:lo + cnt])
+    work = dist.all_gather_into_tensor(buf, mine, group=group, async_op=async_op)
+    return work, (lambda: span.copy_(buf[:n]))
+
   def reduce(self, span, group, async_op=True):
     """span: fp32 view of the flat gradient buffer.  -> (work handle, finish callable)"""
     wire = self.dtype if self.dtype not in (None, torch.float32) else None
     world = dist.get_world_size(group)
     if self.algo == 'rs_ag' and world > 1:
       n = span.numel()
-      per = -(-n // world)
-      dt = wire or torch.float32
-      if wire is None and n == per * world:
-        buf = span  # the gathered result lands in the gradient buffer itself
-      else:
-        buf = self._buf(span, per * world, dt)  # (the zero tail stays zero: only [:n] is ever written)
-        buf[:n].copy_(span)
-      key = ('shard', span.data_ptr(), per, dt)
-      shard = self._bufs.get(key)  # this rank's reduced shard: its own buffer (no send / receive aliasing)
-      if shard is None:
-        shard = self._bufs[key] = torch.empty(per, device=span.device, dtype=dt)
-      rs = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+      rs, shard, buf, _, _ = self.reduce_scatter(span, group, async_op)
       fin = (lambda: None) if buf is span else (lambda: span.copy_(buf[:n]))
       if dist.get_backend(group) == 'nccl':
         # both collectives run in issue order on the communicator's stream: no host round trip between them

@@ -10,6 +10,12 @@ from . import _lib, ops
 from ._lib import check
 
 
+def ctypes_ptr(t, offset):
+  """Raw pointer to element `offset` of the fp32 tensor `t`."""
+  import ctypes
+  return ctypes.c_void_p(t.data_ptr() + 4 * int(offset))
+
+
 class FlatAdam:
   """`param_groups` is shaped like a torch optimizer's, so scheduler code that only touches
   `optimizer.param_groups[i]['lr']` (the reference's StepLR + LinearWarmup, train.py:101-103,
@@ -118,6 +124,9 @@ class FlatAdam:
       self._ensure_state()
       steps = set()
       with torch.no_grad():
+        # parameters without an entry in the checkpoint (never stepped there) must not keep moments of THIS run
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
         for i, p in enumerate(f.params):
           st = state.get(i, state.get(str(i)))
           if st is None:
@@ -162,6 +171,27 @@ class FlatAdam:
                                    f.count, float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                    ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()), 'mmt_adam_step')
     f._dirty = True  # the bf16 shadows are stale now (the kernel wrote through raw pointers)
+
+  @torch.no_grad()
+  def step_shard(self, offset, count, grad, first):
+    """Adam over master[offset : offset + count] with the gradients in `grad` (fp32, >= count elements) -- a data-parallel
+    rank's share of the step when the gradient exchange is a reduce-scatter (`GraphedTrainStep(shard_optimizer=True)`:
+    train.py:97-103's optimizer run on 1/N of the parameters per rank, the updated weights all-gathered afterwards).  All
+    shards of a step share one step count: `first` advances it.  The bf16 shadows are stale afterwards (`flat.pack`)."""
+    f = self.flat
+    self._ensure_state()
+    self.sync_lr()
+    if first:
+      self.step_dev.add_(1)
+    if count <= 0:
+      return
+    if offset % 4 or count % 4:
+      raise ValueError('FlatAdam.step_shard: offset and count must be multiples of 4 elements')
+    check(_lib.lib().mmt_adam_step(ctypes_ptr(f.master, offset), ops._p(grad), ctypes_ptr(self.exp_avg, offset),
+                                   ctypes_ptr(self.exp_avg_sq, offset), count, float(self.lr), self.betas[0], self.betas[1],
+                                   self.eps, self.weight_decay, ops._p(self.step_dev), ops._p(self.lr_dev), ops._stream()),
+          'mmt_adam_step')
+    f._dirty = True
 
   @torch.no_grad()
   def step_span(self, offset, count, bump):
@@ -285,4 +315,25 @@ def load_merged_state_dict(model, optimizers, sd):
     own = opt.state_dict()['param_groups'][0]
     g = dict(own, **{k: v for k, v in hyper.items() if k in own and not torch.is_tensor(own[k])})
     g['params'] = list(range(len(params)))
+    if isinstance(opt, torch.optim.Optimizer) and len(opt.state):
+      # A torch optimizer that has stepped -- possibly inside a captured graph, which holds the ADDRESSES of its state
+      # tensors: torch's load_state_dict would replace them (the graph would keep updating the orphans).  Copy in place.
+      with torch.no_grad():
+        for local, p in enumerate(params):
+          cur, st = opt.state.get(p), sub_state.get(local)
+          if cur is None:
+            if st is not None:
+              raise ValueError('optimizer state for a parameter this optimizer has never stepped: load before the first step')
+            continue
+          for k in ('step', 'exp_avg', 'exp_avg_sq'):
+            if st is None:
+              cur[k].zero_()
+            elif torch.is_tensor(cur[k]):
+              cur[k].copy_(torch.as_tensor(st[k]).to(cur[k].dtype))
+            else:
+              cur[k] = st[k]
+        for k, v in g.items():
+          if k != 'params' and not torch.is_tensor(opt.param_groups[0].get(k)):
+            opt.param_groups[0][k] = v
+      continue
     opt.load_state_dict({'state': sub_state, 'param_groups': [g]})

@@ -49,10 +49,12 @@ def vid_bert_params(hidden=512, layers=4, heads=4, inter=3072, max_pos=32, dropo
 
 
 def make_batch(seed, batch, modalities, max_tokens=30, captions=1, max_words=30,
-               max_pos=32, text_dim=768, missing_prob=None):
+               max_pos=32, text_dim=768, missing_prob=None, fill=None):
   """Returns (minibatch dict of CPU tensors, text (B,C,text_dim) fp32).
 
-  `text` stands in for the output of the (out-of-scope) text tower."""
+  `text` stands in for the output of the (out-of-scope) text tower.  fill (None = SURVEY 8d's U{0..max_tokens} valid
+  lengths, mean fill 0.5): mean fraction of the feature-token slots that hold a real token -- valid lengths uniform on
+  {0..2 fill max_tokens} (fill <= 0.5) or on {max_tokens (2 fill - 1)..max_tokens} (fill > 0.5); bench.py --fill."""
   rs = np.random.RandomState(seed)
   dims = compute_dims(modalities)
   mb = {k: collections.OrderedDict() for k in
@@ -60,6 +62,12 @@ def make_batch(seed, batch, modalities, max_tokens=30, captions=1, max_words=30,
   for mod in dims:
     d = dims[mod]['dim']
     k = rs.randint(0, max_tokens + 1, size=batch)  # valid length, 0 => missing
+    if fill is not None:  # (same draws, rescaled: the default stream of the golden fixtures is untouched)
+      f = min(max(float(fill), 0.0), 1.0)
+      if f <= 0.5:
+        k = np.round(k * (2.0 * f)).astype(k.dtype)
+      else:
+        k = (max_tokens - np.round((max_tokens - k) * (2.0 - 2.0 * f))).astype(k.dtype)
     if missing_prob is not None:
       k = np.where(rs.rand(batch) < missing_prob, 0, np.maximum(k, 1))
     ind = (np.arange(max_tokens)[None, :] < k[:, None]).astype(np.float32)

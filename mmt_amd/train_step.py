@@ -137,13 +137,18 @@ class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
                overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
-               grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None):
+               grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None, shard_optimizer=False):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
     grad_dtype: torch.bfloat16 sends the gradient all-reduces in bf16 (half the bytes over xGMI, `dist.WireBuffer`);
     None / torch.float32 reduces the fp32 buffer in place.
     grad_algo: 'allreduce' | 'rs_ag' (reduce-scatter + all-gather per span, `dist.WireBuffer`).
+    shard_optimizer (with grad_algo='rs_ag', world size > 1): each rank runs Adam on the 1/N shard of every span whose
+    reduced gradients the reduce-scatter left with it, and the UPDATED WEIGHTS are all-gathered instead of the reduced
+    gradients (same bytes on the wire) -- the optimizer pass (HBM-bound: 28 B per parameter) shrinks N-fold per rank,
+    at the price of one re-pack of the bf16 weight shadows.  Bit-identical weights to the all-reduce path
+    (tests/test_dist_cpu.py, tests/test_dp_gpu.py).  Reference: train.py:97-103, trainer/trainer.py:203-204.
     split_bottom: staged mode reduces layer 0's gradients before the embedding / token stage runs, so that only the
     expert projections + embedding tables (about half of the last span) are reduced after the backward has ended.
     input_slots: K > 1 keeps K sets of static input buffers and captures the step once per set (same kernels, same
@@ -180,6 +185,7 @@ class GraphedTrainStep:
     # invalidates a capture that happens to be open.  Calls of the capturing thread itself stay checked.
     self._cap_mode = 'thread_local' if dist.is_initialized() else 'global'
     self._one_graph = False
+    self._pool = None  # graph memory pool shared by the captures of every input slot
     self._staging = None  # device-side landing buffer of prefetch()
     flats = model.flats() if hasattr(model, 'flats') else [model._flat]  # video side (+ the native text tower's)
     flat_ids = {id(p) for f in flats for p in f.params}
@@ -199,6 +205,9 @@ class GraphedTrainStep:
       self.opt_rest = None
     self.grad_dtype = grad_dtype
     self.grad_algo, self._split_bottom = grad_algo, bool(split_bottom)
+    self.shard_opt = bool(shard_optimizer) and self.world > 1
+    if shard_optimizer and grad_algo != 'rs_ag':
+      raise ValueError("shard_optimizer needs grad_algo='rs_ag' (the shards are what the reduce-scatter leaves on a rank)")
     self._wire = mdist.WireBuffer(grad_dtype, grad_algo)
     self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group, grad_dtype=grad_dtype, algo=grad_algo)
                   for i, f in enumerate(flats)]
@@ -238,7 +247,12 @@ class GraphedTrainStep:
           self.static = st
           if self._bind:
             self._bind(st)
+          # the slots never replay concurrently: their captures share ONE graph memory pool (activations / workspaces of a
+          # step exist once, not once per slot); what a capture leaves alive (its loss / embedding outputs) stays allocated
           self._capture()
+          if self._pool is None:
+            g0 = self._graphs[0]
+            self._pool = g0.pool()
           self._caps.append((self._graphs, self._e, self.loss, self._one_graph))
         self.static = self._statics[0]
         if self._bind:
@@ -552,16 +566,38 @@ class GraphedTrainStep:
     out = []
     for n in names:
       flat, off, cnt = self._regions[n]
-      out.append(self._wire.reduce(flat.current_grad()[off:off + cnt], self.group))
+      span = flat.current_grad()[off:off + cnt]
+      if self.shard_opt:
+        work, shard, _, lo, own = self._wire.reduce_scatter(span, self.group)
+        out.append((work, dict(flat=flat, off=off, cnt=cnt, span=span, shard=shard, lo=lo, own=own)))
+      else:
+        out.append(self._wire.reduce(span, self.group))
     return out
 
-  @staticmethod
-  def _finish(handles):
-    """handles: [(work, finish)] of WireBuffer.reduce -- wait for every collective, then unpack the wire buffers."""
+  def _finish(self, handles):
+    """handles: [(work, finish)] of WireBuffer.reduce -- wait for every collective, then unpack the wire buffers.  Sharded
+    optimizer: [(work, span record)] of WireBuffer.reduce_scatter -- Adam on this rank's shard of every span, all-gather of
+    the updated weights, one re-pack of the bf16 shadows."""
     for h, _ in handles:
       h.wait()
-    for _, fin in handles:
+    if not self.shard_opt:
+      for _, fin in handles:
+        fin()
+      return
+    seen = set()
+    for _, r in handles:
+      opt = self.opt_flats[[id(o.flat) for o in self.opt_flats].index(id(r['flat']))]
+      grad = self._wire.shard_f32(r['span'], r['shard'])
+      opt.step_shard(r['off'] + r['lo'], r['own'], grad, first=id(opt) not in seen)
+      seen.add(id(opt))
+    gathers = [self._wire.all_gather_span(r['flat'].master[r['off']:r['off'] + r['cnt']], self.group) for _, r in handles]
+    for w, _ in gathers:
+      w.wait()
+    for _, fin in gathers:
       fin()
+    for o in self.opt_flats:
+      if id(o) in seen:
+        o.flat.pack(force=True)
 
   def _zero(self):
     for o in self.opt_flats:
@@ -570,12 +606,20 @@ class GraphedTrainStep:
       self.opt_rest.zero_grad(set_to_none=True)
 
   def _opt(self):
-    for o in self.opt_flats:
-      o.step()
+    if not self.shard_opt:  # (sharded: the flat buffers were stepped shard by shard in _finish)
+      for o in self.opt_flats:
+        o.step()
     if self.opt_rest is not None:
       self.opt_rest.step()
 
   def _sync_all(self):
+    if self.shard_opt:  # every flat buffer as ONE span; parameters outside them keep the all-reduce bucket
+      self._regions = {'flat%d' % i: (o.flat, 0, o.flat.count) for i, o in enumerate(self.opt_flats)}
+      for o in self.opt_flats:
+        mdist.gather_stray_grads(o.flat)
+      self._finish(self._reduce_async(list(self._regions)))
+      mdist.GradSync(None, self.sync.other, self.group).sync(force=self._force_coll)
+      return
     for sy in self.syncs:
       sy.sync(force=self._force_coll)
 
@@ -590,6 +634,18 @@ class GraphedTrainStep:
     moments / step counts from the same device buffers, so no re-capture is needed."""
     from .optim import load_merged_state_dict
     load_merged_state_dict(self.model, self.opt_flats + [self.opt_rest], sd)
+    # the checkpoint's learning rate reaches EVERY optimizer of the step: a captured step keeps the rate of its torch Adam
+    # in a device scalar, which load_merged_state_dict leaves alone (it only copies python-number hyper-parameters)
+    lr = sd['param_groups'][0].get('lr')
+    if lr is not None:
+      self.set_lr(float(lr))
+
+  def weights_changed(self):
+    """Call after writing parameters behind the runner's back (model.load_state_dict on a runner that already exists, e.g.
+    base/base_trainer.py:426-432 resuming into a live trainer): the captured step reads the GEMM weights from their bf16
+    shadows, which only the optimizer -- or this call -- regenerates."""
+    for o in self.opt_flats:
+      o.flat.pack(force=True)
 
   def set_lr(self, lr):
     """One learning rate for every optimizer of the step (the reference has a single param group, train.py:100)."""
@@ -648,7 +704,7 @@ class GraphedTrainStep:
     self._zero()
     if not self._multi and self._fork_on:
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
+      with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         self._fork_step()  # ONE graph whose branches are the main and the side stream
       self._graphs, self._e = (ga, None, None), None
       torch.cuda.synchronize()
@@ -656,7 +712,7 @@ class GraphedTrainStep:
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     e = g = pool = None
     if self._multi or self.staged:
-      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
+      with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
       pool = ga.pool()
       with torch.cuda.stream(self._stream):
@@ -666,7 +722,7 @@ class GraphedTrainStep:
       # single-rank one -- RCCL's stream joins the capture through the events torch.distributed records, the cross-stream
       # waits become graph edges.  Verified on a 1-rank RCCL group only (no multi-GPU box this round), hence not default.
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
+      with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
         g = self._gather(e)
         if self.staged:
@@ -687,7 +743,7 @@ class GraphedTrainStep:
     if not self._multi and not self.staged:
       # nothing happens between forward and backward on one rank: one graph for both (one launch gap less per step)
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, stream=self._stream, capture_error_mode=self._cap_mode):
+      with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
         g = self._gather(e)
         self.loss = self._loss_backward(e, g)
@@ -706,8 +762,11 @@ class GraphedTrainStep:
     else:
       with torch.cuda.graph(gb, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
         self.loss = self._loss_backward(e, g)
-    with torch.cuda.graph(gc, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
-      self._opt()
+    if self.shard_opt and self.opt_rest is None:
+      gc = None  # (the flat buffers were stepped shard by shard between the graphs: nothing left to capture)
+    else:
+      with torch.cuda.graph(gc, pool=pool, stream=self._stream, capture_error_mode=self._cap_mode):
+        self._opt()
     self._graphs, self._e = (ga, gb, gc), e
     torch.cuda.synchronize()
 

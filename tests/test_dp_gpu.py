@@ -55,7 +55,7 @@ def _slice_batch(mb, text, sl):
 
 
 def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BATCH, force_collectives=False,
-         capture_collectives=False, fork=None, grad_algo='allreduce', **build_kw):
+         capture_collectives=False, fork=None, grad_algo='allreduce', shard_optimizer=False, **build_kw):
   from mmt_amd import synthetic
   from mmt_amd.loss import MaxMarginRankingLoss
   from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
@@ -68,7 +68,8 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
   model.txt_bert.text = static['text']
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, use_graphs=True, warmup_steps=1,
                             overlap_grad_sync=overlap, grad_dtype=grad_dtype, force_collectives=force_collectives,
-                            capture_collectives=capture_collectives, fork=fork, grad_algo=grad_algo)
+                            capture_collectives=capture_collectives, fork=fork, grad_algo=grad_algo,
+                            shard_optimizer=shard_optimizer)
   if fork is not None:
     assert runner._fork_on == bool(fork)
   assert runner.staged == ((world > 1 or force_collectives) if overlap is None else overlap)
@@ -290,6 +291,47 @@ def test_reduce_scatter_all_gather_gradient_sync_equals_all_reduce(tmp_path):
   assert a['losses'] == b['losses']
   assert torch.equal(a['grad'], b['grad'])
   assert torch.equal(a['master'], b['master'])
+
+
+@pytest.mark.parametrize('overlap', [None, False])
+def test_sharded_optimizer_gives_the_all_reduce_paths_weights(tmp_path, overlap):
+  """GraphedTrainStep(grad_algo='rs_ag', shard_optimizer=True): each rank runs Adam on the shard of every gradient span
+  the reduce-scatter left with it and the UPDATED WEIGHTS are all-gathered (train.py:97-103 on 1/N of the parameters per
+  rank).  Two ranks (gloo, one GPU), staged and single-span exchange: same losses and bit-identical fp32 weights as the
+  all-reduce + full Adam path after 3 captured steps -- so the bf16 shadows the next forward reads were re-packed too."""
+  outs = {}
+  for name, kw in (('ar', dict()), ('shard', dict(grad_algo='rs_ag', shard_optimizer=True))):
+    out = str(tmp_path / name)
+    kw = dict(kw, txt_pro='gbn', dropout=0.1, layers=4, steps=3, overlap=overlap)
+    mp.spawn(_worker, args=(2, _free_port(), out, kw), nprocs=2, join=True)
+    outs[name] = (torch.load(out + '.0'), torch.load(out + '.1'))
+  a, b = outs['ar'][0], outs['shard'][0]
+  assert torch.equal(outs['shard'][0]['master'], outs['shard'][1]['master'])  # replicas in lock-step
+  assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
+  assert torch.equal(a['master'], b['master']), (a['master'] - b['master']).abs().max().item()
+
+
+def test_bench_two_ranks_sharded_optimizer_smoke(tmp_path):
+  """`python bench.py --gpus 2 --grad-algo rs_ag --shard-optimizer` end to end (self-spawned ranks, gloo moving the tensors
+  of two ranks that share this GPU): the N > 1 control flow a multi-GPU driver run takes, on the sharded-optimizer path."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MMT_BENCH_BACKEND='gloo')
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                      '--no-cpu-baseline', '--no-dense', '--grad-algo', 'rs_ag', '--shard-optimizer'],
+                     env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  line = json.loads(r.stdout.strip().splitlines()[-1])
+  assert line['n_gpus'] == 2 and line['value'] > 0
+  assert line['config']['grad_algo'] == 'rs_ag' and line['config']['optimizer_sharded'] is True
+  # and the unvalidated captured-collectives path is refused for N > 1
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--capture-collectives'], env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+  assert r.returncode != 0 and 'capture-collectives' in (r.stderr + r.stdout)
 
 
 def test_bf16_gradient_wire_format_tracks_fp32_reduction(tmp_path):

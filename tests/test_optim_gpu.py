@@ -199,3 +199,53 @@ def test_reference_optimizer_checkpoint_splits_over_the_steps_optimizers():
     fo2.step(); ro2.step(); fresh.step()
   for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
     assert torch.allclose(p.detach(), q.detach(), rtol=2e-5, atol=2e-6), n
+
+
+def test_graphed_step_optimizer_checkpoint_on_a_real_cenet():
+  """GraphedTrainStep.optimizer_state_dict / load_optimizer_state_dict on a real CENet whose step runs TWO optimizers: the
+  FlatAdam of the engine's flat buffer and a captured torch Adam (learning rate in a device scalar) for the parameters
+  outside it (txt_pro='lin' text heads).  A checkpoint taken after 2 steps and loaded into a runner that has trained on
+  restores the reference-layout state: the learning rate reaches BOTH optimizers (the device scalar included), the
+  moments of every parameter are the checkpoint's, and both runners then train in lock-step (base/base_trainer.py:353-365,
+  426-432)."""
+  from mmt_amd import synthetic
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
+  from tests.test_dp_gpu import BATCH, MODS, TOKENS, _build, _slice_batch
+  dev = torch.device('cuda', 0)
+
+  def make(lr):
+    torch.manual_seed(0)
+    model = _build(dev, txt_pro='lin', dropout=0.0)
+    mb, text = synthetic.make_batch(33, BATCH, MODS, TOKENS)
+    static = FlatMinibatch(_slice_batch(mb, text, slice(0, BATCH)), dev)
+    model.txt_bert.text = static['text']
+    return model, GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=lr, warmup_steps=1)
+
+  m1, r1 = make(1e-4)
+  assert r1.opt_rest is not None and r1._rest_lr is not None  # (the situation the device-scalar learning rate exists for)
+  for _ in range(2):
+    r1.step()
+  torch.cuda.synchronize()
+  sd = r1.optimizer_state_dict()
+  weights = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+  assert sd['param_groups'][0]['lr'] == pytest.approx(1e-4) and len(sd['param_groups']) == 1
+  # a second runner with ANOTHER rate that has already stepped (stale moments everywhere, also for parameters the
+  # checkpoint has no entry for): load weights + optimizer state, then both must continue identically
+  m2, r2 = make(3e-3)
+  for _ in range(3):
+    r2.step()
+  torch.cuda.synchronize()
+  m2.load_state_dict(weights)
+  r2.weights_changed()  # (the captured step reads bf16 shadows of the weights: regenerate them)
+  r2.load_optimizer_state_dict(sd)
+  assert r2.opt_flat.lr == pytest.approx(1e-4) and float(r2.opt_flat.lr_dev.item()) == pytest.approx(1e-4)
+  assert float(r2._rest_lr.item()) == pytest.approx(1e-4)
+  assert int(r2.opt_flat.step_dev.item()) == 2
+  assert torch.equal(r2.opt_flat.exp_avg, r1.opt_flat.exp_avg) and torch.equal(r2.opt_flat.exp_avg_sq, r1.opt_flat.exp_avg_sq)
+  l1 = [float(r1.step().item()) for _ in range(3)]
+  l2 = [float(r2.step().item()) for _ in range(3)]
+  torch.cuda.synchronize()
+  assert l1 == l2
+  for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+    assert torch.equal(p.detach(), q.detach()), n
