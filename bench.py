@@ -310,6 +310,11 @@ def main():
   ap.add_argument('--input-slots', type=int, default=0,
                   help='sets of static input buffers the step is captured for (GraphedTrainStep(input_slots=)); 0 = one per '
                        'resident minibatch (3 with --host-inputs); 1 = one set, every minibatch copied into it inside the step')
+  ap.add_argument('--in-graph-feed', action='store_true',
+                  help='with --host-inputs: the upload of minibatch i + 1 as a copy node of step i\'s graph (GraphedTrainStep(host_feed=)); '
+                       'measured SLOWER than the copy-stream upload on this runtime (the node does not overlap the kernels)')
+  ap.add_argument('--stream-wait-uploads', action='store_true',
+                  help='with --host-inputs: order upload and step by a stream-side event wait (r03) instead of a host-side one')
   ap.add_argument('--ragged-inputs', action='store_true',
                   help='video features in the ragged bf16 wire format (mmt_amd.feature_store.RaggedFeatures: live rows only, '
                        'no cast kernel) instead of the reference\'s dict of dense fp32 tensors')
@@ -409,6 +414,7 @@ def main():
     batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
 
   slots_used = 1
+  in_graph_feed_used = False
 
   def timed_run(pack, steps, warmup):
     """Builds the model + captured step for one token layout and times `steps` steps as the contract prescribes
@@ -425,17 +431,32 @@ def main():
     # Input slots: the captured step exists once per set of input buffers, so a resident minibatch (or one that a copy
     # stream uploads while the previous step runs) is consumed where it lies.  --input-slots 1 = the r01-r02 arrangement:
     # ONE set of static inputs, every minibatch copied into it (device to device) inside the timed step.
-    slots = 1 if args.eager else (args.input_slots or (3 if args.host_inputs else NBATCH))
+    slots = 1 if args.eager else (args.input_slots or (NBATCH if args.in_graph_feed or not args.host_inputs else 3))
+    # --host-inputs: the pinned minibatches ARE the loader's per-slot buffers; the captured step of slot s carries the
+    # upload of slot s + 1 (GraphedTrainStep(host_feed=)).  --ragged-inputs keeps the r03 event-ordered upload path (its
+    # copies depend on the live row counts of the minibatch).
+    in_graph_feed = args.in_graph_feed and args.host_inputs and not args.ragged_inputs and not args.eager and slots == NBATCH and slots > 1
     runner = GraphedTrainStep(model, loss_fn, static, lr=5e-5, use_graphs=not args.eager,
                               overlap_grad_sync={'auto': None, 'staged': True, 'single': False}[args.grad_sync],
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
                               capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
-                              input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer)
+                              input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer,
+                              host_feed=batches if in_graph_feed else None)
     runner.measure_exposed = world > 1 or args.force_collectives
-    nonlocal slots_used
+    runner.host_sync_uploads = not args.stream_wait_uploads
+    nonlocal slots_used, in_graph_feed_used
     slots_used = slots
+    in_graph_feed_used = in_graph_feed
     it, first = 0, None
-    if slots > 1 and args.host_inputs:
+    if in_graph_feed:
+      runner.prime(0)
+
+      def feed():  # nothing to do per step: step(slot) uploads slot + 1 from its pinned buffer inside its own graph
+        nonlocal it
+        cur = it % slots
+        it += 1
+        return cur
+    elif slots > 1 and args.host_inputs:
       # minibatch i+1 crosses PCIe on a copy stream, straight into the next slot, while step i computes
       def feed():
         nonlocal it
@@ -547,7 +568,8 @@ def main():
                                 'text tower = random-init bert-base-cased on the native engine, fine-tuned (30 tokens)'),
                    'global_batch': world * BATCH, 'seq_len': seq,
                    'parallelism': 'dp%d' % world, 'token_packing': not args.dense, 'hip_graphs': not args.eager,
-                   'inputs': 'pinned host, uploaded every step (double-buffered on a copy stream)' if args.host_inputs else 'resident in HBM',
+                   'inputs': ('pinned host, uploaded every step (the copy of minibatch i + 1 is a node of step i\'s graph)' if in_graph_feed_used else
+                              'pinned host, uploaded every step (double-buffered on a copy stream)') if args.host_inputs else 'resident in HBM',
                    # sets of input buffers the step was captured for (1 = every minibatch is copied, device to device, into
                    # one static set inside the timed step; > 1 = a minibatch is consumed in the slot it was put into)
                    'input_slots': slots_used,

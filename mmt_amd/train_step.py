@@ -137,7 +137,8 @@ class GraphedTrainStep:
 
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
                overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
-               grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None, shard_optimizer=False):
+               grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None, shard_optimizer=False,
+               host_feed=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -157,6 +158,13 @@ class GraphedTrainStep:
     runs, and the device-to-device copy of the whole minibatch into ONE set of static buffers (12 us for 26 MB at
     config B) disappears from the step.  bind_inputs(static): called before the captures of each slot, for modules
     that hold a pointer to an input tensor (bench.py's synthetic text tower).
+    host_feed: list of K = input_slots PINNED host FlatMinibatches, one per slot (where a loader deposits minibatches,
+    trainer/trainer.py:36-52,167): the captured step of slot s then CONTAINS the upload of slot (s + 1) % K from its pinned
+    buffer -- a host-to-device copy node with no predecessor inside the graph, on a branch of its own, joined at the end.
+    No cross-stream event is recorded or waited for per step (each cost 35-70 us of queue plumbing on this runtime: the
+    r03 upload path ran 0.16 ms per step behind the resident one whatever the bytes); `prime()` uploads slot 0 once.
+    Contract for the loader: pinned buffer (s + 1) % K holds minibatch i + 1 when step(s) is launched for minibatch i and is
+    not rewritten before that step has finished (`step_done(slot)`).
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
@@ -179,6 +187,10 @@ class GraphedTrainStep:
     self._bind = bind_inputs
     self._caps = None
     self._slot_ev = None
+    self._host_feed = list(host_feed) if host_feed else None
+    self._feed_stream = None
+    self._next_upload = None  # (static, pinned) the capture in progress should carry
+    self._done_ev = None
     self.capture_collectives = bool(capture_collectives)
     # With a process group alive, its watchdog thread polls events of collectives still in flight (the eager all-gather
     # issued between two captures, a neighbour's slow broadcast): in 'global' mode such a call from ANOTHER thread
@@ -243,8 +255,13 @@ class GraphedTrainStep:
       if int(input_slots) > 1:
         self._statics += [_clone_tree(minibatch) for _ in range(int(input_slots) - 1)]
         self._caps = []
-        for st in self._statics:
+        if self._host_feed is not None and len(self._host_feed) != len(self._statics):
+          raise ValueError('host_feed: one pinned FlatMinibatch per input slot')
+        for si, st in enumerate(self._statics):
           self.static = st
+          if self._host_feed is not None:
+            nx = (si + 1) % len(self._statics)
+            self._next_upload = (self._statics[nx], self._host_feed[nx])
           if self._bind:
             self._bind(st)
           # the slots never replay concurrently: their captures share ONE graph memory pool (activations / workspaces of a
@@ -303,7 +320,37 @@ class GraphedTrainStep:
     self._zero()
 
   # ---- pieces ------------------------------------------------------------------------------------
+  def _upload_branch_begin(self):
+    """Inside a capture: the next slot's host-to-device copy as a ROOT node of the graph (a branch of its own)."""
+    if self._next_upload is None or not torch.cuda.is_current_stream_capturing():
+      return
+    dst, src = self._next_upload
+    if self._feed_stream is None:
+      self._feed_stream = torch.cuda.Stream()
+    self._feed_stream.wait_stream(torch.cuda.current_stream())  # joins the capture; nothing captured yet: no predecessor
+    with torch.cuda.stream(self._feed_stream):
+      dst.flat.copy_(src.flat, non_blocking=True)
+
+  def _upload_branch_end(self):
+    if self._next_upload is None or not torch.cuda.is_current_stream_capturing():
+      return
+    torch.cuda.current_stream().wait_stream(self._feed_stream)
+
+  def prime(self, slot=0):
+    """host_feed mode: bring `slot`'s pinned minibatch into its input buffers before the first step (synchronous)."""
+    if self._host_feed is None:
+      raise RuntimeError('prime() needs host_feed')
+    self._statics[slot].flat.copy_(self._host_feed[slot].flat, non_blocking=False)
+    torch.cuda.synchronize()
+
+  def step_done(self, slot):
+    """host_feed mode: host-side wait until the last step(slot) has finished -- its graph carried the upload of slot
+    (slot + 1) % K, whose pinned buffer may be refilled from then on."""
+    if self._done_ev is not None and self._done_ev[slot] is not None:
+      self._done_ev[slot].synchronize()
+
   def _forward(self):
+    self._upload_branch_begin()
     mb = self.static
     e = self.model(mb['token_ids'], mb['features'], mb.get('features_t'), mb.get('features_ind'),
                    mb.get('features_avgpool'), mb.get('features_maxpool'), mb['query_masks'], out='embds')
@@ -706,6 +753,7 @@ class GraphedTrainStep:
       ga = torch.cuda.CUDAGraph()
       with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         self._fork_step()  # ONE graph whose branches are the main and the side stream
+        self._upload_branch_end()
       self._graphs, self._e = (ga, None, None), None
       torch.cuda.synchronize()
       return
@@ -714,6 +762,7 @@ class GraphedTrainStep:
     if self._multi or self.staged:
       with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
+        self._upload_branch_end()
       pool = ga.pool()
       with torch.cuda.stream(self._stream):
         g = self._gather(e)
@@ -736,6 +785,7 @@ class GraphedTrainStep:
           self.loss = self._loss_backward(e, g)
           self._sync_all()
         self._opt()
+        self._upload_branch_end()
       self._graphs, self._e = (ga, None, None), e
       self._one_graph = True
       torch.cuda.synchronize()
@@ -748,6 +798,7 @@ class GraphedTrainStep:
         g = self._gather(e)
         self.loss = self._loss_backward(e, g)
         self._opt()  # ... and the optimizer: the whole step is ONE graph launch
+        self._upload_branch_end()
       self._graphs, self._e = (ga, None, None), e
       torch.cuda.synchronize()
       return
@@ -811,7 +862,12 @@ class GraphedTrainStep:
       self._copy_stream = torch.cuda.Stream()
     ev = self._slot_ev[slot]
     if ev['free'] is not None:
-      self._copy_stream.wait_event(ev['free'])  # the last step that read this slot has finished
+      # the last step that read this slot has finished (K - 1 steps back): waited for on the host as well, so that no
+      # stream of the step ever waits for another stream
+      if self.host_sync_uploads:
+        ev['free'].synchronize()
+      else:
+        self._copy_stream.wait_event(ev['free'])
     else:
       self._copy_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._copy_stream):
@@ -878,11 +934,23 @@ class GraphedTrainStep:
       raise ValueError('step(slot=%d): the runner was built with one input slot' % slot)
     ev = self._slot_ev[slot] if self._slot_ev is not None else None
     if ev is not None and ev.get('pending'):
-      torch.cuda.current_stream().wait_event(ev['ready'])
+      # The upload of this slot was enqueued a whole step ago.  Waiting for it on the HOST (normally already complete: a
+      # query) keeps the compute stream free of cross-stream dependencies: a hipStreamWaitEvent in front of the graph
+      # launch costs ~0.1 ms of queue plumbing per step on this runtime, whatever the bytes (tools/feed_lab.py).
+      if self.host_sync_uploads:
+        ev['ready'].synchronize()
+      else:
+        torch.cuda.current_stream().wait_event(ev['ready'])
       ev['pending'] = False
     try:
       return self._replay()
     finally:
+      if self._host_feed is not None:
+        if self._done_ev is None:
+          self._done_ev = [None] * len(self._statics)
+        if self._done_ev[slot] is None:
+          self._done_ev[slot] = torch.cuda.Event()
+        self._done_ev[slot].record(torch.cuda.current_stream())
       if ev is not None:
         if ev['free'] is None:
           ev['free'] = torch.cuda.Event()
@@ -919,6 +987,7 @@ class GraphedTrainStep:
     return self.loss
 
   measure_exposed = False
+  host_sync_uploads = True
 
   def _exposed_pair(self):
     if not (self.measure_exposed and self._multi):

@@ -188,11 +188,26 @@ def _run_feed(dev, slots, host, steps=7):
   def bind(st):
     model.txt_bert.text = st['text']
   bind(static)
+  pinned = [FlatMinibatch(mbs[0], 'cpu', pin_memory=True) for _ in range(slots)] if host == 'graph' else None
   runner = GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-4, warmup_steps=1, input_slots=slots,
-                            bind_inputs=bind)
+                            bind_inputs=bind, host_feed=pinned)
   assert runner.input_slots == slots
   feed = [FlatMinibatch(m, 'cpu', pin_memory=True) if host else FlatMinibatch(m, dev) for m in mbs]
   losses = []
+  if host == 'graph':
+    # the loader's side of GraphedTrainStep(host_feed=): slot buffers in pinned memory, minibatch i + 1 deposited in the
+    # buffer of slot (i + 1) % K before step i is launched, never before the step that last read that buffer is done
+    pinned[0].flat.copy_(feed[0].flat)
+    runner.prime(0)
+    for i in range(steps):
+      slot = i % slots
+      if i + 1 < steps:
+        runner.step_done(slot)  # the previous step(slot), K steps back, uploaded from pinned[(slot + 1) % K]
+        pinned[(i + 1) % slots].flat.copy_(feed[i + 1].flat)
+      losses.append(runner.step(slot).clone())
+    torch.cuda.synchronize()
+    return dict(losses=[float(l.item()) for l in losses], master=model._flat.master.detach().clone().cpu(),
+                buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()})
   if host:
     runner.upload(feed[0], 0)
   for i in range(steps):
@@ -208,12 +223,13 @@ def _run_feed(dev, slots, host, steps=7):
               buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()})
 
 
-@pytest.mark.parametrize('slots,host', [(3, False), (2, True), (3, True)])
+@pytest.mark.parametrize('slots,host', [(3, False), (2, True), (3, True), (2, 'graph'), (3, 'graph')])
 def test_input_slots_run_the_same_steps_as_one_static_input_set(slots, host):
   """GraphedTrainStep(input_slots=K): the step captured once per set of input buffers (a minibatch is consumed where the
   loader put it -- no device-to-device copy inside the step) trains exactly as the single-set step that copies every
   minibatch in: identical losses, weights and BatchNorm statistics over 7 different minibatches, also when the next
-  minibatch is uploaded from pinned host memory into its slot while the current step runs."""
+  minibatch is uploaded from pinned host memory into its slot while the current step runs -- by the event-ordered copy
+  stream of `upload`, or ('graph') by a host-to-device copy node inside the captured step itself (host_feed)."""
   dev = torch.device('cuda', 0)
   a, b = _run_feed(dev, 1, False), _run_feed(dev, slots, host)
   assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
