@@ -569,6 +569,16 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, unsigned ch
       }
     }
     const bf16x8_t sb[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+#ifdef MMT_ATTN_LAB_DS_SPLIT  // lab: dS = hi + lo, two bf16 MFMAs -- does bf16 rounding of dS explain the q / k error?
+    bf16x8_t sl[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x4 r0, r1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { r0[r] = s[2 * h2][r] - (float)sb[h2][r]; r1[r] = s[2 * h2 + 1][r] - (float)sb[h2][4 + r]; }
+      sl[h2] = pack8(r0, r1);
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) lgkm_wait<8>(); else lgkm_wait<0>();
@@ -579,6 +589,9 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, unsigned ch
       for (int j = 0; j < 4; ++j) {
         const int idx = g * 4 + j, ks = idx / FD, fd = idx % FD;
         o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_bf8(tlo[g][j], thi[g][j]), sb[ks], o[fd], 0, 0, 0);
+#ifdef MMT_ATTN_LAB_DS_SPLIT
+        o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_bf8(tlo[g][j], thi[g][j]), sl[ks], o[fd], 0, 0, 0);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -769,6 +782,16 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, unsigned c
     tissue(1);
     const bf16x8_t ab[2] = {pack8(pa[0], pa[1]), pack8(pa[2], pa[3])};
     const bf16x8_t sb[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+#ifdef MMT_ATTN_LAB_DS_SPLIT
+    bf16x8_t sl[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x4 r0, r1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { r0[r] = s[2 * h2][r] - (float)sb[h2][r]; r1[r] = s[2 * h2 + 1][r] - (float)sb[h2][4 + r]; }
+      sl[h2] = pack8(r0, r1);
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < 2 * NG; ++g) {
       if (g + 1 < 2 * NG) lgkm_wait<8>(); else lgkm_wait<0>();
@@ -780,6 +803,9 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, unsigned c
         const int idx = (g % NG) * 4 + j, ks = idx / FD, fd = idx % FD;
         if (g < NG) dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_bf8(tlo[g][j], thi[g][j]), ab[ks], dv[fd], 0, 0, 0);
         else dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_bf8(tlo[g][j], thi[g][j]), sb[ks], dk[fd], 0, 0, 0);
+#ifdef MMT_ATTN_LAB_DS_SPLIT
+        if (g >= NG) dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_bf8(tlo[g][j], thi[g][j]), sl[ks], dk[fd], 0, 0, 0);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -174,6 +174,9 @@ def run_cenet_fixture(R, name, fx):
     out['gradnorm/' + key] = np.float64(g.double().norm().item())
   bn_key = 'text_GU.%s.cg.batch_norm.running_mean' % mods[0]
   out['bn_running_mean_after'] = model.state_dict()[bn_key].numpy()
+  # r04: the other two BatchNorm buffers of that text head after the train-mode forward (model/model.py:736-750)
+  out['bn_running_var_after'] = model.state_dict()[bn_key.replace('running_mean', 'running_var')].numpy()
+  out['bn_num_batches_tracked_after'] = np.int64(model.state_dict()[bn_key.replace('running_mean', 'num_batches_tracked')].item())
 
   # --- oracle vs reference (fp32 oracle; fp64 oracle bounds the fp32 noise) ---
   cfg = dict(modalities=mods, expert_dims=expert_dims, vid_bert_params=arch_args(fx)['vid_bert_params'],

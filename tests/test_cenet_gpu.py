@@ -59,14 +59,27 @@ def test_cenet_matches_reference(name, pack):
   assert np.abs(emb['text_embds'].cpu().numpy() - g['eval_text_embds']).max() < 1e-4
   assert np.abs(emb['text_weights'].cpu().numpy() - g['eval_text_weights']).max() < 1e-5
   assert np.abs(emb['vid_weights'].cpu().numpy() - g['eval_vid_weights']).max() < 1e-6
-  # R@K from the native sims (reference's metric code restated in the oracle) vs the reference's R@K.
-  # One query changing rank bucket moves R@K by 100/n, so allow that much where sims gaps are below tol.
+  # R@K from the native sims (reference's metric code restated in the oracle) vs the reference's R@K: every query's rank
+  # must lie in the interval that the MEASURED similarity error allows around the reference's matrix (the rank-interval
+  # logic of tests/test_eval_loop_gpu.py), so R@K may differ from the reference's only by queries whose interval straddles K
+  # -- no blanket "one bucket flip" slack.
   n = sims.shape[0]
-  for key, fn in (('eval_t2v', O.t2v_metrics), ('eval_v2t', O.v2t_metrics)):
+  assert sims.shape == (n, n)  # one caption per video in these fixtures: the positives are the diagonal
+  err = float(np.abs(sims - g['eval_sims']).max()) + 1e-7
+  ref = g['eval_sims']
+  for key, fn, mat in (('eval_t2v', O.t2v_metrics, ref), ('eval_v2t', O.v2t_metrics, ref.T)):
     want = json.loads(str(g[key]))
     got = fn(sims)
-    for k in ('R1', 'R5', 'R10'):
-      assert abs(got[k] - want[k]) <= 100.0 / n + 1e-6, (key, k, got[k], want[k])
+    pos = np.diag(mat)
+    off = ~np.eye(n, dtype=bool)
+    lo = ((mat > pos[:, None] + 2 * err) & off).sum(1)    # competitors certainly above the positive
+    hi = ((mat >= pos[:, None] - 2 * err) & off).sum(1)   # ... possibly above it
+    for k, K in (('R1', 1), ('R5', 5), ('R10', 10)):
+      lowk, highk = 100.0 * float((hi < K).sum()) / n, 100.0 * float((lo < K).sum()) / n
+      assert lowk - 1e-6 <= got[k] <= highk + 1e-6, (key, k, got[k], lowk, highk)
+      assert lowk - 1e-6 <= want[k] <= highk + 1e-6, (key, k, want[k], lowk, highk)
+      if lowk == highk:
+        assert abs(got[k] - want[k]) < 1e-6, (key, k, got[k], want[k])
   # ---- train mode (dropout p = 0 in the fixtures), loss + backward ----
   model.train()
   loss_fn = MaxMarginRankingLoss(margin=0.05, fix_norm=True)
@@ -91,8 +104,11 @@ def test_cenet_matches_reference(name, pack):
     assert c > 0.995 and 0.97 < ratio < 1.03, (pname, c, ratio)
   c = _cos(subsample(t.grad), g['train_text_grad'])
   assert c > 0.995, ('text grad', c)
-  bn = model.state_dict()['text_GU.%s.cg.batch_norm.running_mean' % fx.meta['modalities'][0]].cpu().numpy()
-  assert np.abs(bn - g['bn_running_mean_after']).max() < 1e-4
+  sd_after = model.state_dict()
+  bn_key = 'text_GU.%s.cg.batch_norm.' % fx.meta['modalities'][0]
+  assert np.abs(sd_after[bn_key + 'running_mean'].cpu().numpy() - g['bn_running_mean_after']).max() < 1e-4
+  assert np.abs(sd_after[bn_key + 'running_var'].cpu().numpy() - g['bn_running_var_after']).max() < 1e-4
+  assert int(sd_after[bn_key + 'num_batches_tracked'].item()) == int(g['bn_num_batches_tracked_after'])
 
 
 @pytest.mark.parametrize('name', ['configA', 'configB'])
