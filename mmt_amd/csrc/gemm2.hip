@@ -585,7 +585,7 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   static_assert(CH % RG == 0 && (BM + BN) % (8 * WGM * WGN) == 0 && BM % (8 * WGM * WGN) == 0 && BN % (8 * WGM * WGN) == 0,
                 "tile geometry");
   constexpr size_t stage_bytes = (size_t)NS * (BM + BN) * BK * 2;
-  constexpr size_t epi_bytes = (size_t)(CH * (BN + 4) + RG * BN) * 4;
+  constexpr size_t epi_bytes = (size_t)(CH * (BN + 4) + RG * BN + MMT_GELU_LUT_N) * 4;  // image + column sums + GELU table
   constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static bool configured = false;
   if (!configured) {

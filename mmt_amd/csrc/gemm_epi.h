@@ -5,34 +5,31 @@
 #pragma once
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
+#include "gelu_lut.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// erf-form GELU (model/bert.py:37-53) via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the
-// bf16 rounding of the stored activations).  One exp serves Phi(x) and phi(x).
-__device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-  const float e = __expf(-0.5f * x * x);
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(t, p, 1.421413741f);
-  p = fmaf(t, p, -0.284496736f);
-  p = fmaf(t, p, 0.254829592f);
-  const float half_erfc = 0.5f * t * p * e;  // 0.5 * erfc(|x|/sqrt2)
-  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
-  pdf = 0.39894228040143268f * e;
+// erf-form GELU (model/bert.py:37-53) of a bf16-ROUNDED pre-activation, by table: the epilogues apply the activation to
+// the value they store (backward differentiates exactly what was applied), so its argument is one of 65536 bf16 numbers
+// and Phi(|x|) / gelu'(|x|) for the 2304 magnitudes in [2^-15, 8) are EXACT table entries (gelu_lut.h, double precision
+// rounded to fp32; smaller / larger magnitudes clamp: relative error < 1.3e-5 / none).  Per element: and, med3, LDS read,
+// sign fix, multiply -- the Abramowitz-Stegun form it replaces (|erf error| 1.5e-7) cost one v_rcp + one v_exp + a dozen
+// fma: ~45 of the ~110 issue slots of a 4-element sweep step, and the sweep is VALU-bound (tools/gemm2_budget.py r04).
+__device__ __forceinline__ float gelu_lut_abs(const float* __restrict__ lut, unsigned b) {
+  const unsigned mag = b & 0x7fffu;
+  const unsigned idx = min(max(mag, (unsigned)MMT_GELU_LUT_LO), (unsigned)(MMT_GELU_LUT_LO + MMT_GELU_LUT_N - 1)) - MMT_GELU_LUT_LO;
+  return lut[idx];
 }
-__device__ __forceinline__ float gelu2(float x) {
-  float c, p;
-  gelu_cdf_pdf(x, c, p);
-  return x * c;
+// x Phi(x) for x = the bf16 number with bits b (lut = the Phi table in LDS)
+__device__ __forceinline__ float gelu_lut(const float* __restrict__ lut, unsigned b) {
+  const float t = gelu_lut_abs(lut, b);
+  return bf2f((bf16_t)b) * ((b & 0x8000u) ? 1.0f - t : t);
 }
-__device__ __forceinline__ float gelu2_grad(float x) {
-  float c, p;
-  gelu_cdf_pdf(x, c, p);
-  return fmaf(x, p, c);
+// d/dx [x Phi(x)] (lut = the derivative table): g'(-x) = 1 - g'(x)
+__device__ __forceinline__ float gelu_grad_lut(const float* __restrict__ lut, unsigned b) {
+  const float t = gelu_lut_abs(lut, b);
+  return (b & 0x8000u) ? 1.0f - t : t;
 }
-
 
 // acc[MI][NJ]: wave (wm, wn) of a WGM x WGN grid owns rows wm * WTM + 32 i .. and columns wn * WTN + 32 j .. of the BM x BN
 // tile at (m0, n0).  PH: two wave groups (kg = 0 / 1) hold partial tiles over alternate K-steps; group 1 adds its partial
@@ -81,7 +78,8 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
   const int64_t off_c = rb * ldc + cb0, off_res = rb * epi.ldres + cb0, off_aux = rb * epi.ldaux + cb0,
                 off_o2 = rb * epi.ldout2 + cb0, off_dot = rb * epi.lddot + cb0;
   constexpr int SW = CH / RG, NPF = (BM / CH) * SW * NCB;
-  constexpr bool PF_FITS = NPF <= 8;  // (the 256-row lab tiles would spend > 64 registers on it: they keep the in-sweep loads)
+  constexpr bool PF_FITS = NPF <= 8;  // (256-row tiles would spend > 64 registers on it: they prefetch chunk by chunk, below)
+  constexpr bool PFC = !PF_FITS && SW * NCB <= 8;  // second operands of ONE 64-row chunk, fetched before its staging pass
   constexpr bool PF_RES = PF_FITS && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32);
   constexpr bool PF_AUX = PF_FITS && (EPI == MMT_EPI_DGELU || EPI == MMT_EPI_BF16);  // (BF16: dot_src, when dot_out is set)
   f32x4 pf_res[PF_RES ? NPF : 1];
@@ -116,7 +114,22 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
         }
       }
   }
+  // GELU tables: global -> registers now (the round trip overlaps the barrier and the first staging pass), -> LDS below
+  constexpr bool LUT = EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_DGELU;
+  constexpr int LUTN = (MMT_GELU_LUT_N + NT - 1) / NT;
+  float* lut = red + RG * BN;
+  float lutv[LUT ? LUTN : 1];
+  if constexpr (LUT) {
+    const float* src = EPI == MMT_EPI_BIAS_GELU ? g_gelu_lut_cdf : g_gelu_lut_dgelu;
+#pragma unroll
+    for (int i = 0; i < LUTN; ++i) lutv[i] = src[min(i * NT + tid, MMT_GELU_LUT_N - 1)];
+  }
   __syncthreads();  // every wave is done with the stage buffers
+  if constexpr (LUT) {
+#pragma unroll
+    for (int i = 0; i < LUTN; ++i)
+      if (i * NT + tid < MMT_GELU_LUT_N) lut[i * NT + tid] = lutv[i];
+  }
 #ifdef MMT_GEMM2_INSTR
   long long e_stage = 0, e_sweep = 0, tp = clock64();
   const long long e_t0 = tp;
@@ -126,6 +139,25 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
 #endif
 #pragma unroll
   for (int ch = 0; ch < BM / CH; ++ch) {
+    f32x4 pc_res[PFC && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32) ? SW * NCB : 1];
+    u32x2 pc_aux[PFC && EPI == MMT_EPI_DGELU ? SW * NCB : 1];
+    if constexpr (PFC && (EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32 || EPI == MMT_EPI_DGELU)) {
+#pragma unroll
+      for (int sw = 0; sw < SW; ++sw) {
+        const int dr = ch * CH + sw * RG;
+        const bool in = m0 + dr + rg < M;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          if constexpr (EPI == MMT_EPI_DGELU) {
+            const int64_t o = in ? off_aux + (int64_t)dr * epi.ldaux + cb * CB : (int64_t)(M - 1) * epi.ldaux + cb0 + cb * CB;
+            pc_aux[sw * NCB + cb] = *(const u32x2*)((const bf16_t*)epi.aux + o);
+          } else {
+            const int64_t o = in ? off_res + (int64_t)dr * epi.ldres + cb * CB : (int64_t)(M - 1) * epi.ldres + cb0 + cb * CB;
+            pc_res[sw * NCB + cb] = *(const f32x4*)(epi.res + o);
+          }
+        }
+      }
+    }
     if (kg == 0) {  // the fragment rows of this wave that belong to chunk ch (a wave tile may span several chunks)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -192,9 +224,8 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *(u32x2*)((bf16_t*)Cout + o_c) = o;
             // GELU of the bf16-rounded pre-activation: backward differentiates exactly what was applied
-            const float p0 = bf2f((bf16_t)(o[0] & 0xffff)), p1 = bf2f((bf16_t)(o[0] >> 16));
-            const float p2 = bf2f((bf16_t)(o[1] & 0xffff)), p3 = bf2f((bf16_t)(o[1] >> 16));
-            u32x2 g = {pack_bf2(gelu2(p0), gelu2(p1)), pack_bf2(gelu2(p2), gelu2(p3))};
+            u32x2 g = {pack_bf2(gelu_lut(lut, o[0] & 0xffff), gelu_lut(lut, o[0] >> 16)),
+                       pack_bf2(gelu_lut(lut, o[1] & 0xffff), gelu_lut(lut, o[1] >> 16))};
             *(u32x2*)((bf16_t*)epi.out2 + off_o2 + (int64_t)dr * epi.ldout2 + cb * CB) = g;
           } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
             if (epi.drop_thr16) {
@@ -207,16 +238,18 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
               for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
             }
             if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
+            else if constexpr (PFC) v += pc_res[(r0 / RG) * NCB + cb];
             else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
             *(f32x4*)((float*)Cout + o_c) = v;
           } else if constexpr (EPI == MMT_EPI_DGELU) {
             u32x2 a;
             if constexpr (PF_AUX) a = pf_aux[(ch * SW + r0 / RG) * NCB + cb];
+            else if constexpr (PFC) a = pc_aux[(r0 / RG) * NCB + cb];
             else a = *(const u32x2*)((const bf16_t*)epi.aux + off_aux + (int64_t)dr * epi.ldaux + cb * CB);
-            v[0] *= gelu2_grad(bf2f((bf16_t)(a[0] & 0xffff)));
-            v[1] *= gelu2_grad(bf2f((bf16_t)(a[0] >> 16)));
-            v[2] *= gelu2_grad(bf2f((bf16_t)(a[1] & 0xffff)));
-            v[3] *= gelu2_grad(bf2f((bf16_t)(a[1] >> 16)));
+            v[0] *= gelu_grad_lut(lut, a[0] & 0xffff);
+            v[1] *= gelu_grad_lut(lut, a[0] >> 16);
+            v[2] *= gelu_grad_lut(lut, a[1] & 0xffff);
+            v[3] *= gelu_grad_lut(lut, a[1] >> 16);
             u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *(u32x2*)((bf16_t*)Cout + o_c) = o;
             if (row < nrows) {
@@ -225,6 +258,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x16 (&acc)[BM / WGM / 32][
             }
           } else if constexpr (EPI == MMT_EPI_ADD_F32) {
             if constexpr (PF_RES) v += pf_res[(ch * SW + r0 / RG) * NCB + cb];
+            else if constexpr (PFC) v += pc_res[(r0 / RG) * NCB + cb];
             else v += *(const f32x4*)(epi.res + off_res + (int64_t)dr * epi.ldres + cb * CB);
             *(f32x4*)((float*)Cout + o_c) = v;
           } else {  // MMT_EPI_F32 / MMT_EPI_BIAS_F32
