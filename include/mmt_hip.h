@@ -212,6 +212,16 @@ int mmt_ln_bwd_slabs(const float* slabs, int splits, int64_t slab_stride, const 
                      const float* mean, const float* rstd, const float* gamma, float* dz, void* dy, float* partials,
                      int rows, int d, int drop_mode, const int32_t* row_index, uint32_t drop_key, uint32_t thr16,
                      float drop_scale, const uint32_t* seed_dev, void* stream);
+/* the same on a packed batch: n_rows_dev (nullable) = device count of live rows, rows = the capacity launched for */
+int mmt_splitk_ln_fwd_ex(const float* slabs, int splits, int64_t slab_stride, const float* bias, const float* res,
+                         const int32_t* res_rows, const int32_t* rowidx, const int32_t* row_index, int32_t* rowidx_out,
+                         uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
+                         const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean, float* rstd,
+                         int rows, int d, const int32_t* n_rows_dev, void* stream);
+int mmt_ln_bwd_slabs_ex(const float* slabs, int splits, int64_t slab_stride, const float* res, const float* z,
+                        const float* mean, const float* rstd, const float* gamma, float* dz, void* dy, float* partials,
+                        int rows, int d, int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
+                        uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream);
 
 /* LayerNorm backward.  drop_mode 0: none; 1: the LN input was dropout(y)+res -> dy(bf16) = mask*dz*scale;
  * 2: dropout followed the LN (embeddings) -> dout is masked first.  `partials` receives
@@ -429,24 +439,33 @@ int mmt_retrieval_ranks(const float* sims, const uint8_t* qmask, int NQ, int NV,
  *   mmt_ls_finish   : S[t,v] /= sum_m tw[t,m] vw[v,m] (0 -> 1e-5), in place.
  *   mmt_ls_diag     : diag_local[t] = S[t, r0+t] / den from the RAW numerators (before the division below).
  *   mmt_ls_counts_ex: rowcnt[t] +=, colcnt[c] += (both zeroed by the caller), un-normalised hinge sums per column block
- *                     loss_part[t, cb], cb < mmt_ls_col_blocks(n); finish = 1 also divides the raw numerators (one sweep).
+ *                     loss_part[t, cb], cb < mmt_ls_col_blocks(n); finish = 1 also divides the raw numerators (one sweep);
+ *                     finish = 2 divides on the fly and leaves S raw (mmt_ls_grad_ex(raw = 1) divides again: the row block
+ *                     is never rewritten).
  *   mmt_ls_counts   : the same with finish = 0.
  *   mmt_ls_grad     : G16[t,v] = bf16((dL/dS)/den) from the global counts; gs_part[t,cb,m] = sum over column block cb of
- *                     G' S vw[v,m].
+ *                     G' S vw[v,m].  mmt_ls_grad_ex: raw = 1 when S still holds the raw numerators.
+ *   vw_t (nullable, mmt_ls_counts_ex / mmt_ls_grad_ex): vw transposed to [M, n] -- coalesced 16-byte loads in the sweeps.
  * n, ld, ldg multiples of 4.
  *   mmt_ls_unfold   : dx[r,m,:] = w[r,m] P[r,m*d:], dw[r,m] = <x[r,m], P[r,m]> - gsub[r,m]. */
 int mmt_ls_fold_bf16(const float* x, const float* w, int R, int Rpad, int M, int d, void* out16, void* stream);
+/* dst[c, r] = src[r, c], bf16, rows and cols multiples of 128 (ld in elements, multiples of 8): K-contiguous operands for the
+ * NT GEMMs of the backward (V'^T, G'^T, T'^T). */
+int mmt_transpose_bf16(const void* src, int64_t ld_src, int rows, int cols, void* dst, int64_t ld_dst, void* stream);
 int mmt_ls_finish(float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, void* stream);
 int mmt_ls_col_blocks(int n);
 int mmt_ls_diag(const float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, int r0, float* diag_local,
                 void* stream);
-int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int M, int finish, int b, int n,
+int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const float* vw_t, int M, int finish, int b, int n,
                      int r0, float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part, void* stream);
 int mmt_ls_counts(const float* S, int64_t ld, const float* diag, int b, int n, int r0, float margin, int32_t* rowcnt,
                   int32_t* colcnt, float* loss_part, void* stream);
 int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const int32_t* rowcnt,
                 const int32_t* colcnt_total, int b, int n, int M, int r0, float margin, float inv_norm, void* G16,
                 int64_t ldg, float* gs_part, void* stream);
+int mmt_ls_grad_ex(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const float* vw_t, const int32_t* rowcnt,
+                   const int32_t* colcnt_total, int b, int n, int M, int r0, float margin, float inv_norm, void* G16,
+                   int64_t ldg, float* gs_part, int raw, void* stream);
 int mmt_ls_unfold(const float* P, int64_t ldp, const float* x, const float* w, const float* gsub, int R, int M, int d,
                   float* dx, float* dw, void* stream);
 

@@ -153,6 +153,10 @@ SIGNATURES = {
                                   c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mmt_ln_bwd_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp,
                                  c_u32, c_u32, c_f32, c_vp, c_vp]),
+    'mmt_splitk_ln_fwd_ex': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp,
+                                     c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'mmt_ln_bwd_slabs_ex': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp,
+                                    c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_ln_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                            c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_col_reduce': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -206,13 +210,16 @@ SIGNATURES = {
     'mmt_sims_eval': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_retrieval_ranks': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_fold_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mmt_transpose_bf16': (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp]),
     'mmt_ls_finish': (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mmt_ls_col_blocks': (c_int, [c_int]),
     'mmt_ls_diag': (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
-    'mmt_ls_counts_ex': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_ls_counts_ex': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_counts': (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'mmt_ls_grad': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64,
                             c_vp, c_vp]),
+    'mmt_ls_grad_ex': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64,
+                            c_vp, c_int, c_vp]),
     'mmt_ls_unfold': (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mmt_simloss_small_max_n': (c_int, []),
     'mmt_simloss_bwd_small': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_int, c_vp, c_vp,

@@ -37,6 +37,7 @@ struct Ws {
   // dy / dy2 / dhpre / dqkv are what the weight gradients of a layer read: two sets, used by even / odd layers, so that
   // the weight gradients of layer l may still be running (MMT_FORK_WGRAD) while layer l-1 produces its own
   char *dy_[2], *dy2_[2], *dhpre_[2], *dqkv_[2], *dctx;
+  float* kslab;  // split-K partial slabs of the main path's K = intermediate, N = hidden GEMMs (up to 4 x [R, d])
   size_t bytes;
 };
 
@@ -85,6 +86,7 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   // second set of the weight-gradient operands (odd layers under MMT_FORK_WGRAD), behind everything else: the buffers of
   // the serial path keep the addresses (and the cache-set relationships) they had before forking existed
   w->dy_[1] = take(R * d * 2); w->dy2_[1] = take(R * d * 2); w->dhpre_[1] = take(R * I * 2); w->dqkv_[1] = take(R * 3 * d * 2);
+  w->kslab = (float*)take((size_t)4 * R * d * 4);
   w->bytes = off;
 }
 
@@ -195,6 +197,22 @@ static int gemm_hidden(const Ws& w, int rows, int d, const void* A, int64_t lda,
   return mmt_gemm_nt_bf16(A, lda, B, ldb, C, ldc, rows, d, K, epi, e, nr, stream);
 }
 
+// K = intermediate, N = hidden on thousands of rows: one 128x64 tile per CU walks 48 dependent K-steps at the CU's
+// L2 -> LDS ingest limit (24 KB per step).  Split 2 ways over K on 128x128 tiles: the same block count, 2/3 of the operand
+// bytes per CU, and the partial slabs are summed by the LayerNorm pass that follows anyway (fwd: + bias, dropout,
+// residual; bwd: + residual gradient).  MMT_SPLITK_FFN = 10 * splits + wide (0: off).
+static int splitk_ffn_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("MMT_SPLITK_FFN");
+    mode = e ? atoi(e) : 0;
+  }
+  return mode;
+}
+static bool splitk_ffn(const Ws&, int rows, int d, int K) {
+  return splitk_ffn_mode() > 0 && rows >= 2048 && K >= 2048 && d <= 512;
+}
+
 extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last,
                                 int training, void* stream) {
   TRY(check_model(m, b));
@@ -262,11 +280,28 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
     e = {};
     e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
+    float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
+    if (splitk_ffn(w, rows, d, I)) {
+      const int mode = splitk_ffn_mode();
+      int sp = 0;
+      int64_t sstride = 0;
+      TRY(mmt_gemm_splitk_geometry(rows, d, I, mode / 10, &sp, &sstride));
+      {
+        ProbeScope probe(1, l == 0, stream);
+        TRY(mmt_gemm_nt_splitk_ex(L.g, I, P.w2, I, nullptr, d, rows, d, I, MMT_EPI_F32, nullptr, w.kslab, mode / 10, mode % 10,
+                                  b->n_rows_dev, 1, stream));
+      }
+      TRY(mmt_splitk_ln_fwd_ex(w.kslab, sp, sstride, P.b2, L.a32, nullptr, nullptr, b->row_index, nullptr,
+                               site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16,
+                               L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
+      hin32 = hout32;
+      hin16 = L.h16;
+      continue;
+    }
     {
       ProbeScope probe(1, l == 0, stream);
       TRY(gemm_hidden(w, rows, d, L.g, I, P.w2, I, L.z2, d, I, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
     }
-    float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
     TRY(mmt_ln_fwd(L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16, L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
     hin32 = hout32;
     hin16 = L.h16;
@@ -422,12 +457,24 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       TRY(mmt_wgrad_grouped(&gffn, side));
     }
     // --- BertIntermediate: dense(d->I) ---
+    if (splitk_ffn(w, rows, d, I)) {
+      const int mode = splitk_ffn_mode();
+      int sp = 0;
+      int64_t sstride = 0;
+      TRY(mmt_gemm_splitk_geometry(rows, d, I, mode / 10, &sp, &sstride));
+      TRY(mmt_gemm_nt_splitk_ex(dhpre, I, P.w1_t, I, nullptr, d, rows, d, I, MMT_EPI_F32, nullptr, w.kslab, mode / 10, mode % 10,
+                                nr, 1, stream));
+      // w.dz is read (residual gradient) and rewritten (LN1 input gradient) by the same lanes at the same elements
+      TRY(mmt_ln_bwd_slabs_ex(w.kslab, sp, sstride, w.dz, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1],
+                              rows, d, 1, nr, b->row_index, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+    } else {
     e = {};
     e.res = w.dz; e.ldres = d;
     TRY(gemm_hidden(w, rows, d, dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
     TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
+    }
     add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
     e = {};
     e.dot_src = L.ctx; e.lddot = d; e.dot_out = w.delta;  // rowsum(dO * O) per 64 columns, while dO is in registers

@@ -10,6 +10,8 @@
 //   backward  : P = G' V'  (b x Md),  Q = G'^T T'  (n x Md, reduce-scattered across ranks by the host),
 //               dT[t][m] = tw P,  dtw[t][m] = <T[t][m], P[t][m]> - gs[t][m]      (and the mirror for V)
 // Kernels here are the HBM-bound passes over the row block; the GEMMs reuse gemm2.hip / wgrad_grouped.
+#include <type_traits>
+
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 
@@ -43,26 +45,70 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
 static inline int ls_col_blocks(int n) { return (n + LS_CPB - 1) / LS_CPB; }
 extern "C" int mmt_ls_col_blocks(int n) { return n > 0 ? ls_col_blocks(n) : MMT_ERR_ARG; }
 
+// vwt (nullable): the video weights TRANSPOSED, [M, n] -- one coalesced 16-byte load per expert for the thread's four
+// columns.  From the [n, M] layout the same data is 4 * M four-byte loads per thread, each instruction spread over
+// 64 * M * 16 bytes: 28 load instructions x 56 cache lines per wave and chunk at M = 7 against 16 x 8 for the row block
+// itself -- the sweeps ran at 1.5 TB/s on that, not on HBM.
 template <int MM>
-__device__ __forceinline__ void ls_load_cols(const float* __restrict__ vw, const float* __restrict__ diag, int c0, int n, int M,
-                                             float (&vwc)[4][MM], f32x4& dg) {
+__device__ __forceinline__ void ls_load_cols(const float* __restrict__ vw, const float* __restrict__ vwt,
+                                             const float* __restrict__ diag, int c0, int n, int M, float (&vwc)[4][MM], f32x4& dg) {
+  if (vwt) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int m = 0; m < MM; ++m) {
+      const f32x4 v = m < M ? *(const f32x4*)(vwt + (int64_t)m * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < MM; ++m) vwc[j][m] = (m < M && c0 + j < n) ? vw[(int64_t)(c0 + j) * M + m] : 0.f;
+      for (int j = 0; j < 4; ++j) vwc[j][m] = v[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < MM; ++m) vwc[j][m] = (vw && m < M && c0 + j < n) ? vw[(int64_t)(c0 + j) * M + m] : 0.f;
+  }
   dg = diag ? *(const f32x4*)(diag + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// raw numerators -> similarities (MODE 1, in place) and / or pass 1 (MODE 2: counts; MODE 3: both in one sweep).
+// similarity = numerator / den as ONE v_rcp_f32 and ONE v_mul_f32 (inline asm: opaque to -ffast-math, so the two
+// instructions are the same wherever the similarity is recomputed -- the counting sweep, the gradient pass, the diagonal --
+// and the hinge decisions of the passes agree bit for bit).  <= 1.5 ulp from the correctly rounded quotient.
+// (v_rcp_f32 sits inside the asm with its wait state: the compiler's hazard recognizer does not look into inline asm, and a
+// VALU instruction reading a transcendental result one slot later reads the OLD register on gfx950)
+__device__ __forceinline__ float ls_rcp(float den) {
+  float r;
+  asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(den));
+  return r;
+}
+__device__ __forceinline__ float ls_quot(float num, float rcp_den) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(num), "v"(rcp_den));
+  return r;
+}
+// den(t, v) = sum_m tw[t][m] vw[v][m] as a fixed fma chain; 0 -> 1e-5 (model.py:816)
+template <int MM>
+__device__ __forceinline__ float ls_den(const float (&twr)[MM], const float (&vwj)[MM], bool* zero) {
+  float den = 0.f;
+#pragma unroll
+  for (int m = 0; m < MM; ++m) den = __builtin_fmaf(twr[m], vwj[m], den);
+  *zero = den == 0.f;
+  return *zero ? 1e-5f : den;
+}
+
+// raw numerators -> similarities (MODE 1, in place) and / or pass 1 (MODE 2: counts; MODE 3: both in one sweep; MODE 7: both,
+// but the similarities are NOT written back -- the gradient pass divides again (RAW) and the row block is never rewritten).
 //   rowcnt[t] = #{c != r : m - s_rr + s_rc > 0},  colcnt[c] += [m - s_cc + s_rc > 0],  loss_part[t][cb] = hinge sums
+// Two copies of the chunk body: CHECKED (rows beyond b and the diagonal element tested per row / per element) for the last
+// row block and for the few threads whose four columns cross the block's diagonal, and the plain one for everything else.
+// The r04 first version tested everywhere: 46 VALU instructions per element, 512 VGPRs + spills, one wave per SIMD, and
+// 1.5 TB/s.  Row counts are wave ballots (v_cmp + s_bcnt1: the scalar unit counts, nothing to reduce at the end).
 template <int TR, int MM, int MODE>
-__global__ __launch_bounds__(256) void ls_sweep_kernel(float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
-                                                       const float* __restrict__ tw, const float* __restrict__ vw, int b, int n,
-                                                       int M, int r0, float margin, int32_t* __restrict__ rowcnt,
-                                                       int32_t* __restrict__ colcnt, float* __restrict__ loss_part) {
-  constexpr bool FIN = MODE & 1, CNT = MODE & 2;
+__global__ __launch_bounds__(256, 2) void ls_sweep_kernel(float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
+                                                          const float* __restrict__ tw, const float* __restrict__ vw,
+                                                          const float* __restrict__ vwt, int b, int n,
+                                                          int M, int r0, float margin, int32_t* __restrict__ rowcnt,
+                                                          int32_t* __restrict__ colcnt, float* __restrict__ loss_part) {
+  constexpr bool FIN = MODE & 1, CNT = MODE & 2, STORE = !(MODE & 4);
   __shared__ float tws[TR][MM];
-  __shared__ float srr_s[TR];
+  __shared__ float ms_s[TR];  // margin - s_rr
   __shared__ float redf[4][TR];
   __shared__ int redi[4][TR];
   const int cb = blockIdx.x, ncb = gridDim.x, t0 = blockIdx.y * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,50 +118,64 @@ __global__ __launch_bounds__(256) void ls_sweep_kernel(float* __restrict__ S, in
       tws[r][m] = (t0 + r < b && m < M) ? tw[(int64_t)(t0 + r) * M + m] : 0.f;
     }
   }
-  if (CNT && tid < TR) srr_s[tid] = t0 + tid < b ? diag[r0 + t0 + tid] : 0.f;
+  if (CNT && tid < TR) ms_s[tid] = t0 + tid < b ? margin - diag[r0 + t0 + tid] : 0.f;
   __syncthreads();
   float acc[TR];
-  int cnt[TR];
+  int cnt[TR];  // wave totals (ballot counts: the same value in every lane)
 #pragma unroll
   for (int r = 0; r < TR; ++r) { acc[r] = 0.f; cnt[r] = 0; }
+  const bool full = t0 + TR <= b;
+  const int rg0 = r0 + t0;  // global column of the block's first diagonal element
   const int c_end = min(n, (cb + 1) * LS_CPB);
   for (int c0 = cb * LS_CPB + tid * 4; c0 < c_end; c0 += LS_CHUNK) {
+    // (the row data in LDS is loop-invariant: without this the compiler hoists all TR x MM of it into VGPRs and spills)
+    asm volatile("" ::: "memory");
     float vwc[4][MM];
     f32x4 dg;
-    ls_load_cols<MM>(FIN ? vw : nullptr, CNT ? diag : nullptr, c0, FIN ? n : 0, M, vwc, dg);
+    ls_load_cols<MM>(FIN ? vw : nullptr, FIN ? vwt : nullptr, CNT ? diag : nullptr, c0, n, M, vwc, dg);
     f32x4 sv[TR];
 #pragma unroll
-    for (int r = 0; r < TR; ++r)
-      sv[r] = t0 + r < b ? *(const f32x4*)(S + (int64_t)(t0 + r) * ld + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < TR; ++r)  // (rows beyond b re-read row b - 1; nothing of them is kept)
+      sv[r] = *(const f32x4*)(S + (int64_t)min(t0 + r, b - 1) * ld + c0);
+    float md[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) md[j] = margin - dg[j];
     int cc[4] = {0, 0, 0, 0};
+    auto rows = [&](auto checked_t) {
+      constexpr bool CHECKED = decltype(checked_t)::value;
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
-      if (t0 + r >= b) continue;  // (block-uniform)
-      f32x4 s = sv[r];
-      if constexpr (FIN) {
+      for (int r = 0; r < TR; ++r) {
+        if (CHECKED && t0 + r >= b) continue;  // (block-uniform)
+        f32x4 sr = sv[r];
+        if constexpr (FIN) {
+          float twr[MM];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float den = 0.f;
+          for (int m = 0; m < MM; ++m) twr[m] = tws[r][m];
 #pragma unroll
-          for (int m = 0; m < MM; ++m) den += tws[r][m] * vwc[j][m];
-          if (den == 0.f) den = 1e-5f;
-          s[j] /= den;
+          for (int j = 0; j < 4; ++j) {
+            bool zero;
+            const float den = ls_den<MM>(twr, vwc[j], &zero);
+            sr[j] = ls_quot(sr[j], ls_rcp(den));
+          }
+          if constexpr (STORE) *(f32x4*)(S + (int64_t)(t0 + r) * ld + c0) = sr;
         }
-        *(f32x4*)(S + (int64_t)(t0 + r) * ld + c0) = s;
-      }
-      if constexpr (CNT) {
-        const int rg = r0 + t0 + r;
-        const float srr = srr_s[r];
+        if constexpr (CNT) {
+          const float ms = ms_s[r];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (c0 + j == rg) continue;
-          const float h1 = margin - srr + s[j], h2 = margin - dg[j] + s[j];
-          acc[r] += fmaxf(h1, 0.f) + fmaxf(h2, 0.f);
-          cnt[r] += h1 > 0.f;
-          cc[j] += h2 > 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const bool skip = CHECKED && c0 + j == rg0 + r;  // the diagonal element carries no hinge
+            const float h1 = ms + sr[j], h2 = md[j] + sr[j];
+            const bool p1 = h1 > 0.f && !skip, p2 = h2 > 0.f && !skip;
+            acc[r] += (p1 ? h1 : 0.f) + (p2 ? h2 : 0.f);
+            cnt[r] += __builtin_popcountll(__ballot(p1));  // (the branch below is wave-uniform: every lane is here)
+            cc[j] += p2;
+          }
         }
       }
-    }
+    };
+    // (wave-uniform choice: one lane crossing the diagonal sends its whole wave through the checked copy)
+    if (full && !(CNT && __ballot(c0 < rg0 + TR && c0 + 4 > rg0))) rows(std::false_type{});
+    else rows(std::true_type{});
     if constexpr (CNT) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -126,9 +186,7 @@ __global__ __launch_bounds__(256) void ls_sweep_kernel(float* __restrict__ S, in
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
       const float a = wave_sum(acc[r]);
-      int c = cnt[r];
-      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-      if (lane == 0) { redf[wave][r] = a; redi[wave][r] = c; }
+      if (lane == 0) { redf[wave][r] = a; redi[wave][r] = cnt[r]; }
     }
     __syncthreads();
     if (tid < TR && t0 + tid < b) {
@@ -145,21 +203,24 @@ __global__ __launch_bounds__(256) void ls_diag_kernel(const float* __restrict__ 
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= b) return;
   float den = 0.f;
-  for (int m = 0; m < M; ++m) den += tw[(int64_t)t * M + m] * vw[(int64_t)(r0 + t) * M + m];
+  for (int m = 0; m < M; ++m) den = __builtin_fmaf(tw[(int64_t)t * M + m], vw[(int64_t)(r0 + t) * M + m], den);
   if (den == 0.f) den = 1e-5f;
-  diag_local[t] = S[(int64_t)t * ld + r0 + t] / den;
+  diag_local[t] = ls_quot(S[(int64_t)t * ld + r0 + t], ls_rcp(den));
 }
 
 // pass 2: G'[t][v] (bf16) = g(t, v) / den(t, v) with g = ((h1 > 0) + (h2 > 0)) / norm off the diagonal and
 // -(rowcnt[t] + colcnt[r]) / norm on it; gs_part[t][cb][m] = sum over the block's columns of G'[t][v] S[t][v] vw[v][m]
-template <int TR, int MM>
-__global__ __launch_bounds__(256) void ls_grad2_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
-                                                       const float* __restrict__ tw, const float* __restrict__ vw,
-                                                       const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ colcnt,
-                                                       int b, int n, int M, int r0, float margin, float inv_norm,
-                                                       bf16_t* __restrict__ G16, int64_t ldg, float* __restrict__ gs_part) {
+// RAW: S holds the raw numerators (mmt_ls_counts_ex(finish = 2)); the division is redone here, bit for bit (ls_quot).
+// Checked / plain copies of the chunk body as in the sweep above.
+template <int TR, int MM, bool RAW>
+__global__ __launch_bounds__(256, 2) void ls_grad2_kernel(const float* __restrict__ S, int64_t ld, const float* __restrict__ diag,
+                                                          const float* __restrict__ tw, const float* __restrict__ vw,
+                                                          const float* __restrict__ vwt,
+                                                          const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ colcnt,
+                                                          int b, int n, int M, int r0, float margin, float inv_norm,
+                                                          bf16_t* __restrict__ G16, int64_t ldg, float* __restrict__ gs_part) {
   __shared__ float tws[TR][MM];
-  __shared__ float srr_s[TR], gdiag_s[TR];
+  __shared__ float ms_s[TR], gdiag_s[TR];
   __shared__ float red[4][TR][MM];
   const int cb = blockIdx.x, ncb = gridDim.x, t0 = blockIdx.y * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < TR * MM; e += 256) {
@@ -167,7 +228,7 @@ __global__ __launch_bounds__(256) void ls_grad2_kernel(const float* __restrict__
     tws[r][m] = (t0 + r < b && m < M) ? tw[(int64_t)(t0 + r) * M + m] : 0.f;
   }
   if (tid < TR && t0 + tid < b) {
-    srr_s[tid] = diag[r0 + t0 + tid];
+    ms_s[tid] = margin - diag[r0 + t0 + tid];
     gdiag_s[tid] = -(float)(rowcnt[t0 + tid] + colcnt[r0 + t0 + tid]) * inv_norm;
   }
   __syncthreads();
@@ -176,43 +237,54 @@ __global__ __launch_bounds__(256) void ls_grad2_kernel(const float* __restrict__
   for (int r = 0; r < TR; ++r)
 #pragma unroll
     for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+  const bool full = t0 + TR <= b;
+  const int rg0 = r0 + t0;
   const int c_end = min(n, (cb + 1) * LS_CPB);
   for (int c0 = cb * LS_CPB + tid * 4; c0 < c_end; c0 += LS_CHUNK) {
+    // (the row data in LDS is loop-invariant: without this the compiler hoists all TR x MM of it into VGPRs and spills)
+    asm volatile("" ::: "memory");
     float vwc[4][MM];
     f32x4 dg;
-    ls_load_cols<MM>(vw, diag, c0, n, M, vwc, dg);
+    ls_load_cols<MM>(vw, vwt, diag, c0, n, M, vwc, dg);
     f32x4 sv[TR];
 #pragma unroll
-    for (int r = 0; r < TR; ++r)
-      sv[r] = t0 + r < b ? *(const f32x4*)(S + (int64_t)(t0 + r) * ld + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < TR; ++r) sv[r] = *(const f32x4*)(S + (int64_t)min(t0 + r, b - 1) * ld + c0);
+    float md[4];
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
-      if (t0 + r >= b) continue;  // (block-uniform)
-      const int rg = r0 + t0 + r;
-      const float srr = srr_s[r];
-      u32x2 o;
-      float gpb[4];
+    for (int j = 0; j < 4; ++j) md[j] = margin - dg[j];
+    auto rows = [&](auto checked_t) {
+      constexpr bool CHECKED = decltype(checked_t)::value;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float s = sv[r][j];
-        float g;
-        if (c0 + j == rg) g = gdiag_s[r];
-        else g = ((margin - srr + s > 0.f ? 1.f : 0.f) + (margin - dg[j] + s > 0.f ? 1.f : 0.f)) * inv_norm;
-        float den = 0.f;
+      for (int r = 0; r < TR; ++r) {
+        if (CHECKED && t0 + r >= b) continue;  // (block-uniform)
+        const float ms = ms_s[r];
+        float twr[MM];
 #pragma unroll
-        for (int m = 0; m < MM; ++m) den += tws[r][m] * vwc[j][m];
-        const bool zero = den == 0.f;
-        if (zero) den = 1e-5f;
-        const bf16_t gb = f2bf(g / den);
-        gpb[j] = zero ? 0.f : bf2f(gb) * s;  // the 1e-5 branch carries no normaliser gradient (model.py:816)
-        if (j & 1) o[j >> 1] |= (unsigned)gb << 16; else o[j >> 1] = gb;
+        for (int m = 0; m < MM; ++m) twr[m] = tws[r][m];
+        float gq[4], gpb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bool zero;
+          const float rden = ls_rcp(ls_den<MM>(twr, vwc[j], &zero));
+          const float sj = RAW ? ls_quot(sv[r][j], rden) : sv[r][j];
+          float g = ((ms + sj > 0.f) ? inv_norm : 0.f) + ((md[j] + sj > 0.f) ? inv_norm : 0.f);
+          if (CHECKED && c0 + j == rg0 + r) g = gdiag_s[r];
+          gq[j] = ls_quot(g, rden);
+          // the 1e-5 branch carries no normaliser gradient (model.py:816)
+          gpb[j] = zero ? 0.f : sj;
+        }
+        const u32x2 o = {pack_bf2(gq[0], gq[1]), pack_bf2(gq[2], gq[3])};
+        *(u32x2*)(G16 + (int64_t)(t0 + r) * ldg + c0) = o;
+        gpb[0] *= __uint_as_float(o[0] << 16); gpb[1] *= __uint_as_float(o[0] & 0xffff0000u);
+        gpb[2] *= __uint_as_float(o[1] << 16); gpb[3] *= __uint_as_float(o[1] & 0xffff0000u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MM; ++m) acc[r][m] += gpb[j] * vwc[j][m];
       }
-      *(u32x2*)(G16 + (int64_t)(t0 + r) * ldg + c0) = o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] += gpb[j] * vwc[j][m];
-    }
+    };
+    if (full && !__ballot(c0 < rg0 + TR && c0 + 4 > rg0)) rows(std::false_type{});
+    else rows(std::true_type{});
   }
 #pragma unroll
   for (int r = 0; r < TR; ++r)
@@ -258,21 +330,21 @@ extern "C" int mmt_ls_fold_bf16(const float* x, const float* w, int R, int Rpad,
 }
 
 template <int MODE>
-static int ls_sweep(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int b, int n, int M, int r0,
+static int ls_sweep(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const float* vwt, int b, int n, int M, int r0,
                     float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part, hipStream_t s) {
   if ((n & 3) || (ld & 3) || ((uintptr_t)S & 15)) return MMT_ERR_ALIGN;
   if (M <= 8)
-    hipLaunchKernelGGL((ls_sweep_kernel<16, 8, MODE>), dim3(ls_col_blocks(n), (b + 15) / 16), dim3(256), 0, s, S, ld, diag, tw, vw, b, n,
+    hipLaunchKernelGGL((ls_sweep_kernel<16, 8, MODE>), dim3(ls_col_blocks(n), (b + 15) / 16), dim3(256), 0, s, S, ld, diag, tw, vw, vwt, b, n,
                        M, r0, margin, rowcnt, colcnt, loss_part);
   else
-    hipLaunchKernelGGL((ls_sweep_kernel<8, 16, MODE>), dim3(ls_col_blocks(n), (b + 7) / 8), dim3(256), 0, s, S, ld, diag, tw, vw, b, n,
+    hipLaunchKernelGGL((ls_sweep_kernel<8, 16, MODE>), dim3(ls_col_blocks(n), (b + 7) / 8), dim3(256), 0, s, S, ld, diag, tw, vw, vwt, b, n,
                        M, r0, margin, rowcnt, colcnt, loss_part);
   return (int)hipGetLastError();
 }
 
 extern "C" int mmt_ls_finish(float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, void* stream) {
   if (!S || !tw || !vw || b <= 0 || n <= 0 || M <= 0 || M > LS_MAXM) return MMT_ERR_ARG;
-  return ls_sweep<1>(S, ld, nullptr, tw, vw, b, n, M, 0, 0.f, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  return ls_sweep<1>(S, ld, nullptr, tw, vw, nullptr, b, n, M, 0, 0.f, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int mmt_ls_diag(const float* S, int64_t ld, const float* tw, const float* vw, int b, int n, int M, int r0,
@@ -282,36 +354,90 @@ extern "C" int mmt_ls_diag(const float* S, int64_t ld, const float* tw, const fl
   return (int)hipGetLastError();
 }
 
+// vw_t (nullable): the video weights transposed, [M, n], 16-byte aligned -- the layout the sweeps read fastest.
 // rowcnt and colcnt must be zero on entry (they accumulate); loss_part [b, mmt_ls_col_blocks(n)] holds the UN-normalised
 // hinge sums of the local rows per column block.  finish = 1: S holds the raw numerators of the similarity GEMM on entry
 // and the similarities on return (tw / vw / M needed) -- the division and pass 1 in ONE sweep over the block.
-extern "C" int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, int M, int finish,
+extern "C" int mmt_ls_counts_ex(float* S, int64_t ld, const float* diag, const float* tw, const float* vw, const float* vw_t,
+                                int M, int finish,
                                 int b, int n, int r0, float margin, int32_t* rowcnt, int32_t* colcnt, float* loss_part,
                                 void* stream) {
   if (!S || !diag || !rowcnt || !colcnt || !loss_part || b <= 0 || n <= 1 || r0 < 0 || r0 + b > n) return MMT_ERR_ARG;
   if (finish && (!tw || !vw || M <= 0 || M > LS_MAXM)) return MMT_ERR_ARG;
-  if (finish) return ls_sweep<3>(S, ld, diag, tw, vw, b, n, M, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
-  return ls_sweep<2>(S, ld, diag, nullptr, nullptr, b, n, 0, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
+  if (finish == 2) return ls_sweep<7>(S, ld, diag, tw, vw, vw_t, b, n, M, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
+  if (finish) return ls_sweep<3>(S, ld, diag, tw, vw, vw_t, b, n, M, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
+  return ls_sweep<2>(S, ld, diag, nullptr, nullptr, nullptr, b, n, 0, r0, margin, rowcnt, colcnt, loss_part, (hipStream_t)stream);
 }
 extern "C" int mmt_ls_counts(const float* S, int64_t ld, const float* diag, int b, int n, int r0, float margin,
                              int32_t* rowcnt, int32_t* colcnt, float* loss_part, void* stream) {
-  return mmt_ls_counts_ex((float*)S, ld, diag, nullptr, nullptr, 0, 0, b, n, r0, margin, rowcnt, colcnt, loss_part, stream);
+  return mmt_ls_counts_ex((float*)S, ld, diag, nullptr, nullptr, nullptr, 0, 0, b, n, r0, margin, rowcnt, colcnt, loss_part, stream);
 }
 
 // gs_part: [b, mmt_ls_col_blocks(n), M] partial sums (the caller adds the column blocks up, in order)
-extern "C" int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw,
-                           const int32_t* rowcnt, const int32_t* colcnt_total, int b, int n, int M, int r0, float margin,
-                           float inv_norm, void* G16, int64_t ldg, float* gs_part, void* stream) {
+extern "C" int mmt_ls_grad_ex(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw,
+                              const float* vw_t, const int32_t* rowcnt, const int32_t* colcnt_total, int b, int n, int M, int r0, float margin,
+                              float inv_norm, void* G16, int64_t ldg, float* gs_part, int raw, void* stream) {
   if (!S || !diag || !tw || !vw || !rowcnt || !colcnt_total || !G16 || !gs_part || b <= 0 || n <= 1 || M <= 0 || M > LS_MAXM)
     return MMT_ERR_ARG;
   if ((n & 3) || (ld & 3) || (ldg & 3) || ((uintptr_t)S & 15) || ((uintptr_t)G16 & 7)) return MMT_ERR_ALIGN;
-  if (M <= 8)
-    hipLaunchKernelGGL((ls_grad2_kernel<16, 8>), dim3(ls_col_blocks(n), (b + 15) / 16), dim3(256), 0, (hipStream_t)stream, S, ld, diag, tw,
-                       vw, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs_part);
-  else
-    hipLaunchKernelGGL((ls_grad2_kernel<8, 16>), dim3(ls_col_blocks(n), (b + 7) / 8), dim3(256), 0, (hipStream_t)stream, S, ld, diag, tw,
-                       vw, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs_part);
+#define LS_GRAD(TRR, MMM, RW)                                                                                                  \
+  hipLaunchKernelGGL((ls_grad2_kernel<TRR, MMM, RW>), dim3(ls_col_blocks(n), (b + TRR - 1) / TRR), dim3(256), 0, (hipStream_t)stream, \
+                     S, ld, diag, tw, vw, vw_t, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, (bf16_t*)G16, ldg, gs_part)
+  // (TR x MM gs accumulators per thread: 8 rows x 8 experts, or 4 x 16, keep two blocks per CU without spills)
+  if (M <= 8) { if (raw) LS_GRAD(8, 8, true); else LS_GRAD(8, 8, false); }
+  else { if (raw) LS_GRAD(4, 16, true); else LS_GRAD(4, 16, false); }
+#undef LS_GRAD
   return (int)hipGetLastError();
+}
+
+// dst[c][r] = src[r][c] for bf16 matrices (rows, cols multiples of 128): the backward GEMMs of the row block are NT GEMMs
+// on the 256x256 eight-phase kernel (gemm3.hip), which wants both operands K-contiguous -- V'^T for P = G' V', and G'^T,
+// T'^T for Q = G'^T T'.  128 x 128 tiles; a thread transposes 2 x 8 patches in registers (dword = two rows of one column),
+// so LDS sees 4-byte accesses only; global reads are 128-byte, writes 256-byte row segments.  HBM-bound: 2 bytes read +
+// 2 written per element (torch's .t().contiguous() ran at 1.0 TB/s on the 0.94 GB V' matrix: 1.87 ms).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int64_t lds_, bf16_t* __restrict__ dst,
+                                                             int64_t ldd) {
+  __shared__ uint32_t tile[128][65];
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
+  u32x4 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pid = i * 256 + t, cg = (pid & 7) + 8 * ((pid >> 6) & 1), p = ((pid >> 3) & 7) + 8 * (pid >> 7);
+    const bf16_t* s0 = src + (r0 + 2 * p) * lds_ + c0 + 8 * cg;
+    a[i] = *(const u32x4*)s0;
+    b[i] = *(const u32x4*)(s0 + lds_);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pid = i * 256 + t, cg = (pid & 7) + 8 * ((pid >> 6) & 1), p = ((pid >> 3) & 7) + 8 * (pid >> 7);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tile[8 * cg + 2 * k][p] = (a[i][k] & 0xffffu) | (b[i][k] << 16);
+      tile[8 * cg + 2 * k + 1][p] = (a[i][k] >> 16) | (b[i][k] & 0xffff0000u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int id = i * 256 + t, q = id & 15, c = id >> 4;
+    const u32x4 v = {tile[c][4 * q], tile[c][4 * q + 1], tile[c][4 * q + 2], tile[c][4 * q + 3]};
+    *(u32x4*)(dst + (c0 + c) * ldd + r0 + 8 * q) = v;
+  }
+}
+
+extern "C" int mmt_transpose_bf16(const void* src, int64_t ld_src, int rows, int cols, void* dst, int64_t ld_dst, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (rows & 127) || (cols & 127) || ld_src < cols || ld_dst < rows) return MMT_ERR_ARG;
+  if ((ld_src & 7) || (ld_dst & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return MMT_ERR_ALIGN;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cols / 128, rows / 128), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     ld_src, (bf16_t*)dst, ld_dst);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mmt_ls_grad(const float* S, int64_t ld, const float* diag, const float* tw, const float* vw,
+                           const int32_t* rowcnt, const int32_t* colcnt_total, int b, int n, int M, int r0, float margin,
+                           float inv_norm, void* G16, int64_t ldg, float* gs_part, void* stream) {
+  return mmt_ls_grad_ex(S, ld, diag, tw, vw, nullptr, rowcnt, colcnt_total, b, n, M, r0, margin, inv_norm, G16, ldg, gs_part, 0, stream);
 }
 
 extern "C" int mmt_ls_unfold(const float* P, int64_t ldp, const float* x, const float* w, const float* gsub, int R, int M,

@@ -86,11 +86,12 @@ struct SplitkLnArgs {
   float* z_out; const float *gamma, *beta; float eps;
   float* h32; bf16_t* h16; float *mean, *rstd;
   int rows, d;
+  const int32_t* n_rows_dev;  // (nullable) live rows of a packed batch
 };
 __global__ __launch_bounds__(256) void splitk_ln_fwd_kernel(SplitkLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
-  if (row >= a.rows) return;
+  if (row >= a.rows || (a.n_rows_dev && row >= *a.n_rows_dev)) return;
   const int d = a.d, nch = d >> 8;
   const int64_t rrow = a.res_rows ? a.res_rows[row] : row;
   int orow;
@@ -150,17 +151,25 @@ __global__ __launch_bounds__(256) void splitk_ln_fwd_kernel(SplitkLnArgs a) {
     }
 }
 
+extern "C" int mmt_splitk_ln_fwd_ex(const float* slabs, int splits, int64_t slab_stride, const float* bias, const float* res,
+                                 const int32_t* res_rows, const int32_t* rowidx, const int32_t* row_index, int32_t* rowidx_out,
+                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
+                                 const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean,
+                                 float* rstd, int rows, int d, const int32_t* n_rows_dev, void* stream) {
+  if (!slabs || splits <= 0 || splits > 16 || !bias || !res || !z_out || !gamma || !beta || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  SplitkLnArgs a = {slabs, splits, slab_stride, bias, res, res_rows, rowidx, row_index, rowidx_out, drop_key, thr16, drop_scale,
+                    seed_dev, z_out, gamma, beta, eps, h32, (bf16_t*)h16, mean, rstd, rows, d, n_rows_dev};
+  hipLaunchKernelGGL(splitk_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 extern "C" int mmt_splitk_ln_fwd(const float* slabs, int splits, int64_t slab_stride, const float* bias, const float* res,
                                  const int32_t* res_rows, const int32_t* rowidx, const int32_t* row_index, int32_t* rowidx_out,
                                  uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, float* z_out,
                                  const float* gamma, const float* beta, float eps, float* h32, void* h16, float* mean,
                                  float* rstd, int rows, int d, void* stream) {
-  if (!slabs || splits <= 0 || splits > 16 || !bias || !res || !z_out || !gamma || !beta || !mean || !rstd || rows <= 0) return MMT_ERR_ARG;
-  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
-  SplitkLnArgs a = {slabs, splits, slab_stride, bias, res, res_rows, rowidx, row_index, rowidx_out, drop_key, thr16, drop_scale,
-                    seed_dev, z_out, gamma, beta, eps, h32, (bf16_t*)h16, mean, rstd, rows, d};
-  hipLaunchKernelGGL(splitk_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return mmt_splitk_ln_fwd_ex(slabs, splits, slab_stride, bias, res, res_rows, rowidx, row_index, rowidx_out, drop_key, thr16,
+                              drop_scale, seed_dev, z_out, gamma, beta, eps, h32, h16, mean, rstd, rows, d, nullptr, stream);
 }
 
 // DROP: 0 none, 1 dropout applied BEFORE the LN input (dy = mask*dz*scale), 2 dropout applied AFTER the
@@ -666,13 +675,20 @@ extern "C" int mmt_ln_bwd(const float* dout, const float* z, const float* mean, 
 
 // the same with the incoming gradient given as split-K partial slabs (+ an optional residual gradient): dout = sum_s
 // slabs[s] + res -- the ADD_F32 epilogue of the input-gradient GEMM in front of this LayerNorm, without its own launch
+extern "C" int mmt_ln_bwd_slabs_ex(const float* slabs, int splits, int64_t slab_stride, const float* res, const float* z,
+                                const float* mean, const float* rstd, const float* gamma, float* dz, void* dy,
+                                float* partials, int rows, int d, int drop_mode, const int32_t* n_rows_dev, const int32_t* row_index,
+                                uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
+  if (splits <= 0 || splits > 16) return MMT_ERR_ARG;
+  return ln_bwd_impl(slabs, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, n_rows_dev, row_index, drop_key, thr16,
+                     drop_scale, seed_dev, splits, slab_stride, res, stream);
+}
 extern "C" int mmt_ln_bwd_slabs(const float* slabs, int splits, int64_t slab_stride, const float* res, const float* z,
                                 const float* mean, const float* rstd, const float* gamma, float* dz, void* dy,
                                 float* partials, int rows, int d, int drop_mode, const int32_t* row_index,
                                 uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev, void* stream) {
-  if (splits <= 0 || splits > 16) return MMT_ERR_ARG;
-  return ln_bwd_impl(slabs, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, nullptr, row_index, drop_key, thr16,
-                     drop_scale, seed_dev, splits, slab_stride, res, stream);
+  return mmt_ln_bwd_slabs_ex(slabs, splits, slab_stride, res, z, mean, rstd, gamma, dz, dy, partials, rows, d, drop_mode, nullptr,
+                             row_index, drop_key, thr16, drop_scale, seed_dev, stream);
 }
 
 extern "C" int mmt_col_reduce(const float* partials, int nblocks, int nvec, int d, float* out0, float* out1,

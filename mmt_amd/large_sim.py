@@ -13,6 +13,8 @@ owns the text ROWS r0..r0+b: its b texts against all n (all-gathered) videos,
 The maths is phase-structured (`phase_*`) so that the collectives sit between plain function calls; `ShardedSimLoss`
 wires the phases to torch.distributed (RCCL) and degenerates to a single row block without a process group.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,11 +26,22 @@ def _f32(x):
   return x.detach().contiguous().float()
 
 
+def _transposed(L, x):
+  """x [r, c] bf16 (r, c multiples of 128) -> x^T [c, r], contiguous."""
+  r, c = x.shape
+  out = torch.empty(c, r, device=x.device, dtype=torch.bfloat16)
+  check(L.mmt_transpose_bf16(ops._p(x), c, r, c, ops._p(out), r, ops._stream()), 'mmt_transpose_bf16')
+  return out
+
+
 class RowBlock:
   """State of one rank's row block between phases."""
 
-  def __init__(self, txt, tw, vid_all, vw_all, r0, margin, fix_norm=True):
-    """txt [b, M, d], tw [b, M]: local texts; vid_all [n, M, d], vw_all [n, M]: every rank's videos (rank order)."""
+  def __init__(self, txt, tw, vid_all, vw_all, r0, margin, fix_norm=True, keep_similarity=False):
+    """txt [b, M, d], tw [b, M]: local texts; vid_all [n, M, d], vw_all [n, M]: every rank's videos (rank order).
+    keep_similarity: `self.S` holds the similarities after phase_counts (an extra write of the row block); by default it keeps
+    the raw numerators of the GEMM and both passes divide on the fly (`similarity()` returns a finished copy)."""
+    self.keep_similarity = bool(keep_similarity)
     self.txt, self.tw, self.vid_all, self.vw_all = _f32(txt), _f32(tw), _f32(vid_all), _f32(vw_all)
     self.b, self.m, self.d = self.txt.shape
     self.n = self.vid_all.shape[0]
@@ -38,6 +51,7 @@ class RowBlock:
     self.norm = 2.0 * self.n * (self.n - 1) if fix_norm else 2.0 * self.n * self.n
     self.dev = self.txt.device
     self.L = _lib.lib()
+    self.vw_t = self.vw_all.t().contiguous()  # [M, n]: the layout the two sweeps read (coalesced per expert)
 
   # ---- phase A: similarity row block -------------------------------------------------------------
   def phase_similarity(self):
@@ -48,11 +62,13 @@ class RowBlock:
     check(L.mmt_ls_fold_bf16(ops._p(self.txt), ops._p(self.tw), b, bp, m, d, ops._p(self.t16), ops._stream()), 'mmt_ls_fold_bf16')
     check(L.mmt_ls_fold_bf16(ops._p(self.vid_all), ops._p(self.vw_all), n, n, m, d, ops._p(self.v16), ops._stream()),
           'mmt_ls_fold_bf16')
-    self.S = torch.empty(bp, n, device=self.dev, dtype=torch.float32)
+    pad = int(os.environ.get('MMT_LS_PAD', '0'))  # lab: leading dimension of the row block = n + pad
+    self.S = torch.empty(bp, n + pad, device=self.dev, dtype=torch.float32)[:, :n]
+    self.ld = self.S.stride(0)
     ops.gemm_nt(self.t16, self.v16, self.S, 'F32', m=b)
     # S holds the raw numerators until phase_counts divides them in its own sweep; the diagonal needs b divisions now
     self.diag_local = torch.empty(b, device=self.dev, dtype=torch.float32)
-    check(L.mmt_ls_diag(ops._p(self.S), n, ops._p(self.tw), ops._p(self.vw_all), b, n, m, self.r0, ops._p(self.diag_local),
+    check(L.mmt_ls_diag(ops._p(self.S), self.ld, ops._p(self.tw), ops._p(self.vw_all), b, n, m, self.r0, ops._p(self.diag_local),
                         ops._stream()), 'mmt_ls_diag')
     return self.diag_local
 
@@ -64,24 +80,35 @@ class RowBlock:
     self.colcnt = torch.zeros(n, device=self.dev, dtype=torch.int32)
     part = torch.empty(b, L.mmt_ls_col_blocks(n), device=self.dev, dtype=torch.float32)
     # numerators -> similarities and pass 1 (hinge sums and counts) in ONE sweep over the row block
-    check(L.mmt_ls_counts_ex(ops._p(self.S), n, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), self.m, 1, b, n,
+    check(L.mmt_ls_counts_ex(ops._p(self.S), self.ld, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), ops._p(self.vw_t),
+                             self.m, 1 if self.keep_similarity else 2, b, n,
                              self.r0, self.margin, ops._p(self.rowcnt), ops._p(self.colcnt), ops._p(part), ops._stream()),
           'mmt_ls_counts_ex')
     self.loss_part = part.sum(1)  # per row, column blocks in order
     return self.colcnt, self.loss_part.sum() / self.norm
+
+  def similarity(self):
+    """The [b, n] similarities of the block (after phase_similarity)."""
+    if self.keep_similarity and hasattr(self, 'rowcnt'):
+      return self.S[:self.b]
+    s = self.S[:self.b].contiguous().clone() if self.ld != self.n else self.S[:self.b].clone()
+    check(self.L.mmt_ls_finish(ops._p(s), self.n, ops._p(self.tw), ops._p(self.vw_all), self.b, self.n, self.m, ops._stream()),
+          'mmt_ls_finish')
+    return s
 
   # ---- phase C: gradients of the local texts, contribution to every video ----------------------------
   def phase_backward(self, colcnt_total):
     L, b, n, m, d = self.L, self.b, self.n, self.m, self.d
     md, bp = m * d, self.t16.shape[0]
     colcnt_total = colcnt_total.to(device=self.dev, dtype=torch.int32).contiguous()
-    g16 = torch.zeros(bp, n, device=self.dev, dtype=torch.bfloat16)
+    g16 = torch.empty(bp, n, device=self.dev, dtype=torch.bfloat16)
+    g16[b:].zero_()                                        # (pad rows: K of the Q product)
     gs_part = torch.empty(b, L.mmt_ls_col_blocks(n), m, device=self.dev, dtype=torch.float32)
-    check(L.mmt_ls_grad(ops._p(self.S), n, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), ops._p(self.rowcnt),
-                        ops._p(colcnt_total), b, n, m, self.r0, self.margin, 1.0 / self.norm, ops._p(g16), n, ops._p(gs_part),
-                        ops._stream()), 'mmt_ls_grad')
+    check(L.mmt_ls_grad_ex(ops._p(self.S), self.ld, ops._p(self.diag_all), ops._p(self.tw), ops._p(self.vw_all), ops._p(self.vw_t),
+                           ops._p(self.rowcnt), ops._p(colcnt_total), b, n, m, self.r0, self.margin, 1.0 / self.norm, ops._p(g16), n, ops._p(gs_part),
+                           0 if self.keep_similarity else 1, ops._stream()), 'mmt_ls_grad_ex')
     gs = gs_part.sum(1)
-    v16t = self.v16.t().contiguous()                       # [M*d, n]: B operand of P = G' V'
+    v16t = _transposed(L, self.v16)                        # [M*d, n]: B operand of P = G' V'
     p = torch.empty(bp, md, device=self.dev, dtype=torch.float32)
     ops.gemm_nt(g16, v16t, p, 'F32', m=b)
     dtxt = torch.empty_like(self.txt)
@@ -89,7 +116,7 @@ class RowBlock:
     check(L.mmt_ls_unfold(ops._p(p), md, ops._p(self.txt), ops._p(self.tw), ops._p(gs), b, m, d, ops._p(dtxt), ops._p(dtw),
                           ops._stream()), 'mmt_ls_unfold')
     q = torch.empty(n, md, device=self.dev, dtype=torch.float32)   # Q = G'^T T': this rank's share of every video's gradient
-    ops.wgrad_grouped([(g16, self.t16, q, None)], b)
+    ops.gemm_nt(_transposed(L, g16), _transposed(L, self.t16), q, 'F32')   # K = the (zero-padded) local rows
     return dtxt, dtw, q
 
   # ---- phase D: gradient of the local videos from the reduce-scattered Q rows ---------------------------

@@ -418,12 +418,13 @@ def test_row_sharded_similarity_and_maxmargin(world):
   loss_ref = O.max_margin_ranking_loss(sims_ref, margin, True)
   loss_ref.backward()
   b = n // world
-  blocks = [RowBlock(txt[r * b:(r + 1) * b].to(DEV), tw[r * b:(r + 1) * b].to(DEV), vid.to(DEV), vw.to(DEV), r * b, margin)
-            for r in range(world)]
+  # (odd blocks keep the finished similarities in S; even ones leave the raw numerators there and divide in both passes)
+  blocks = [RowBlock(txt[r * b:(r + 1) * b].to(DEV), tw[r * b:(r + 1) * b].to(DEV), vid.to(DEV), vw.to(DEV), r * b, margin,
+                     keep_similarity=bool(r % 2)) for r in range(world)]
   diag = torch.cat([blk.phase_similarity() for blk in blocks])                     # all-gather
   assert (diag.cpu() - sims_ref.detach().diagonal()).abs().max() < 2e-3
   parts = [blk.phase_counts(diag) for blk in blocks]
-  S = torch.cat([blk.S[:b] for blk in blocks]).cpu()  # (the counts sweep is what turns the GEMM's numerators into similarities)
+  S = torch.cat([blk.similarity() for blk in blocks]).cpu()
   assert (S - sims_ref.detach()).abs().max() < 2e-3
   colcnt = sum(p[0] for p in parts)                                                 # all-reduce
   loss = sum(p[1] for p in parts)

@@ -580,3 +580,19 @@ def test_attention_dropout_is_keyed_on_original_positions(DH):
   dctx_z[:rows][~keep.reshape(-1).to(_dev())] = 0
   dq_dz = ops.attn_bwd(qkv, bias, ctx_d, lse_d, dctx_z, B, S, H, scale, drop_key=31, drop_p=0.2)
   _close('dqkv', dq_p[:n], dq_dz[idx], 4e-2, 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols,pad', [(128, 128, 0), (384, 1152, 0), (1024, 256, 64)])
+def test_transpose_bf16_is_exact(rows, cols, pad):
+  """mmt_transpose_bf16 (K-contiguous operands for the row block's backward NT GEMMs): a permutation of bf16 bit patterns,
+  with leading dimensions wider than the matrices (elements outside stay untouched)."""
+  from mmt_amd import _lib, ops
+  from mmt_amd._lib import check
+  src = _rand((rows, cols + pad), seed=31, dtype=torch.bfloat16)
+  dst = torch.full((cols, rows + pad), 3.0, device=_dev(), dtype=torch.bfloat16)
+  check(_lib.lib().mmt_transpose_bf16(ops._p(src), cols + pad, rows, cols, ops._p(dst), rows + pad, ops._stream()), 'transpose')
+  assert torch.equal(dst[:, :rows], src[:, :cols].t())
+  if pad:
+    assert bool((dst[:, rows:] == 3.0).all())
+  assert _lib.lib().mmt_transpose_bf16(ops._p(src), cols + pad, rows - 1, cols, ops._p(dst), rows + pad, ops._stream()) != 0

@@ -51,7 +51,7 @@ def test_row_block_at_full_size_matches_oracle_on_sampled_rows(b, n, rank):
   txt_r = txt_all[r0 + rows].cpu().requires_grad_(True)
   tw_r = tw_all[r0 + rows].cpu().requires_grad_(True)
   s_rows = O.cross_view_rows(txt_r, tw_r, vid_c, vw_c)                              # (16, n)
-  got_rows = blk.S[rows].cpu()
+  got_rows = blk.similarity()[rows].cpu()
   assert (got_rows - s_rows.detach()).abs().max().item() < 2e-3                    # bf16 operands, K = M*d = 7168
 
   # column hinge counts of the sampled columns over the block's rows: a full column of the block each
@@ -87,5 +87,58 @@ def test_row_block_at_full_size_matches_oracle_on_sampled_rows(b, n, rank):
     assert cos > 0.99 and abs(float(gv.norm() / wv.norm()) - 1.0) < 0.05, (name, cos, float(gv.norm() / wv.norm()))
   # the whole block: finite, |S| <= 1 for unit-norm inputs, counts within range
   assert torch.isfinite(loss) and torch.isfinite(dtxt).all() and torch.isfinite(q).all()
-  assert blk.S[:b].abs().max().item() <= 1.0 + 2e-3
+  assert blk.similarity().abs().max().item() <= 1.0 + 2e-3
   assert int(blk.rowcnt.max()) < n and int(colcnt.max()) <= b
+
+
+@pytest.mark.parametrize('m', [7, 12])
+def test_sweep_variants_agree_bit_for_bit(m):
+  """The sweeps in their three forms -- (a) finish in place, then counts / gradient on the finished block with vw as [n, M]
+  (mmt_ls_finish, mmt_ls_counts, mmt_ls_grad); (b) one finishing sweep (finish = 1) + gradient; (c) S left raw, both passes
+  divide on the fly and read vw transposed (finish = 2, raw = 1, vw_t) -- produce identical hinge counts and G' (the division
+  is the same two instructions everywhere: largesim.hip ls_quot) and loss / gs partial sums equal up to fp32 association.  Video weights vary per column here (zeros included: the 1e-5 branch)."""
+  from mmt_amd import _lib, ops
+  from mmt_amd._lib import check
+  L = _lib.lib()
+  b, n, r0, margin = 43, 2048 + 512, 256, 0.05  # (43: a partial last row block -- the checked copy of the sweeps)
+  g = torch.Generator(device=DEV).manual_seed(5)
+  raw = torch.randn(b, n, device=DEV, generator=g) * 0.05
+  tw = torch.softmax(torch.randn(b, m, device=DEV, generator=g), -1)
+  vw = torch.softmax(torch.randn(n, m, device=DEV, generator=g), -1)
+  vw[5] = 0.0                                                    # den == 0 -> 1e-5, no normaliser gradient
+  vw_t = vw.t().contiguous()
+  diag = torch.randn(n, device=DEV, generator=g) * 0.05
+  ncb = L.mmt_ls_col_blocks(n)
+  inv_norm = 1.0 / (2.0 * n * (n - 1))
+
+  def run(kind):
+    S = raw.clone()
+    rowcnt = torch.zeros(b, device=DEV, dtype=torch.int32)
+    colcnt = torch.zeros(n, device=DEV, dtype=torch.int32)
+    part = torch.zeros(b, ncb, device=DEV)
+    g16 = torch.zeros(b, n, device=DEV, dtype=torch.bfloat16)
+    gs = torch.zeros(b, ncb, m, device=DEV)
+    st = ops._stream()
+    if kind == 'a':
+      check(L.mmt_ls_finish(ops._p(S), n, ops._p(tw), ops._p(vw), b, n, m, st), 'finish')
+      check(L.mmt_ls_counts(ops._p(S), n, ops._p(diag), b, n, r0, margin, ops._p(rowcnt), ops._p(colcnt), ops._p(part), st), 'counts')
+      check(L.mmt_ls_grad(ops._p(S), n, ops._p(diag), ops._p(tw), ops._p(vw), ops._p(rowcnt), ops._p(colcnt), b, n, m, r0, margin,
+                          inv_norm, ops._p(g16), n, ops._p(gs), st), 'grad')
+    else:
+      fin, vt = (1, None) if kind == 'b' else (2, ops._p(vw_t))
+      check(L.mmt_ls_counts_ex(ops._p(S), n, ops._p(diag), ops._p(tw), ops._p(vw), vt, m, fin, b, n, r0, margin, ops._p(rowcnt),
+                               ops._p(colcnt), ops._p(part), st), 'counts_ex')
+      check(L.mmt_ls_grad_ex(ops._p(S), n, ops._p(diag), ops._p(tw), ops._p(vw), vt, ops._p(rowcnt), ops._p(colcnt), b, n, m, r0,
+                             margin, inv_norm, ops._p(g16), n, ops._p(gs), 1 if kind == 'c' else 0, st), 'grad_ex')
+      if kind == 'c':
+        assert torch.equal(S, raw)                               # the row block was never rewritten
+    return rowcnt, colcnt, part, g16, gs
+
+  ref = run('a')
+  assert int(ref[0].sum()) > 0 and int(ref[1].sum()) > 0
+  for kind in ('b', 'c'):
+    for name, x, y in zip(('rowcnt', 'colcnt', 'loss_part', 'G16', 'gs_part'), ref, run(kind)):
+      if name in ('loss_part', 'gs_part'):  # float sums: the kernels' instantiations may associate them differently
+        assert (x - y).abs().max().item() <= 1e-5 * x.abs().max().item(), (kind, name)
+      else:                                 # decisions and the bf16 operand: identical
+        assert torch.equal(x, y), (kind, name)

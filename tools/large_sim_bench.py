@@ -44,7 +44,8 @@ flops = 3 * 2.0 * a.b * a.n * a.m * a.d
 assert torch.isfinite(loss) and torch.isfinite(dtxt).all() and torch.isfinite(dvid).all()
 # size-independent properties: the gradient wrt S sums to zero row-block-wise up to the column hinges owned elsewhere;
 # unit-norm inputs => |S| <= 1; tw sums to one => dtw is orthogonal to the all-ones direction up to the normaliser term
-assert blk.S[:a.b].abs().max().item() <= 1.0 + 2e-3
+smax = blk.similarity().abs().max().item()
+assert smax <= 1.0 + 2e-3
 print('row block %d x %d, M=%d, d=%d: %.1f ms fwd+bwd (%.0f TFLOP/s on the three GEMMs), loss %.5f, max|S| %.4f, peak mem %.1f GB'
-      % (a.b, a.n, a.m, a.d, best * 1e3, flops / best / 1e12, loss.item(), blk.S[:a.b].abs().max().item(),
+      % (a.b, a.n, a.m, a.d, best * 1e3, flops / best / 1e12, loss.item(), smax,
          torch.cuda.max_memory_allocated() / 2 ** 30))

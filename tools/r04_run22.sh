@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+timeout 900 python -m pytest tests/test_large_sim_gpu.py tests/test_cenet_gpu.py -x -q -k "large or row_sharded or sweep_variants or row_block" 2>&1 | grep -v "^$" | tail -12
+bash tools/r04_run18.sh 2>&1 | grep "ls_\|gemm3\|total\|transpose\|fold" | cut -c1-120
+grep "row block" gpurun_out/r04_rowblock/prof.log
