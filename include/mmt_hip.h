@@ -628,7 +628,8 @@ int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch* b, void* 
  * records one pair around layer 0's FFN up-projection GEMM launch (the dominant kernel) on its stream.
  * The arrays must stay alive until the events have been read.  Pass NULL/0 to disarm. */
 int mmt_probe_arm(void** start_events, void** stop_events, int n);
-/* the same per site: 0 = FFN up-projection GEMM, 1 = FFN down-projection GEMM, 2 = grouped weight gradients (layer 0) */
+/* the same per site: 0 = FFN up-projection GEMM, 1 = FFN down-projection GEMM, 2 = grouped weight gradients, 3 / 4 = attention
+ * forward / backward (all of layer 0) */
 int mmt_probe_arm_site(int site, void** start_events, void** stop_events, int n);
 int mmt_probe_count_site(int site);
 /* y = dropout(x) (n % 4 == 0, 16-byte aligned) with the counter-based RNG of the engine: nn.Dropout in front of the text

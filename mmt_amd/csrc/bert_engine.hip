@@ -103,8 +103,9 @@ int check_model(const MmtBertModel* m, const MmtBertBatch* b) {
 // Profiling probes (bench.py): HIP events recorded on the launch stream around ONE launch per step of the three kernel
 // families that lead the rocprof time table -- site 0: FFN up-projection GEMM (+GELU) of layer 0, site 1: FFN
 // down-projection GEMM (N = hidden, K = intermediate; + bias/dropout/residual) of layer 0, site 2: the grouped
-// weight-gradient launch of layer 0 -- until the armed event pairs of a site are used up.
-enum { PROBE_SITES = 3 };
+// weight-gradient launch of layer 0, sites 3 / 4: the attention forward / backward launch of layer 0 -- until the armed
+// event pairs of a site are used up.
+enum { PROBE_SITES = 5 };
 hipEvent_t* g_probe_start[PROBE_SITES] = {};
 hipEvent_t* g_probe_stop[PROBE_SITES] = {};
 int g_probe_n[PROBE_SITES] = {}, g_probe_i[PROBE_SITES] = {};
@@ -264,8 +265,11 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
                             stream));
       break;
     }
-    TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
-                     site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    {
+      ProbeScope probe(3, l == 0, stream);
+      TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
+                       site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    }
     e = {};
     e.bias = P.bo; e.res = hin32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
@@ -480,8 +484,11 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     e.dot_src = L.ctx; e.lddot = d; e.dot_out = w.delta;  // rowsum(dO * O) per 64 columns, while dO is in registers
     TRY(mmt_gemm_nt_bf16(dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
-    TRY(mmt_attn_bwd_ex(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, 1, b->batch, b->seq,
-                        m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    {
+      ProbeScope probe(4, l == 0, stream);
+      TRY(mmt_attn_bwd_ex(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, 1, b->batch, b->seq,
+                          m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+    }
     if (fork_w) {
       // --- weight + bias gradients on the side stream, under the input-gradient GEMM below and the layers that follow ---
       TRY(mmt_stream_fork(stream, side));

@@ -1,14 +1,13 @@
-# gpurun_out/final/* (scratch, merged back by gpurun) -> profiles/r03_* (tracked)
+# gpurun_out/r04_final/* (scratch, merged back by gpurun) -> profiles/r04_* (tracked)
 set -e
 cd "$(dirname "$0")/.."
-for f in gpurun_out/final/*.json gpurun_out/final/*.txt gpurun_out/final/*.csv; do
+for f in gpurun_out/r04_final/*.json gpurun_out/r04_final/*.txt gpurun_out/r04_final/*.csv; do
   b=$(basename $f)
   case $b in
-    pmc_kernels.csv) cp $f profiles/r03_pmc_kernels.csv ;;
-    pmc_kernels.txt) cp $f profiles/r03_pmc_kernels.txt ;;
-    pmc_*) cp $f profiles/r03_$b ;;
-    fork_lab.txt) cp $f profiles/r03_fork_lab_final.txt ;;
-    *) cp $f profiles/r03_final_$b ;;
+    pmc_*) cp $f profiles/r04_$b ;;
+    gemm2_budget.txt) cp $f profiles/r04_gemm2_budget.txt ;;
+    attn_budget.txt) cp $f profiles/r04_attn_budget.txt ;;
+    *) cp $f profiles/r04_final_$b ;;
   esac
 done
-ls profiles | grep r03
+ls profiles | grep r04
