@@ -119,7 +119,9 @@ def pmc_traffic(kernel_subs, grid_sub=None):
   """HBM traffic per launch of a kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this same command,
   tools/final_profiles.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE reports half of a wide coalesced
   read (MI355X_MICROARCH.md, HBM section).  Of the grids a kernel was launched with, the one that holds most of its time
-  (the full layers' launches, not the tail's).  None if the profile is not there."""
+  (the full layers' launches, not the tail's).  The N = hidden epilogue kernel serves two GEMMs per layer (attention output,
+  K = hidden, and FFN down-projection, K = intermediate) with one grid: its figure is the mean over both.  None if the
+  profile is not there."""
   import csv
   path = os.path.join(ROOT, PMC_CSV)
   if not os.path.exists(path):
@@ -165,11 +167,11 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
   elif site == 0:
     name, flops = 'FFN up-projection GEMM + bias + erf-GELU (N=%d, K=%d; gemm2_kernel, EPI BIAS_GELU)' % (i, d), 2.0 * rows * i * d
     nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
-    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2'], None
+    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2', 'gemm3_kernel<2>'], None
   elif site == 1:
     name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
     nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
-    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3', 'gemm2_kernel<128, 128, 2, 4, 2, 3'], None
+    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3', 'gemm2_kernel<128, 128, 2, 4, 2, 3', 'gemm3_kernel<3>'], None
   else:
     name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_phased_kernel)'
     flops = 2.0 * rows * (2 * i * d + 4 * d * d)
