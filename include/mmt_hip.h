@@ -168,6 +168,15 @@ int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32
                      int rows, int d, const int32_t* n_rows_dev, const int32_t* row_index,
                      uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
                      void* stream);
+/* the same launch carrying one extra block that writes the attention backward's block order of this batch (sched_work
+ * nullable = no rider; arguments as for mmt_attn_schedule with tiles = ceil(S / 64)) */
+int mmt_embed_ln_fwd_sched(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
+                           const float* type_emb, const float* pos_emb, float* z_save, const float* gamma,
+                           const float* beta, float eps, float* h32, void* h16, float* mean, float* rstd,
+                           int rows, int d, const int32_t* n_rows_dev, const int32_t* row_index,
+                           uint32_t drop_key, uint32_t thr16, float drop_scale, const uint32_t* seed_dev,
+                           const int32_t* sched_cu, int sched_B, int sched_H, int sched_tiles, int32_t* sched_work,
+                           void* stream);
 /* Compact-row variant: LN over `rows` compact rows; fp32 row i goes to h32[dst_rows[i]] (h16 compact, nullable). */
 int mmt_ln_fwd_scatter(const float* z, const float* gamma, const float* beta, float eps, float* h32,
                        const int32_t* dst_rows, void* h16, float* mean, float* rstd, int rows, int d, void* stream);
@@ -272,10 +281,15 @@ int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_b
  * delta fp32 [rows, d/64]: sums of dctx * ctx over the 64-column groups of a row (delta of head h = its DH/64 groups).
  * mmt_attn_bwd forms them itself (scratch, one extra launch); mmt_attn_bwd_ex(delta_ready = 1) takes them as INPUT --
  * the epilogue of the GEMM that produced dctx writes them (MmtEpilogue.dot_src / dot_out). */
+/* work (nullable, packed batches with (B * H) % 8 == 0): the block order of THIS batch, mmt_attn_schedule_words(B, S, H) int32
+ * words written by mmt_attn_schedule (or by the engine, riding in its embedding LayerNorm launch): longest blocks first,
+ * empty slots at the end of the grid, every block of a (sample, head) on one XCD.  Same results as without. */
 int mmt_attn_bwd_ex(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                     const float* lse, const void* dctx, void* dqkv, float* delta, int delta_ready, int B, int S, int H,
                     int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                    const uint32_t* seed_dev, const int32_t* row_index, void* stream);
+                    const uint32_t* seed_dev, const int32_t* row_index, const int32_t* work, void* stream);
+int64_t mmt_attn_schedule_words(int B, int S, int H);
+int mmt_attn_schedule(const int32_t* cu_seqlens, int B, int S, int H, int32_t* work, void* stream);
 int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                  const float* lse, const void* dctx, void* dqkv, float* delta, int B, int S, int H, int d,
                  float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,

@@ -147,6 +147,8 @@ SIGNATURES = {
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                  c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
+    'mmt_embed_ln_fwd_sched': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                 c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_ln_bwd_rows_per_block': (c_int, [c_int]),
     'mmt_gemm_splitk_geometry': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_splitk_ln_fwd': (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp,
@@ -171,7 +173,9 @@ SIGNATURES = {
     'mmt_attn_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
                              c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_bwd_ex': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_f32,
-                                c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
+                                c_u32, c_u32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'mmt_attn_schedule_words': (c_i64, [c_int, c_int, c_int]),
+    'mmt_attn_schedule': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_attn_bwd_rows_ex': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_int, c_f32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp]),
     'mmt_attn_fwd_rows': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32,

@@ -20,6 +20,7 @@
 // the dense run.  Backward regenerates it.
 #include <stdlib.h>
 #include "mmt_common.h"
+#include "attn_sched.h"
 #include "../../include/mmt_hip.h"
 
 #define LOG2E 1.4426950408889634f
@@ -194,6 +195,8 @@ struct AttnArgs {
   const int32_t* qsel; int nq;
   // token packing: row_index[row] = b * S_dense + original position (nullable: rows are dense, position = row - b*S)
   const int32_t* row_index;
+  // backward only (nullable): block order built by attn_schedule_block (attn_sched.h), one item per block of the grid
+  const int32_t* work;
 };
 
 // original position of (packed) row `row` of sample b
@@ -418,15 +421,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
 // produced dO (MmtEpilogue.dot_out) or by attn_delta_kernel below.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, unsigned char* att_smem, int bx, int b, int h) {
+__device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, unsigned char* att_smem, int bx, int b, int h, int off, int Sb) {
   constexpr int NW = 4, ROWB = DH * 2, TILEB = 64 * ROWB, STAGEB = 2 * TILEB, KK = DH / 32, FD = DH / 16, NG = 2 * FD / 4;
   constexpr int NDMA = 2 * (TILEB / 1024) / NW;
   bf16_t* smem = (bf16_t*)att_smem;
   const int SP = (a.S_dense + 63) & ~63;
   float* bias_s = (float*)(att_smem + 2 * STAGEB);
   int* kpos_s = (int*)(bias_s + SP);
-  const int off = a.cu ? a.cu[b] : b * a.S_dense;
-  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int q0 = bx * 64;
   const int nqs = a.qsel ? a.nq : Sb;
   if (q0 >= nqs || Sb <= 0) return;
@@ -620,7 +621,7 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnArgs& a, unsigned ch
 // lse, delta and the dropout row key of EVERY query of the sample go to LDS once, in the prologue.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, unsigned char* att_smem, int bx, int b, int h) {
+__device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, unsigned char* att_smem, int bx, int b, int h, int off, int Sb) {
   constexpr int NW = 4, ROWB = DH * 2, TILEB = 64 * ROWB, STAGEB = 2 * TILEB, KK = DH / 32, FD = DH / 16, NG = 2 * FD / 4;
   constexpr int NDMA = 2 * (TILEB / 1024) / NW;
   bf16_t* smem = (bf16_t*)att_smem;
@@ -628,8 +629,6 @@ __device__ __forceinline__ void attn_bwd_dkv_block(const AttnArgs& a, unsigned c
   float* lse_s = (float*)(att_smem + 2 * STAGEB);  // [SP] lse (x log2 e), +inf for dead rows
   float* dlt_s = lse_s + SP;                        // [SP] delta
   float* rk_s = dlt_s + SP;                         // [SP] dropout row key (bits)
-  const int off = a.cu ? a.cu[b] : b * a.S_dense;
-  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   const int k0 = bx * 64;
   if (k0 >= Sb) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -837,21 +836,32 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, int q_tiles, int k_tiles) {
   extern __shared__ __attribute__((aligned(256))) unsigned char att_smem[];
   ATT_MARK(0);
+  if (a.work) {  // scheduled order (attn_sched.h): one scalar 16-byte load tells the block what it is
+    const int32_t* w = a.work + (int64_t)blockIdx.x * 4;
+    const int wb = w[0], wk = w[1], woff = w[2], wlen = w[3];
+    if (wb >= 0) {
+      const int h = wk & 0xff, role = (wk >> 8) & 1, tile = wk >> 16;
+      if (role) attn_bwd_dq_block<DH>(a, att_smem, tile, wb, h, woff, wlen);
+      else attn_bwd_dkv_block<DH>(a, att_smem, tile, wb, h, woff, wlen);
+    }
+  } else {
   const int nbh = a.H * a.B, bh = (int)blockIdx.x % nbh, slot = (int)blockIdx.x / nbh;
   const int b = bh / a.H, h = bh % a.H;
+  const int off = a.cu ? a.cu[b] : b * a.S_dense;
+  const int Sb = a.cu ? a.cu[b + 1] - off : a.S_dense;
   if (q_tiles < 0) {  // lab (MMT_ATTN_BWD_MERGE=1): tile i of BOTH roles in one block, one after the other
-    attn_bwd_dkv_block<DH>(a, att_smem, slot, b, h);
+    attn_bwd_dkv_block<DH>(a, att_smem, slot, b, h, off, Sb);
     __syncthreads();
-    if (slot < -q_tiles) attn_bwd_dq_block<DH>(a, att_smem, slot, b, h);
+    if (slot < -q_tiles) attn_bwd_dq_block<DH>(a, att_smem, slot, b, h, off, Sb);
   } else {
   // All dK/dV tiles first (the longer role), then the dQ tiles.  Tiles past a sample's length exit at once and hand their
-  // slot to the next block in line, so when more blocks are live than fit (536 of 1024 on 512 slots at the synthetic
-  // MSRVTT fill) it is the LAST, shortest ones that wait for a slot.
+  // slot to the next block in line.  (Order without a work list: callers outside the engine, dense batches.)
   int role, tile;  // role 0 = dK/dV, 1 = dQ
   if (slot < k_tiles) { role = 0; tile = slot; }
   else { role = 1; tile = slot - k_tiles; }
-  if (role) attn_bwd_dq_block<DH>(a, att_smem, tile, b, h);
-  else attn_bwd_dkv_block<DH>(a, att_smem, tile, b, h);
+  if (role) attn_bwd_dq_block<DH>(a, att_smem, tile, b, h, off, Sb);
+  else attn_bwd_dkv_block<DH>(a, att_smem, tile, b, h, off, Sb);
+  }
   }
 #ifdef MMT_GEMM2_INSTR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -865,7 +875,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, int q_tile
 // delta partials for callers that do not get them from a GEMM epilogue: dparts[row, c] = sum over the 64 columns of group c
 // of dO[row, .] * O[row, .] (fp32 accumulation of bf16 products), 16 lanes x 4 columns per (row, group).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
-                                                         int64_t ld, float* __restrict__ dparts, int rows, int d) {
+                                                         int64_t ld, float* __restrict__ dparts, int rows, int d,
+                                                         const int32_t* __restrict__ cu, int B) {
+  if (cu) rows = min(rows, cu[B]);  // packed batch: the buffers hold the live rows only, not B * S
   const int groups = d / 64;
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t g = idx >> 4;
@@ -950,14 +962,16 @@ static int launch_bwd(const AttnArgs& a, int tq, int tk, int H, int B, bool dh12
   if (!delta_ready) {
     const int64_t lanes = (int64_t)rows_c * (a.d / 64) * 16;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a.dctx, (const bf16_t*)a.ctx, a.ldc,
-                       (float*)a.dparts, rows_c, a.d);
+                       (float*)a.dparts, rows_c, a.d, a.qsel ? nullptr : a.cu, B);
   }
   auto go = [&](int q_tiles, int k_tiles) {
     const int gx = (q_tiles + k_tiles) * H * B;
     if (dh128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(gx), dim3(256), lds, s, a, q_tiles, k_tiles);
     else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(gx), dim3(256), lds, s, a, q_tiles, k_tiles);
   };
-  if (split == 2 && tq <= tk) {  // lab: merged roles (see the kernel)
+  if (a.work) {
+    go(tq, tk);
+  } else if (split == 2 && tq <= tk) {  // lab: merged roles (see the kernel)
     const int gx = tk * H * B;
     if (dh128) hipLaunchKernelGGL(attn_bwd_kernel<128>, dim3(gx), dim3(256), lds, s, a, -tq, tk);
     else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(gx), dim3(256), lds, s, a, -tq, tk);
@@ -983,10 +997,23 @@ extern "C" int mmt_attn_fwd(const void* qkv, const int32_t* cu_seqlens, const fl
   return launch_fwd(a, S, H, B, d == H * 128, (hipStream_t)stream);
 }
 
+// The block order of the backward for a packed batch (attn_sched.h): work = mmt_attn_schedule_words(B, S, H) int32 words.
+__global__ __launch_bounds__(512) void attn_schedule_kernel(AttnSched s) { attn_schedule_block(s); }
+extern "C" int64_t mmt_attn_schedule_words(int B, int S, int H) { return (int64_t)2 * ((S + 63) / 64) * B * H * 4; }
+static bool attn_schedulable(int B, int H) { return (B * H) % 8 == 0 && B * H <= 8 * 64 * ATT_SCHED_CHUNKS && H <= 255; }
+extern "C" int mmt_attn_schedule(const int32_t* cu_seqlens, int B, int S, int H, int32_t* work, void* stream) {
+  if (!cu_seqlens || !work || B <= 0 || S <= 0 || H <= 0 || !attn_schedulable(B, H)) return MMT_ERR_ARG;
+  AttnSched sc = {cu_seqlens, work, B, H, (S + 63) / 64};
+  hipLaunchKernelGGL(attn_schedule_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, sc);
+  return (int)hipGetLastError();
+}
+
+// work (nullable): the schedule of THIS batch (mmt_attn_schedule, or the engine's rider in the embedding LayerNorm launch);
+// same results, blocks in longest-first order.
 extern "C" int mmt_attn_bwd_ex(const void* qkv, const int32_t* cu_seqlens, const float* mask_bias, const void* ctx,
                                const float* lse, const void* dctx, void* dqkv, float* delta, int delta_ready, int B, int S,
                                int H, int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
-                               const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
+                               const uint32_t* seed_dev, const int32_t* row_index, const int32_t* work, void* stream) {
   if (int e = check_args(qkv, B, S, H, d)) return e;
   if (!mask_bias || !ctx || !lse || !dctx || !dqkv || !delta) return MMT_ERR_ARG;
   AttnArgs a = {};
@@ -995,6 +1022,8 @@ extern "C" int mmt_attn_bwd_ex(const void* qkv, const int32_t* cu_seqlens, const
   a.dparts = delta; a.H = H; a.d = d; a.B = B; a.scale = scale;
   a.drop_key = drop_key; a.thr16 = thr16; a.drop_scale = drop_scale; a.S4 = (S + 3) & ~3; a.seed_dev = seed_dev;
   a.row_index = row_index;
+  if (work && (!cu_seqlens || !attn_schedulable(B, H))) return MMT_ERR_ARG;
+  a.work = work;
   const int tiles = (S + 63) / 64;
   return launch_bwd(a, tiles, tiles, H, B, d == H * 128, delta_ready, B * S, (hipStream_t)stream);
 }
@@ -1003,7 +1032,7 @@ extern "C" int mmt_attn_bwd(const void* qkv, const int32_t* cu_seqlens, const fl
                             int d, float scale, uint32_t drop_key, uint32_t thr16, float drop_scale,
                             const uint32_t* seed_dev, const int32_t* row_index, void* stream) {
   return mmt_attn_bwd_ex(qkv, cu_seqlens, mask_bias, ctx, lse, dctx, dqkv, delta, 0, B, S, H, d, scale, drop_key, thr16, drop_scale,
-                         seed_dev, row_index, stream);
+                         seed_dev, row_index, nullptr, stream);
 }
 
 // Query-subset variants: only the rows qsel[b*nq + i] act as queries (all rows of a sample remain keys/values).

@@ -37,6 +37,8 @@ struct Ws {
   // dy / dy2 / dhpre / dqkv are what the weight gradients of a layer read: two sets, used by even / odd layers, so that
   // the weight gradients of layer l may still be running (MMT_FORK_WGRAD) while layer l-1 produces its own
   char *dy_[2], *dy2_[2], *dhpre_[2], *dqkv_[2], *dctx;
+  size_t attn_work_words;
+  int32_t* attn_work;  // block order of the attention backward for the batch in flight (attn_sched.h; written by the forward)
   float* kslab;  // split-K partial slabs of the main path's K = intermediate, N = hidden GEMMs (up to 4 x [R, d])
   size_t bytes;
 };
@@ -87,6 +89,9 @@ void layout(const MmtBertModel* m, int R, char* base, Ws* w) {
   // the serial path keep the addresses (and the cache-set relationships) they had before forking existed
   w->dy_[1] = take(R * d * 2); w->dy2_[1] = take(R * d * 2); w->dhpre_[1] = take(R * I * 2); w->dqkv_[1] = take(R * 3 * d * 2);
   w->kslab = (float*)take((size_t)4 * R * d * 4);
+  // B * ceil(S / 64) <= R / 64 + B tile slots per role and head, and a schedule is only built for B * H <= 2048
+  w->attn_work_words = (size_t)2 * ((size_t)R / 64 + (R < 2048 ? (size_t)R : 2048)) * H * 4;
+  w->attn_work = (int32_t*)take(w->attn_work_words * 4);
   w->bytes = off;
 }
 
@@ -214,6 +219,19 @@ static bool splitk_ffn(const Ws&, int rows, int d, int K) {
   return splitk_ffn_mode() > 0 && rows >= 2048 && K >= 2048 && d <= 512;
 }
 
+// the attention backward's block order (attn_sched.h) exists for packed batches whose (sample, head) pairs split over 8 XCDs
+static const int32_t* attn_work_of(const MmtBertModel* m, const MmtBertBatch* b, const Ws& w) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MMT_ATTN_SCHED");
+    on = e ? atoi(e) : 1;
+  }
+  const long bh = (long)b->batch * m->heads;
+  if (!on || !b->cu_seqlens || bh % 8 || bh > 2048 || m->heads > 255) return nullptr;
+  if ((size_t)mmt_attn_schedule_words(b->batch, b->seq, m->heads) > w.attn_work_words) return nullptr;
+  return w.attn_work;
+}
+
 extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, void* ws, float* out_last,
                                 int training, void* stream) {
   TRY(check_model(m, b));
@@ -225,9 +243,10 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
   const float sh = scale_of(th), sa = scale_of(ta);
   const float qk_scale = m->hidden == m->heads * 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(head dim)
 
-  TRY(mmt_embed_ln_fwd(b->features, b->type_ids, b->pos_ids, m->type_emb, m->pos_emb, w.z0, m->emb_ln_g,
+  TRY(mmt_embed_ln_fwd_sched(b->features, b->type_ids, b->pos_ids, m->type_emb, m->pos_emb, w.z0, m->emb_ln_g,
                        m->emb_ln_b, m->ln_eps, w.h32_in, w.h16_in, w.mean0, w.rstd0, rows, d, b->n_rows_dev,
-                       b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, stream));
+                       b->row_index, site_key(0, SITE_EMB), th, sh, b->seed_dev, b->cu_seqlens, b->batch, m->heads, (b->seq + 63) / 64,
+                             const_cast<int32_t*>(attn_work_of(m, b, w)), stream));
   const float* hin32 = w.h32_in;
   const char* hin16 = w.h16_in;
   const int nc = tail_rows(b, w);
@@ -487,7 +506,8 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     {
       ProbeScope probe(4, l == 0, stream);
       TRY(mmt_attn_bwd_ex(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, w.dctx, dqkv, w.delta, 1, b->batch, b->seq,
-                          m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
+                          m->heads, d, qk_scale, site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, attn_work_of(m, b, w),
+                          stream));
     }
     if (fork_w) {
       // --- weight + bias gradients on the side stream, under the input-gradient GEMM below and the layers that follow ---

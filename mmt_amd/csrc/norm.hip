@@ -8,6 +8,7 @@
 //   col_reduce   : sums the per-block partials
 //   table_grad   : embedding-table gradients (deterministic segmented sums, no atomics)
 #include "mmt_common.h"
+#include "attn_sched.h"
 #include "../../include/mmt_hip.h"
 
 #define MAXC 4  // d <= 1024: up to 4 float4 chunks per lane
@@ -19,12 +20,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ h32,
     bf16_t* __restrict__ h16, float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
     const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ row_index, uint32_t drop_key_in,
-    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev, const int32_t* __restrict__ dst_rows) {
+    uint32_t thr16, float drop_scale, const uint32_t* __restrict__ seed_dev, const int32_t* __restrict__ dst_rows,
+    int ln_blocks, AttnSched sched) {
+  // rider (EMBED launches of the encoder engine): ONE extra block builds the attention backward's block order of this batch
+  // (attn_sched.h) -- independent of everything here, needed a forward pass later, and not worth a graph node of its own
+  if (EMBED && (int)blockIdx.x >= ln_blocks) {
+    if (sched.work) attn_schedule_block(sched);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = n_rows_dev ? min(*n_rows_dev, rows) : rows;
   const int nch = d >> 8;
   const unsigned drop_key = eff_key(drop_key_in, seed_dev);
-  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += ln_blocks * 4) {
     const int64_t hrow = dst_rows ? dst_rows[row] : row;  // where the fp32 output row goes (scatter to token rows)
     f32x4 x[MAXC];
     float s = 0.f;
@@ -498,7 +506,7 @@ extern "C" int mmt_ln_fwd(const float* z, const float* gamma, const float* beta,
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
                      nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f, nullptr, nullptr);
+                     rstd, rows, d, n_rows_dev, nullptr, 0u, 0u, 1.0f, nullptr, nullptr, ln_grid(rows), AttnSched{});
   return (int)hipGetLastError();
 }
 
@@ -510,7 +518,7 @@ extern "C" int mmt_ln_fwd_scatter(const float* z, const float* gamma, const floa
   if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
   hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, z,
                      nullptr, nullptr, nullptr, nullptr, nullptr, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, nullptr, nullptr, 0u, 0u, 1.0f, nullptr, dst_rows);
+                     rstd, rows, d, nullptr, nullptr, 0u, 0u, 1.0f, nullptr, dst_rows, ln_grid(rows), AttnSched{});
   return (int)hipGetLastError();
 }
 
@@ -603,20 +611,32 @@ extern "C" int mmt_embedding_grad(const float* g, const int32_t* ids, int n, int
   return (int)hipGetLastError();
 }
 
+extern "C" int mmt_embed_ln_fwd_sched(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
+                                const float* type_emb, const float* pos_emb, float* z_save,
+                                const float* gamma, const float* beta, float eps, float* h32, void* h16,
+                                float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev,
+                                const int32_t* row_index, uint32_t drop_key, uint32_t thr16, float drop_scale,
+                                const uint32_t* seed_dev, const int32_t* sched_cu, int sched_B, int sched_H, int sched_tiles,
+                                      int32_t* sched_work, void* stream) {
+  if (!features || !type_ids || !type_emb || !gamma || !beta || !h16 || !mean || !rstd || rows <= 0)
+    return MMT_ERR_ARG;
+  if (pos_ids && !pos_emb) return MMT_ERR_ARG;
+  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
+  const AttnSched sc = {sched_cu, sched_work, sched_B, sched_H, sched_tiles};
+  hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(ln_grid(rows) + (sched_work ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, features,
+                     type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, (bf16_t*)h16, mean,
+                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev, nullptr, ln_grid(rows), sc);
+  return (int)hipGetLastError();
+}
 extern "C" int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32_t* pos_ids,
                                 const float* type_emb, const float* pos_emb, float* z_save,
                                 const float* gamma, const float* beta, float eps, float* h32, void* h16,
                                 float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev,
                                 const int32_t* row_index, uint32_t drop_key, uint32_t thr16, float drop_scale,
                                 const uint32_t* seed_dev, void* stream) {
-  if (!features || !type_ids || !type_emb || !gamma || !beta || !h16 || !mean || !rstd || rows <= 0)
-    return MMT_ERR_ARG;
-  if (pos_ids && !pos_emb) return MMT_ERR_ARG;
-  if (d % 256 || d > MAXC * 256) return MMT_ERR_ARG;
-  hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, features,
-                     type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, (bf16_t*)h16, mean,
-                     rstd, rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev, nullptr);
-  return (int)hipGetLastError();
+  return mmt_embed_ln_fwd_sched(features, type_ids, pos_ids, type_emb, pos_emb, z_save, gamma, beta, eps, h32, h16, mean, rstd,
+                                rows, d, n_rows_dev, row_index, drop_key, thr16, drop_scale, seed_dev, nullptr, 0, 0, 0, nullptr,
+                                stream);
 }
 
 // rows per block: 16 (two rows per wave) for big inputs; 8 (one row per wave) when there are few rows, so that a

@@ -249,15 +249,23 @@ def attn_fwd(qkv, mask_bias, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p
 
 
 def attn_bwd(qkv, mask_bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=None, drop_key=0, drop_p=0.0,
-             seed_dev=None, row_index=None):
+             seed_dev=None, row_index=None, scheduled=False):
+  """scheduled: run the blocks in the order of mmt_attn_schedule (packed batches with (B * H) % 8 == 0): same results."""
   _need_cuda(qkv)
   R, d3 = qkv.shape
   d = d3 // 3
   dqkv = torch.zeros_like(qkv)
   delta = torch.zeros(R, d // 64, device=qkv.device, dtype=torch.float32)  # scratch: dO * O sums per 64 columns
   thr, sc = dropout_params(drop_p)
-  check(_lib.lib().mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
-                                _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _p(row_index), _stream()), 'mmt_attn_bwd')
+  L = _lib.lib()
+  if scheduled:
+    work = torch.empty(L.mmt_attn_schedule_words(B, S, H), device=qkv.device, dtype=torch.int32)
+    check(L.mmt_attn_schedule(_p(cu_seqlens), B, S, H, _p(work), _stream()), 'mmt_attn_schedule')
+    check(L.mmt_attn_bwd_ex(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), 0, B, S, H, d,
+                            scale, drop_key, thr, sc, _p(seed_dev), _p(row_index), _p(work), _stream()), 'mmt_attn_bwd_ex')
+    return dqkv
+  check(L.mmt_attn_bwd(_p(qkv), _p(cu_seqlens), _p(mask_bias), _p(ctx), _p(lse), _p(dctx), _p(dqkv),
+                       _p(delta), B, S, H, d, scale, drop_key, thr, sc, _p(seed_dev), _p(row_index), _stream()), 'mmt_attn_bwd')
   return dqkv
 
 

@@ -596,3 +596,62 @@ def test_transpose_bf16_is_exact(rows, cols, pad):
   if pad:
     assert bool((dst[:, rows:] == 3.0).all())
   assert _lib.lib().mmt_transpose_bf16(ops._p(src), cols + pad, rows - 1, cols, ops._p(dst), rows + pad, ops._stream()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('DH,B,H,S', [(128, 8, 4, 218), (64, 16, 12, 30), (128, 6, 4, 400)])
+def test_attention_backward_block_schedule_changes_nothing(DH, B, H, S):
+  """mmt_attn_schedule (attn_sched.h): the backward's blocks in longest-first order, every block of a (sample, head) on one
+  XCD, empty slots at the end.  The work list must name every live (role, tile, sample, head) exactly once -- checked
+  directly -- and the scheduled backward must produce the bits of the unscheduled one (packed batch with dropout)."""
+  from mmt_amd import _lib, ops
+  from mmt_amd._lib import check
+  d = H * DH
+  scale = 1.0 / math.sqrt(float(DH))
+  g = torch.Generator(device='cpu').manual_seed(40 + B)
+  lens = torch.randint(1, S + 1, (B,), generator=g)
+  lens[0], lens[1] = S, 1
+  cu = torch.zeros(B + 1, dtype=torch.int32)
+  cu[1:] = torch.cumsum(lens, 0)
+  rows = int(cu[-1])
+  R = ops.pad_rows(rows)
+  cu_d = cu.to(_dev())
+  L = _lib.lib()
+  tiles = (S + 63) // 64
+  work = torch.full((L.mmt_attn_schedule_words(B, S, H),), 7, device=_dev(), dtype=torch.int32)
+  check(L.mmt_attn_schedule(ops._p(cu_d), B, S, H, ops._p(work), ops._stream()), 'mmt_attn_schedule')
+  w = work.view(-1, 4).cpu()
+  assert w.shape[0] == 2 * tiles * B * H
+  live = w[w[:, 0] >= 0]
+  want = set()
+  for b in range(B):
+    for h in range(H):
+      for role in range(2):
+        for t in range((int(lens[b]) + 63) // 64):
+          want.add((b, h, role, t))
+  got = [(int(r[0]), int(r[1]) & 0xff, (int(r[1]) >> 8) & 1, int(r[1]) >> 16) for r in live]
+  assert len(got) == len(set(got)) and set(got) == want
+  for r in live:
+    assert int(r[2]) == int(cu[int(r[0])]) and int(r[3]) == int(lens[int(r[0])])
+  pos = torch.nonzero(w[:, 0] >= 0).flatten()
+  for i, r in zip(pos.tolist(), live):                     # XCD of a block = its index mod 8 = (sample, head) pair mod 8
+    assert i % 8 == (int(r[0]) * H + (int(r[1]) & 0xff)) % 8
+  for x in range(8):                                       # per XCD: iterations descending, dK/dV before dQ inside a count
+    seq = [(-((int(lens[int(r[0])]) + 63) // 64), (int(r[1]) >> 8) & 1) for i, r in zip(pos.tolist(), live) if i % 8 == x]
+    assert seq == sorted(seq)
+    dead = [i for i in range(x, w.shape[0], 8) if w[i, 0] < 0]
+    assert not dead or min(dead) > max([i for i in pos.tolist() if i % 8 == x] + [-1])
+  qkv = _rand((R, 3 * d), 1.0, seed=41, dtype=torch.bfloat16)
+  bias = torch.zeros(R, device=_dev())
+  bias[3:5] = -10000.0
+  ridx = torch.zeros(R, dtype=torch.int32)
+  for b in range(B):
+    ridx[int(cu[b]):int(cu[b + 1])] = b * S + torch.arange(int(lens[b]), dtype=torch.int32)
+  ridx = ridx.to(_dev())
+  ctx, lse = ops.attn_fwd(qkv, bias, B, S, H, scale, cu_seqlens=cu_d, drop_key=5, drop_p=0.1, row_index=ridx)
+  dctx = _rand((R, d), seed=42, dtype=torch.bfloat16)
+  a = ops.attn_bwd(qkv, bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=cu_d, drop_key=5, drop_p=0.1, row_index=ridx)
+  b_ = ops.attn_bwd(qkv, bias, ctx, lse, dctx, B, S, H, scale, cu_seqlens=cu_d, drop_key=5, drop_p=0.1, row_index=ridx,
+                    scheduled=True)
+  assert torch.equal(a, b_)
+  assert a[:rows].float().abs().sum().item() > 0

@@ -39,9 +39,15 @@ def fwd():
   _lib.check(L.mmt_attn_fwd(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), B, S, H, d, scale, 7, thr, sc, None, None, _stream()), 'f')
 
 
+SCHED = '--nosched' not in sys.argv  # the engine's block order (attn_sched.h); --nosched: slot order of the plain API
+work = torch.empty(L.mmt_attn_schedule_words(B, S, H), device=dev, dtype=torch.int32)
+_lib.check(L.mmt_attn_schedule(_p(cu), B, S, H, _p(work), _stream()), 'sched')
+print('block order:', 'scheduled (longest first, dead slots last)' if SCHED else 'slot order (dK/dV tiles, then dQ tiles)')
+
+
 def bwd():  # (the delta sums are in place after the first plain call: the kernel alone, as the engine launches it)
   _lib.check(L.mmt_attn_bwd_ex(_p(qkv), _p(cu), _p(mask), _p(ctx), _p(lse), _p(dctx), _p(dqkv), _p(delta), 1, B, S, H, d,
-                               scale, 7, thr, sc, None, None, _stream()), 'b')
+                               scale, 7, thr, sc, None, None, _p(work) if SCHED else None, _stream()), 'b')
 
 
 fwd()
