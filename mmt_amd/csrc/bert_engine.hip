@@ -204,9 +204,11 @@ static int gemm_hidden(const Ws& w, int rows, int d, const void* A, int64_t lda,
 }
 
 // K = intermediate, N = hidden on thousands of rows: one 128x64 tile per CU walks 48 dependent K-steps at the CU's
-// L2 -> LDS ingest limit (24 KB per step).  Split 2 ways over K on 128x128 tiles: the same block count, 2/3 of the operand
-// bytes per CU, and the partial slabs are summed by the LayerNorm pass that follows anyway (fwd: + bias, dropout,
-// residual; bwd: + residual gradient).  MMT_SPLITK_FFN = 10 * splits + wide (0: off).
+// L2 -> LDS ingest limit (24 KB per step).  Lab switch MMT_SPLITK_FFN = 10 * splits + wide (0 = off, the default): the GEMM
+// split over K with the partial slabs summed by the LayerNorm pass that follows anyway (fwd: + bias, dropout, residual;
+// bwd: + residual gradient).  Same-box A/B of the whole step (3 alternations, r04): off 1.2864 ms; 2 splits of 128x64
+// tiles 1.2912; 2 splits of 128x128 tiles 1.3245; 4 splits of 256x128 tiles 1.2808 -- the slab traffic (4 x 7.3 MB written
+// and read back per GEMM) eats what the shorter K-chains win.  Parity-tested (tests/test_cenet_gpu.py under the switch).
 static int splitk_ffn_mode() {
   static int mode = -1;
   if (mode < 0) {
