@@ -810,10 +810,43 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
 #endif
 }
 
+int mmt_wgrad3_launch(const MmtWgradGroup& h, int tiles, hipStream_t s);  // wgrad3.hip
+
 extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
   if (!g || g->count <= 0 || g->count > MMT_WGRAD_MAX || g->rows <= 0) return MMT_ERR_ARG;
   MmtWgradGroup h = *g;
   int tiles = 0;
+  // r04: 256 x 256 tiles (wgrad3.hip) when every item is cut into such tiles without remainder, nothing is split over the
+  // rows, and the launch has at least 3/4 of a tile per CU over thousands of rows (configs[4]: d = 1024, 256 tiles).
+  // MMT_WGRAD3=0 switches it off (same-box A/B).
+  {
+    static int w3 = -1;
+    if (w3 < 0) {
+      const char* e = getenv("MMT_WGRAD3");
+      w3 = e ? atoi(e) : 1;
+    }
+    int t3 = 0;
+    bool ok = w3 != 0 && h.rows >= 2048;
+    for (int q = 0; q < h.count && ok; ++q) {
+      const MmtWgradItem& it = h.item[q];
+      ok = it.A && it.B && it.out && it.N > 0 && it.K2 > 0 && it.N % 256 == 0 && it.K2 % 256 == 0 && it.splits <= 1 &&
+           !(it.lda % 8) && !(it.ldb % 8) && !((uintptr_t)it.A & 15) && !((uintptr_t)it.B & 15) && !((uintptr_t)it.out & 15) &&
+           it.lda >= 256 && it.ldb >= 256;
+      t3 += (it.N / 256) * (it.K2 / 256);
+    }
+    if (ok && t3 >= 192) {
+      int tb = 0;
+      for (int q = 0; q < h.count; ++q) {
+        MmtWgradItem& it = h.item[q];
+        if (it.N_out <= 0 || it.N_out > it.N) it.N_out = it.N;
+        if (it.K2_out <= 0 || it.K2_out > it.K2) it.K2_out = it.K2;
+        if (it.ldo <= 0) it.ldo = it.K2_out;
+        it.tile_begin = tb;
+        tb += (it.N / 256) * (it.K2 / 256);
+      }
+      return mmt_wgrad3_launch(h, tb, (hipStream_t)stream);
+    }
+  }
   for (int q = 0; q < h.count; ++q) {
     MmtWgradItem& it = h.item[q];
     if (!it.A || !it.B || !it.out || it.N <= 0 || it.K2 <= 0 || it.N % 128 || it.K2 % 128) return MMT_ERR_ARG;

@@ -655,3 +655,35 @@ def test_attention_backward_block_schedule_changes_nothing(DH, B, H, S):
                     scheduled=True)
   assert torch.equal(a, b_)
   assert a[:rows].float().abs().sum().item() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,live,per_item', [(2304, None, False), (2304, 2129, False), (2304, 65, False), (4096, 3000, True)])
+def test_wgrad_grouped_256x256_tiles(rows, live, per_item):
+  """wgrad3.hip: the four weight gradients of a d = 1024 layer (256 tiles of 256 x 256) in one launch -- eight-phase schedule
+  on k-major operands, transpose reads, buffer loads whose descriptor ends at the live row count (rows past it must read as
+  ZERO: they hold NaN here), bias gradients from the A fragments on the VALU.  Against torch fp32 on the bf16 operands."""
+  from mmt_amd import ops
+  d, inter = 1024, 6144
+  shapes = [(inter, d), (d, inter), (3 * d, d), (d, d)]  # (N, K2) of dW1, dW2, dWqkv, dWo
+  n = rows if live is None else live
+  counts = [n, max(1, n - 70), max(1, n - 200), n] if per_item else [n] * 4
+  items, refs = [], []
+  for q, (N, K2) in enumerate(shapes):
+    a = _rand((rows, N), 0.5, seed=50 + q, dtype=torch.bfloat16)
+    b = _rand((rows, K2), 0.5, seed=60 + q, dtype=torch.bfloat16)
+    refs.append((a[:counts[q]].float().t() @ b[:counts[q]].float(), a[:counts[q]].float().sum(0)))
+    a[counts[q]:] = float('nan')
+    b[counts[q]:] = float('nan')
+    out = torch.full((N, K2), 3.0, device=_dev())
+    bias = torch.full((N,), 3.0, device=_dev()) if q != 2 else None
+    items.append((a, b, out, bias))
+  nrd = torch.tensor([n], device=_dev(), dtype=torch.int32) if live is not None and not per_item else None
+  ird = torch.tensor(counts, device=_dev(), dtype=torch.int32) if per_item else None
+  ops.wgrad_grouped(items, rows, n_rows_dev=nrd, item_rows_dev=ird)
+  for q, ((a, b, out, bias), (want, wb)) in enumerate(zip(items, refs)):
+    scale = want.abs().max().item()
+    assert torch.isfinite(out).all(), q
+    assert (out - want).abs().max().item() <= 2e-3 * scale + 1e-3, (q, (out - want).abs().max().item(), scale)
+    if bias is not None:
+      assert (bias - wb).abs().max().item() <= 1e-3 * wb.abs().max().item() + 1e-3, q
