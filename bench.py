@@ -176,7 +176,7 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
     name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_phased_kernel)'
     flops = 2.0 * rows * (2 * i * d + 4 * d * d)
     nbytes = rows * (2 * i + 6 * d) * 2 + (2 * i * d + 4 * d * d) * 4
-    subs, grid = ['wgrad_phased_kernel', 'wgrad_grouped_kernel'], None
+    subs, grid = ['wgrad3_kernel', 'wgrad_phased_kernel [grid 256 ', 'wgrad_phased_kernel [grid 1024 ', 'wgrad_grouped_kernel'], None
   tf = flops / sec / 1e12
   if site in (3, 4):
     # at ~110 live tokens per sample neither roof is near (a few % of the MFMA peak, ~15 % of HBM): the launch is bound by

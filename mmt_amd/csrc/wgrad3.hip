@@ -78,9 +78,13 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   for (int q = 1; q < g.count; ++q)
     if (id >= g.item[q].tile_begin) p = q;
   const MmtWgradItem& it = g.item[p];
-  const int tiles_k = it.K2 / 256;
+  const int tiles_k = it.K2 / 256, tiles_n = it.N / 256;
   const int tile = id - it.tile_begin;
-  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  // consecutive tile ids (= one XCD, xcd_remap) share a panel of the LARGER operand: its bytes enter that XCD's L2 once.
+  // (tn-major for all items, PMC: 1.36 GB fetched per launch at configs[4] for 0.53 GB of operands -- dW2's 177 MB B operand
+  // went to four XCDs.)
+  const bool k_major = it.K2 > it.N;
+  const int tn = k_major ? tile % tiles_n : tile / tiles_k, tk = k_major ? tile / tiles_n : tile % tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   const int64_t lda = it.lda, ldb = it.ldb;
   const int nrows = it.reserved > 0 ? it.reserved
