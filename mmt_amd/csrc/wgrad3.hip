@@ -18,11 +18,11 @@
 // The bias gradient (column sums of A) is formed on the VALU from the A fragments the waves of the first tile column hold
 // anyway (under the MFMAs) instead of extra MFMAs that would lengthen exactly the blocks everyone waits for.
 // Measured (configs[4], 14.4 k live rows, same box, alternating): 566 -> 529 us per launch, 0.34 -> 0.365 of the MFMA peak.
-// What bounds it now is the LDS read path: a unit costs 8 waves x 24 KiB of fragment reads either way, but
-// ds_read_b64_tr_b16 moves ~64 B/clk/CU (half of ds_read_b128's rate, tools/wgrad_instr.py): 3 k cycles of reads against
-// 2 k cycles of MFMAs per unit -- phases 1 and 3 (16 transpose reads per wave) are read-bound.  The NT kernel with the
-// same schedule reaches 0.53; closing that gap needs operands that are K-contiguous in memory, i.e. transposed copies
-// written by the producers (eight matrices per layer) -- costed at more than it returns.
+// Not understood yet: the NT kernel with the same schedule keeps the MFMA pipe 67 % busy (the per-CU ingest plateau, DESIGN
+// section 7), this one 42 % (PMC: SQ_VALU_MFMA_BUSY_CYCLES / SIMD / launch cycles, profiles/r04_pmc_config4.txt) with the same
+// bytes per unit.  The fragment path is the difference -- 48 ds_read_b64_tr_b16 per unit and wave against 24 ds_read_b128;
+// SQ_LDS_BANK_CONFLICT counts 0, so it is issue / latency of the transpose reads in front of each barrier rather than
+// conflicts.  First thing to look at next round (per-phase s_memtime ticks as in gemm3.hip's lab build).
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include <type_traits>
