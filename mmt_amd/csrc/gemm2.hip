@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm2_body(
     const int32_t* __restrict__ n_rows_dev, const int bid, const int nblk) {
   constexpr int GW = WGM * WGN;  // waves that tile the output once
   constexpr int NW = PH ? 2 * GW : GW, NT = NW * 64, WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NJ = WTN / 32;
-  static_assert(!PH || NS == 4, "the phased loop runs on a four-deep ring");
+  static_assert(!PH || NS == 4 || NS == 6, "the phased loop runs on a four- or six-deep ring");
   // 8-wave blocks run as two groups in opposite phase (waves w and w+4 share a SIMD): group 0 issues the next
   // stage's LDS-DMA and THEN computes, group 1 computes and THEN issues.  An LDS-DMA instruction stalls its wave for
   // ~100 cycles at issue (measured, tools/gemm_instr.py); staggered, that stall hides under the partner wave's MFMAs.
@@ -155,14 +155,15 @@ __device__ __forceinline__ void gemm2_body(
   // drained inside the loop (raw s_barrier -- __syncthreads() would add vmcnt(0), cdna guide section 5).
   auto issue_ph = [&](int kt) {  // phased mode: the four waves of group kt & 1 load K-step kt
     if (kt < KT) {
-      bf16_t* base = smem + (kt & 3) * STAGE;
+      bf16_t* base = smem + (kt % NS) * STAGE;  // (phased mode: NS = ring depth, 4 or 6)
       stage2<BM, GW>(A, lda, m0, amax, kt * BK, base, wave, lane);
       if constexpr (BKN) stage2_kn<BN, GW>(B, ldb, kt * BK, n0, base + BM * BK, wave, lane);
       else stage2<BN, GW>(B, ldb, n0, bmax, kt * BK, base + BM * BK, wave, lane);
     }
   };
   if constexpr (PH) {
-    if (kg == 0) { issue_ph(0); issue_ph(2); } else { issue_ph(1); }
+    // group g has requested its first NS / 2 own K-steps (g, g + 2, ..) but the last, which goes out in the first half-step
+    if (kg == 0) { issue_ph(0); issue_ph(2); if (NS >= 6) issue_ph(4); } else { issue_ph(1); if (NS >= 6) issue_ph(3); }
   } else {
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
@@ -196,8 +197,9 @@ __device__ __forceinline__ void gemm2_body(
     int nxt = 0;
     if constexpr (PH) {
       const bool mine = (kt & 1) == kg;
-      if (mine) {  // outstanding loads of this wave: K-step kt and (issued one half-step ago) kt + 2, L instructions each
-        if (kt + 2 < KT) wait_vmcnt<L>();
+      if (mine) {  // outstanding loads of this wave: K-steps kt, kt + 2 (and kt + 4 in the six-deep ring), L instructions each
+        if (NS >= 6 && kt + 4 < KT) wait_vmcnt<2 * L>();
+        else if (kt + 2 < KT) wait_vmcnt<L>();
         else wait_vmcnt<0>();
       }
       TICK(t_wait);
@@ -205,9 +207,9 @@ __device__ __forceinline__ void gemm2_body(
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       TICK(t_bar);
-      cur = kt & 3;
+      cur = kt % NS;
       if (!mine) {
-        issue_ph(kt + 3);
+        issue_ph(kt + NS - 1);
         TICK(t_issue);
         continue;
       }
@@ -622,6 +624,9 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 17: if (N % 192 == 0) G2(128, 192, 2, 2, 3); break;  // 4 waves on 128x192 (wave 64x96)
     case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
       if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      break;
+    case 22:  // tile 18 with a SIX-deep ring (144 KiB): every group keeps two of its own K-steps in flight beside the one it waits for
+      if (N % 64 == 0) return launch2<128, 64, 2, 2, 6, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;
     case 20: if (N % 192 == 0) G2(128, 192, 4, 2, 2); break;  // 8 waves on 128x192 (wave 32x96), in phase, TWO-deep ring:
                                                               // 80 KiB of LDS = two blocks per CU (tile 16's three stages allow one)
