@@ -985,10 +985,12 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     }
   }
   // lab switches (same-box A/B): MMT_TILE_NARROW = tile for the packed N < 1024 GEMMs, MMT_TILE_WIDE = tile for N >= 1024
-  static int narrow = -1, wide = -1;
+  static int narrow = -1, wide = -1, longk = 0;
   if (narrow < 0) {
     const char* a = getenv("MMT_TILE_NARROW");
     const char* b = getenv("MMT_TILE_WIDE");
+    const char* c = getenv("MMT_TILE_LONGK");  // tile for the packed narrow GEMMs with K >= 1536 (lab: 23 = gemm4.hip)
+    longk = c ? atoi(c) : 0;
     // r03: the phased 128x64 tile (two 4-wave groups on alternate K-steps, gemm2.hip tile 18) replaces the 8-wave spatial
     // split for the packed narrow GEMMs: step 1.397 -> 1.385 ms same box; K-loop 61.8k -> 52.0k cycles at two blocks per
     // CU (dense rows), 49.5k -> 52.0k at one (what bounds both is the ~22-30 B/clk a CU ingests: 24 KiB per K-step of a
@@ -1004,7 +1006,7 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     const double frac = (lf && atof(lf) > 0.0) ? atof(lf) : 0.52;
     const bool one_round = (double)((M + 127) / 128) * frac * (N / 64) <= 256.0;
     if (narrow && N < 1024 && nr != nullptr && (narrow != 18 || one_round))
-      return mmt_gemm2_dispatch(narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      return mmt_gemm2_dispatch(longk && K >= 1536 && one_round ? longk : narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   }
   if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {

@@ -640,12 +640,17 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
 
 int mmt_gemm3_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
                        int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
+int mmt_gemm4_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 
 // tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved); 21 = the 256x256 eight-phase kernel
 // of gemm3.hip
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   if ((tile & 0xff) == 21) return mmt_gemm3_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if ((tile & 0xff) == 23) {  // producer / consumer 128 x 64 (gemm4.hip)
+    return mmt_gemm4_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  }
   switch (epilogue) {
     case MMT_EPI_BF16: return pick2<MMT_EPI_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     case MMT_EPI_BIAS_BF16: return pick2<MMT_EPI_BIAS_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

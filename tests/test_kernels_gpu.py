@@ -96,7 +96,7 @@ def test_gemm_nt_fused_epilogues(tile):
   _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
 
 
-@pytest.mark.parametrize('tile', [3, 4, 5, 7, 10, 11, 12, 13, 14, 18, 19, 22])
+@pytest.mark.parametrize('tile', [3, 4, 5, 7, 10, 11, 12, 13, 14, 18, 19, 22, 23])
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (777, 512, 192), (7168, 1536, 512), (3583, 512, 3072), (640, 512, 64)])
 def test_gemm_nt_wide_tiles(tile, M, N, K):
   """gemm2.hip (256x128 / 256x256 / 128x128 / 128x256 tiles, 32x32x16 MFMA, LDS-staged epilogue): every epilogue."""
