@@ -15,14 +15,15 @@
 //     64 x 32 quadrant = 16 MFMAs (512 cycles, as the NT kernel's 8 of 32x32x16);
 //   * LDS-DMA by buffer_load ... lds with the descriptor re-based per unit and num_records cut at the live row count: the
 //     rows of a ragged last unit read as zeros (no zero-fill pass, no clamping).
-// The bias gradient (column sums of A) is formed on the VALU from the A fragments the waves of the first tile column hold
-// anyway (under the MFMAs) instead of extra MFMAs that would lengthen exactly the blocks everyone waits for.
-// Measured (configs[4], 14.4 k live rows, same box, alternating): 566 -> 529 us per launch, 0.34 -> 0.365 of the MFMA peak.
-// Not understood yet: the NT kernel with the same schedule keeps the MFMA pipe 67 % busy (the per-CU ingest plateau, DESIGN
-// section 7), this one 42 % (PMC: SQ_VALU_MFMA_BUSY_CYCLES / SIMD / launch cycles, profiles/r04_pmc_config4.txt) with the same
-// bytes per unit.  The fragment path is the difference -- 48 ds_read_b64_tr_b16 per unit and wave against 24 ds_read_b128;
-// SQ_LDS_BANK_CONFLICT counts 0, so it is issue / latency of the transpose reads in front of each barrier rather than
-// conflicts.  First thing to look at next round (per-phase s_memtime ticks as in gemm3.hip's lab build).
+// The bias gradient (column sums of A) is formed on the VALU from the A fragments the blocks of the first tile column hold
+// anyway: four v_dot2c per fragment and k-sub-step, fragment wn by wave wn of a wave row (all four hold the same fragments).
+// The first version summed all eight fragments in ONE wave by shift / and / add (~100 VALU instructions in each of phases 1
+// and 3): those waves reached their barriers ~450 cycles late, and since every block is one per CU the launch waited for
+// them -- ~100 of 508 us (parts-off lab: tools/wgrad3_lab.py).
+// Measured (configs[4], 14.4 k live rows): 566 -> 479 us per launch inside the step, 0.34 -> 0.40 of the MFMA peak.  Parts-off
+// lab (tools/wgrad3_lab.py): the transpose reads cost nothing against plain 8-byte reads, and with the fragment reads OR the
+// MFMAs compiled out the launch still takes ~425 us -- a skeleton of requests, waits and barriers (the NT kernel with the same
+// schedule: 0.53); DESIGN section 7.
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include <type_traits>
@@ -35,10 +36,19 @@
 
 #define W3_TIE(x) asm volatile("" : "+v"(x))
 // one fragment = 16 columns x 32 contracted rows: two transpose reads 16 rows (4096 bytes) apart
+#if defined(MMT_W3_LAB_NOREADS)  // lab (wrong results): no fragment reads at all
+#define W3_RD(lo, hi, base, OFF) do { asm volatile("" : "=v"(lo) : "v"(base)); asm volatile("" : "=v"(hi) : "v"(base)); } while (0)
+#elif defined(MMT_W3_LAB_PLAINREADS)  // lab (wrong results): the same bytes by plain 8-byte reads
+#define W3_RD(lo, hi, base, OFF) do {                                                          \
+    asm volatile("ds_read_b64 %0, %1 offset:" #OFF : "=v"(lo) : "v"(base));                   \
+    asm volatile("ds_read_b64 %0, %1 offset:" #OFF "+4096" : "=v"(hi) : "v"(base));           \
+  } while (0)
+#else
 #define W3_RD(lo, hi, base, OFF) do {                                                          \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(lo) : "v"(base));            \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF "+4096" : "=v"(hi) : "v"(base));    \
   } while (0)
+#endif
 
 template <int N> __device__ __forceinline__ void w3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void w3_vmwait_rt(int n) {  // (wave-uniform n from {0, 2, 4, 6, 8})
@@ -57,15 +67,25 @@ __device__ __forceinline__ bf16x8_t w3_join(const u32x2& lo, const u32x2& hi) {
   const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
-// sum of the 8 bf16 values of a fragment register set (fp32)
+// acc + the sum of the 8 bf16 values of a fragment register set: four v_dot2c_f32_bf16 against (1, 1)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float w3_sum8(const u32x2& lo, const u32x2& hi, float acc) {
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    acc += __uint_as_float(lo[e] << 16) + __uint_as_float(lo[e] & 0xffff0000u);
-    acc += __uint_as_float(hi[e] << 16) + __uint_as_float(hi[e] & 0xffff0000u);
-  }
+  const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+  // (elements into scalars first: __builtin_bit_cast of a vector ELEMENT yields element 0 with this compiler)
+  const unsigned a0 = lo[0], a1 = lo[1], a2 = hi[0], a3 = hi[1];
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a0), ones, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a1), ones, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2), ones, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a3), ones, acc, false);
   return acc;
 }
+// the bias sums of fragment I (both k-sub-steps) -- wave wn of a wave row takes fragment wn: the four waves hold the same A
+// fragments, so the work is spread over them and no wave's phase grows by more than eight instructions
+#define W3_BSUM(DST, I) do { DST = w3_sum8(fal[I][0], fah[I][0], DST); DST = w3_sum8(fal[I][1], fah[I][1], DST); } while (0)
+#define W3_BSUM_MINE(DST) do {                                        \
+    if (wn == 0) W3_BSUM(DST, 0); else if (wn == 1) W3_BSUM(DST, 1);  \
+    else if (wn == 2) W3_BSUM(DST, 2); else W3_BSUM(DST, 3);          \
+  } while (0)
 
 __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   extern __shared__ __attribute__((aligned(256))) unsigned char smem_raw[];
@@ -91,14 +111,14 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
                     : it.n_rows_dev ? min(*it.n_rows_dev, g.rows)
                                     : (g.n_rows_dev ? min(*g.n_rows_dev, g.rows) : g.rows);
   const int KT = (nrows + 63) >> 6;  // units of 64 contracted rows
-  const bool want_bias = it.bias_out != nullptr && tk == 0 && wn == 0;
+  const bool want_bias = it.bias_out != nullptr && tk == 0;
 
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bs_top = 0.f, bs_bot = 0.f;  // column sums of A over this lane's contracted rows: fragment wn of the top / bottom half
 
   // ---- LDS-DMA sources: this wave moves rows 8 wave + 4 i + (lane >> 4), i = 0, 1, of every half-tile; 16 lanes x 16 B per
   // row segment; the LDS image is lane-linear and the 16-byte chunk c of row r lies at chunk c ^ ((r & 7) << 1), i.e. the
@@ -148,10 +168,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   const unsigned b_off = t_off ^ (unsigned)(wn * 32 * 2);   // + (j << 5) per fragment
 
   // ---- prologue: unit 0 complete, A-top and B-left of unit 1 ----
-  if (KT <= 0) {  // nothing to contract: the gradient is zero
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
-  } else {
+  if (KT > 0) {  // (nothing to contract: the gradient is zero)
   W3_DMA_AT(0); W3_DMA_BL(0); W3_DMA_BR(0); W3_DMA_AB(0);
   if (KT > 1) { W3_DMA_AT(1); W3_DMA_BL(1); w3_vmwait<8>(); }
   else w3_vmwait<4>();
@@ -161,7 +178,11 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   // fragment registers: A fragments of the current row half (4 fragments x 2 k-sub-steps), right B fragments, left B fragments
   // of the current / next unit
   u32x2 fal[4][2], fah[4][2], frl[2][2], frh[2][2], fll[2][2][2], flh[2][2][2];
+#ifdef MMT_W3_LAB_NOMFMA  // lab (wrong results): the operands are consumed by one cheap op, the matrix pipe idles
+#define W3_MFMA(I, J, BL_, BH_, AL_, AH_) acc[I][J][0] += __uint_as_float(BL_[0] ^ AH_[1])
+#else
 #define W3_MFMA(I, J, BL_, BH_, AL_, AH_) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3_join(BL_, BH_), w3_join(AL_, AH_), acc[I][J], 0, 0, 0)
+#endif
 #define W3_SEG_BEGIN() do { w3_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_setprio(1); } while (0)
 #define W3_SEG_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); w3_barrier(); } while (0)
   {  // left B fragments of unit 0 (landed: the prologue's wait)
@@ -198,12 +219,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) W3_MFMA(i, j, fll[CUR][j][ks], flh[CUR][j][ks], fal[i][ks], fah[i][ks]);
-    if (want_bias) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bsum[i] = w3_sum8(fal[i][ks], fah[i][ks], bsum[i]);
-    }
+    if (want_bias) W3_BSUM_MINE(bs_top);
     W3_SEG_END();
     // ---- phase 2: quadrant (top, right) ----
     {
@@ -246,12 +262,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) W3_MFMA(4 + i, 2 + j, frl[j][ks], frh[j][ks], fal[i][ks], fah[i][ks]);
-    if (want_bias) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bsum[4 + i] = w3_sum8(fal[i][ks], fah[i][ks], bsum[4 + i]);
-    }
+    if (want_bias) W3_BSUM_MINE(bs_bot);
     W3_SEG_END();
     // ---- phase 4: quadrant (bottom, left): its fragments are in registers; the NEXT unit's left B fragments are read ----
     if (!last) {
@@ -294,10 +305,14 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
         }
       }
     }
-    if (want_bias) {  // the four lane groups hold the sums of different contracted rows
-      float b = bsum[i];
+  }
+  if (want_bias) {  // the four lane groups hold the sums of different contracted rows; this wave owns fragments wn and 4 + wn
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float b = h ? bs_bot : bs_top;
       b += __shfl_xor(b, 16, 64);
       b += __shfl_xor(b, 32, 64);
+      const int n = n0 + wm * 128 + h * 64 + wn * 16 + li;
       if (lg == 0 && n < it.N_out) it.bias_out[n] = b;
     }
   }
