@@ -142,9 +142,8 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
     constexpr int SHIFT = decltype(shift_c)::value;  // byte shift of the half-tile's columns: the SCALAR offset (an immediate
     // instruction offset would move the LDS destination as well)
     const int rows_left = nrows - u * 64;  // > 0; rows past it read as zeros (beyond num_records)
-    const int64_t bytes = (int64_t)min(rows_left, 64) * ld * 2;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)u * 64 * ld), 0, (int)(bytes > 0x7fffffff ? 0x7fffffff : bytes), 0x00020000);
+    const int bytes = min(rows_left, 64) * ((int)ld * 2);  // (<= 64 rows of <= 2^20 elements: 32-bit scalar arithmetic)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)u * 64 * ld), 0, bytes, 0x00020000);
     unsigned char* dst = smem_raw + (u & 1) * W3_BUF + half;
 #pragma unroll
     for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + lrow[i]), 16, (int)o[i], SHIFT, 0, 0);
