@@ -16,7 +16,8 @@
 //   * LDS-DMA by buffer_load ... lds with the descriptor re-based per unit and num_records cut at the live row count: the
 //     rows of a ragged last unit read as zeros (no zero-fill pass, no clamping).
 // The bias gradient (column sums of A) is formed on the VALU from the A fragments the blocks of the first tile column hold
-// anyway: four v_dot2c per fragment and k-sub-step, fragment wn by wave wn of a wave row (all four hold the same fragments).
+// anyway: two MFMAs against an all-ones operand per phase, fragment wn by wave wn of a wave row (all four hold the same
+// fragments; v_dot2c on the VALU was tried: ~20 cycles apiece beside the MFMAs, 170 per phase against ~35 for the two MFMAs).
 // The first version summed all eight fragments in ONE wave by shift / and / add (~100 VALU instructions in each of phases 1
 // and 3): those waves reached their barriers ~450 cycles late, and since every block is one per CU the launch waited for
 // them -- ~100 of 508 us (parts-off lab: tools/wgrad3_lab.py).
@@ -81,11 +82,25 @@ __device__ __forceinline__ float w3_sum8(const u32x2& lo, const u32x2& hi, float
 }
 // the bias sums of fragment I (both k-sub-steps) -- wave wn of a wave row takes fragment wn: the four waves hold the same A
 // fragments, so the work is spread over them and no wave's phase grows by more than eight instructions
-#define W3_BSUM(DST, I) do { DST = w3_sum8(fal[I][0], fah[I][0], DST); DST = w3_sum8(fal[I][1], fah[I][1], DST); } while (0)
+#ifdef MMT_W3_BIAS_DOT2  // (the VALU form: ~20 cycles per v_dot2c beside the MFMAs, 170 per phase -- tools/wgrad3_budget.py)
+#define W3_BSUM(DST, I) do { DST[0] = w3_sum8(fal[I][0], fah[I][0], DST[0]); DST[0] = w3_sum8(fal[I][1], fah[I][1], DST[0]); } while (0)
+#else  // two more MFMAs against an all-ones operand: every lane of a column ends up with the column's sum over the unit
+#define W3_BSUM(DST, I) do {                                                                                                  \
+    DST = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, w3_join(fal[I][0], fah[I][0]), DST, 0, 0, 0);                           \
+    DST = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, w3_join(fal[I][1], fah[I][1]), DST, 0, 0, 0);                           \
+  } while (0)
+#endif
 #define W3_BSUM_MINE(DST) do {                                        \
     if (wn == 0) W3_BSUM(DST, 0); else if (wn == 1) W3_BSUM(DST, 1);  \
     else if (wn == 2) W3_BSUM(DST, 2); else W3_BSUM(DST, 3);          \
   } while (0)
+
+#ifdef MMT_GEMM2_INSTR
+__device__ long long* g_wgrad3_dbg = nullptr;  // [blocks][2 groups][20]
+extern "C" int mmt_debug_set_wgrad3_buffer(long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad3_dbg), &p, sizeof(p));
+}
+#endif
 
 __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   extern __shared__ __attribute__((aligned(256))) unsigned char smem_raw[];
@@ -118,7 +133,10 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bs_top = 0.f, bs_bot = 0.f;  // column sums of A over this lane's contracted rows: fragment wn of the top / bottom half
+  f32x4 bs_top = {0.f, 0.f, 0.f, 0.f}, bs_bot = {0.f, 0.f, 0.f, 0.f};  // column sums of A: fragment wn of the top / bottom half
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   // ---- LDS-DMA sources: this wave moves rows 8 wave + 4 i + (lane >> 4), i = 0, 1, of every half-tile; 16 lanes x 16 B per
   // row segment; the LDS image is lane-linear and the 16-byte chunk c of row r lies at chunk c ^ ((r & 7) << 1), i.e. the
@@ -182,8 +200,20 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
 #else
 #define W3_MFMA(I, J, BL_, BH_, AL_, AH_) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3_join(BL_, BH_), w3_join(AL_, AH_), acc[I][J], 0, 0, 0)
 #endif
-#define W3_SEG_BEGIN() do { w3_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_setprio(1); } while (0)
-#define W3_SEG_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); w3_barrier(); } while (0)
+  // lab build (python -m mmt_amd.build --instr): per-phase s_memtime ticks, as gemm3.hip -- [phase][0] reads + requests + vmcnt,
+  // [1] barrier, [2] lgkm wait + 16 MFMAs, [3] barrier; read back by tools/wgrad3_budget.py through mmt_debug_set_wgrad3_buffer
+#ifdef MMT_GEMM2_INSTR
+  long long w3t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, w3p = clock64();
+  const long long w3t0 = w3p;
+  int w3ph = 0;
+#define W3_TICK(k) do { const long long n_ = clock64(); w3t[w3ph * 4 + (k)] += n_ - w3p; w3p = n_; } while (0)
+#define W3_PHASE(p) w3ph = (p)
+#else
+#define W3_TICK(k) do {} while (0)
+#define W3_PHASE(p) do {} while (0)
+#endif
+#define W3_SEG_BEGIN() do { W3_TICK(0); w3_barrier(); W3_TICK(1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_setprio(1); } while (0)
+#define W3_SEG_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); W3_TICK(2); w3_barrier(); W3_TICK(3); } while (0)
   {  // left B fragments of unit 0 (landed: the prologue's wait)
     const unsigned xb = lds0 + W3_BL + b_off;
     W3_RD(fll[0][0][0], flh[0][0][0], xb, 0); W3_RD(fll[0][0][1], flh[0][0][1], xb, 8192);
@@ -194,6 +224,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
     const unsigned bo = lds0 + (unsigned)(t & 1) * W3_BUF, bn = lds0 + (unsigned)((t & 1) ^ 1) * W3_BUF;
     const bool last = t + 1 >= KT, last2 = t + 2 >= KT;
     // ---- phase 1: quadrant (top, left) ----
+    W3_PHASE(0);
     {
       const unsigned xa = bo + W3_AT + a_off;
       W3_RD(fal[0][0], fah[0][0], xa, 0);        W3_RD(fal[0][1], fah[0][1], xa, 8192);
@@ -221,6 +252,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
     if (want_bias) W3_BSUM_MINE(bs_top);
     W3_SEG_END();
     // ---- phase 2: quadrant (top, right) ----
+    W3_PHASE(1);
     {
       const unsigned xb = bo + W3_BR + b_off;
       W3_RD(frl[0][0], frh[0][0], xb, 0);        W3_RD(frl[0][1], frh[0][1], xb, 8192);
@@ -241,6 +273,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
         for (int i = 0; i < 4; ++i) W3_MFMA(i, 2 + j, frl[j][ks], frh[j][ks], fal[i][ks], fah[i][ks]);
     W3_SEG_END();
     // ---- phase 3: quadrant (bottom, right) ----
+    W3_PHASE(2);
     {
       const unsigned xa = bo + W3_AB + a_off;
       W3_RD(fal[0][0], fah[0][0], xa, 0);        W3_RD(fal[0][1], fah[0][1], xa, 8192);
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
     if (want_bias) W3_BSUM_MINE(bs_bot);
     W3_SEG_END();
     // ---- phase 4: quadrant (bottom, left): its fragments are in registers; the NEXT unit's left B fragments are read ----
+    W3_PHASE(3);
     if (!last) {
       const unsigned yb = bn + W3_BL + b_off;
       W3_RD(fll[NXT][0][0], flh[NXT][0][0], yb, 0);        W3_RD(fll[NXT][0][1], flh[NXT][0][1], yb, 8192);
@@ -285,6 +319,13 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   }
   if (wm == 0) w3_barrier();  // group 0 catches up with the extra barrier group 1 took
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MMT_GEMM2_INSTR
+  if (g_wgrad3_dbg && (tid == 0 || tid == 256)) {  // wave 0 of either group
+    long long* d = g_wgrad3_dbg + ((int64_t)blockIdx.x * 2 + wm) * 20;
+    for (int k = 0; k < 16; ++k) d[k] = w3t[k];
+    d[16] = clock64() - w3t0; d[17] = KT; d[18] = want_bias ? 1 : 0;
+  }
+#endif
   }
   // ---- store: acc[i][j][e] = out[n0 + 128 wm + 64 (i >> 2) + 16 (i & 3) + li][k0 + 64 wn + 32 (j >> 1) + 16 (j & 1) + 4 lg + e] ----
   float* __restrict__ out = it.out;
@@ -308,9 +349,11 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(MmtWgradGroup g) {
   if (want_bias) {  // the four lane groups hold the sums of different contracted rows; this wave owns fragments wn and 4 + wn
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float b = h ? bs_bot : bs_top;
+      float b = h ? bs_bot[0] : bs_top[0];
+#ifdef MMT_W3_BIAS_DOT2
       b += __shfl_xor(b, 16, 64);
       b += __shfl_xor(b, 32, 64);
+#endif
       const int n = n0 + wm * 128 + h * 64 + wn * 16 + li;
       if (lg == 0 && n < it.N_out) it.bias_out[n] = b;
     }
