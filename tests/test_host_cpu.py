@@ -226,3 +226,21 @@ def test_flat_minibatch_layout_is_device_independent():
   assert a.flat.numel() == b.flat.numel() and torch.equal(a.flat, b.flat)
   assert torch.equal(b['features']['ocr'], mb['features']['ocr'])
   assert b['features']['ocr'].data_ptr() >= b.flat.data_ptr()
+
+
+def test_bench_refuses_captured_collectives_on_several_gpus():
+  """bench.py --capture-collectives was only ever exercised on a 1-rank RCCL group: with --gpus > 1 it must refuse (and say how
+  to override) BEFORE any rank is spawned or any GPU is touched, so that a multi-GPU driver run cannot pick the unvalidated path."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  env.pop('MMT_ALLOW_CAPTURED_COLLECTIVES', None)
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--capture-collectives'], env=env,
+                     capture_output=True, text=True, timeout=300)
+  out = r.stdout + r.stderr
+  assert 'refusing --gpus 2' in out and 'MMT_ALLOW_CAPTURED_COLLECTIVES' in out
+  assert '"metric"' not in out  # no result line
