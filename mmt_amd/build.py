@@ -27,12 +27,18 @@ def _newest(paths):
   return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False, instr=False):
-  """instr=True builds a separate lab library (cycle counters inside gemm2's K-loop, tools/gemm_instr.py)."""
+def build(force=False, verbose=False, instr=False, lab=False):
+  """The product library holds the tiles the dispatcher selects.  lab=True builds libmmt_hip_lab.so with every tile that was
+  measured and lost as well (-DMMT_LAB_TILES: tools/gemm_lab.py, the MMT_TILE_* switches, the lab-only parity cases);
+  instr=True builds libmmt_hip_instr.so = the lab tiles + s_memtime cycle counters inside the GEMM loops
+  (tools/gemm_instr.py, tools/gemm2_budget.py, tools/g5_budget.py).  Use either through MMT_HIP_LIB=<path>."""
   global OBJ, LIB, FLAGS
   if instr:
     OBJ, LIB = os.path.join(HERE, 'lib', 'obj_instr'), os.path.join(HERE, 'lib', 'libmmt_hip_instr.so')
-    FLAGS = FLAGS + ['-DMMT_GEMM2_INSTR'] + ['-D' + d for d in os.environ.get('MMT_LAB_DEFINES', '').split() if d]
+    FLAGS = FLAGS + ['-DMMT_GEMM2_INSTR', '-DMMT_G5_INSTR', '-DMMT_LAB_TILES'] + ['-D' + d for d in os.environ.get('MMT_LAB_DEFINES', '').split() if d]
+  elif lab:
+    OBJ, LIB = os.path.join(HERE, 'lib', 'obj_lab'), os.path.join(HERE, 'lib', 'libmmt_hip_lab.so')
+    FLAGS = FLAGS + ['-DMMT_LAB_TILES'] + ['-D' + d for d in os.environ.get('MMT_LAB_DEFINES', '').split() if d]
   os.makedirs(OBJ, exist_ok=True)
   sources = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
   headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))
@@ -67,4 +73,4 @@ def build(force=False, verbose=False, instr=False):
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv, verbose=True, instr='--instr' in sys.argv))
+  print(build(force='--force' in sys.argv, verbose=True, instr='--instr' in sys.argv, lab='--lab' in sys.argv))

@@ -926,6 +926,9 @@ static int wide192_tile(int M, int N, bool packed) {
     forced1536 = b ? atoi(b) : 0;
     if (f && atof(f) > 0.0) live_fraction = atof(f);
     enabled = en ? atoi(en) : 0;  // the r02 one-block-per-CU tiles 15 / 16 (whole-step A/B: 1.473 ms off vs 1.485 ms on); MMT_TILE_192=3: tile 20 below
+#ifndef MMT_LAB_TILES
+    forced3072 = forced1536 = enabled = 0;  // (the 192-wide tiles exist in the lab library only)
+#endif
   }
   if (N == 3072 && forced3072) return forced3072;
   if (N == 1536 && forced1536) return forced1536;
@@ -991,6 +994,9 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     const char* b = getenv("MMT_TILE_WIDE");
     const char* c = getenv("MMT_TILE_LONGK");  // tile for the packed narrow GEMMs with K >= 1536 (lab: 23 = gemm4.hip)
     longk = c ? atoi(c) : 0;
+#ifndef MMT_LAB_TILES
+    longk = 0;  // (tile 23 = gemm4.hip exists in the lab library only)
+#endif
     // r03: the phased 128x64 tile (two 4-wave groups on alternate K-steps, gemm2.hip tile 18) replaces the 8-wave spatial
     // split for the packed narrow GEMMs: step 1.397 -> 1.385 ms same box; K-loop 61.8k -> 52.0k cycles at two blocks per
     // CU (dense rows), 49.5k -> 52.0k at one (what bounds both is the ~22-30 B/clk a CU ingests: 24 KiB per K-step of a
@@ -1008,6 +1014,21 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     if (narrow && N < 1024 && nr != nullptr && (narrow != 18 || one_round))
       return mmt_gemm2_dispatch(longk && K >= 1536 && one_round ? longk : narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    // r05: the persistent wave-specialised kernel (gemm5.hip, tile 24) for the wide K = hidden GEMMs once a CU gets >= 4 tiles of
+    // 128 x 128 (its first K-loop and last epilogue are not overlapped with anything: two tiles' worth of every block).  Same-box
+    // A/B of the whole step (r05): headline, 696 live tiles = 2.7 per CU: 1.2934 vs 1.2816 ms with it (lab: 24.7 vs 26.5 us
+    // warm, but 31 vs 28 us inside the step for FFN-up); dense rows (1320+ tiles) 1.8355 vs 1.8680 ms.
+    // MMT_TILE_PP = 0 off, 1 (default) >= 1024 estimated live tiles, 2 >= 512.
+    static int pp = -1;
+    if (pp < 0) {
+      const char* q = getenv("MMT_TILE_PP");
+      pp = q ? atoi(q) : 1;
+    }
+    if (pp && N >= 1024 && N % 128 == 0 && K >= 128 && K <= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
+      const double frac2 = nr ? frac : 1.0;
+      if ((double)((M + 127) / 128) * frac2 * (N / 128) >= (pp >= 2 ? 512.0 : 1024.0))
+        return mmt_gemm2_dispatch(24, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    }
   }
   if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
     const int t = wide192_tile(M, N, nr != nullptr);

@@ -468,6 +468,8 @@ static int splitk_impl(const void* A, int64_t lda, const void* B, int64_t ldb, v
     return MMT_ERR_ALIGN;
   MmtEpilogue e = {};
   if (epi) e = *epi;
+  // the row-dot sums exist in the bf16 epilogue only and need their partner matrix
+  if (e.dot_out && !no_epilogue && (!e.dot_src || epilogue != MMT_EPI_BF16)) return MMT_ERR_ARG;
   const int ksteps = K / BK;
   if (splits <= 0) splits = 16;
   if (splits > ksteps) splits = ksteps;
@@ -608,7 +610,16 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
 #define G2(BM_, BN_, WGM_, WGN_, NS_) \
   return launch2<BM_, BN_, WGM_, WGN_, NS_, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s)
   if (EPI == MMT_EPI_DGELU && e.colsum && (tile & 0xff) == 12) return MMT_ERR_ARG;  // 64-row tiles: no column sums
+  // The tiles the dispatcher selects on its own (gemm.hip: dispatch_tile): 13, 14, 18 (+ 21 = gemm3.hip, 24 = gemm5.hip).
+  // Everything else was measured and lost and is compiled into the LAB library only
+  // (python -m mmt_amd.build --lab: -DMMT_LAB_TILES), where tools/gemm_lab.py and the MMT_TILE_* switches reach it.
   switch (tile & 0xff) {
+    case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
+    case 14: if (N % 128 == 0) G2(128, 128, 2, 4, 2); break;  // 8 waves on 128x128, in phase, 2 blocks/CU
+    case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
+      if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      break;
+#ifdef MMT_LAB_TILES
     case 3: if (N % 128 == 0) G2(256, 128, 4, 2, 3); break;   // 8 waves, staggered
     case 4: if (N % 256 == 0) G2(256, 256, 4, 2, 2); break;   // 8 waves
     case 5: if (N % 128 == 0) G2(128, 128, 2, 2, 2); break;   // 4 waves, 2 blocks/CU
@@ -616,15 +627,10 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 10: if (N % 128 == 0) G2(256, 128, 4, 2, 2); break;  // 8 waves, in phase
     case 11: if (N % 128 == 0) G2(128, 128, 2, 4, 3); break;  // 8 waves on 128x128 (wave 64x32), staggered
     case 12: if (N % 128 == 0) G2(64, 128, 2, 4, 3); break;   // 8 waves on 64x128 (wave 32x32), staggered, 2 blocks/CU
-    case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
-    case 14: if (N % 128 == 0) G2(128, 128, 2, 4, 2); break;  // 8 waves on 128x128, in phase, 2 blocks/CU
     case 15: if (N % 192 == 0) G2(256, 192, 4, 2, 2); break;  // 8 waves on 256x192 (wave 64x96), 1 block/CU: N = 3072 at
                                                               // <= 4096 live rows is ONE round of <= 256 tiles
     case 16: if (N % 192 == 0) G2(128, 192, 4, 2, 3); break;  // 8 waves on 128x192 (wave 32x96), staggered
     case 17: if (N % 192 == 0) G2(128, 192, 2, 2, 3); break;  // 4 waves on 128x192 (wave 64x96)
-    case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
-      if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-      break;
     case 22:  // tile 18 with a SIX-deep ring (144 KiB): every group keeps two of its own K-steps in flight beside the one it waits for
       if (N % 64 == 0) return launch2<128, 64, 2, 2, 6, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;
@@ -633,6 +639,7 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
     case 19:  // 2 x 4 waves on 128x128, PHASED (wave tile 64x64)
       if (N % 128 == 0) return launch2<128, 128, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;
+#endif
   }
 #undef G2
   return MMT_ERR_ARG;
@@ -642,15 +649,22 @@ int mmt_gemm3_dispatch(int epilogue, const void* A, int64_t lda, const void* B, 
                        int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 int mmt_gemm4_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
                        int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
+int mmt_gemm5_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
+                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 
 // tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved); 21 = the 256x256 eight-phase kernel
 // of gemm3.hip
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   if ((tile & 0xff) == 21) return mmt_gemm3_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  if ((tile & 0xff) == 23) {  // producer / consumer 128 x 64 (gemm4.hip)
-    return mmt_gemm4_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if ((tile & 0xff) == 24) {  // persistent, wave-specialised 128 x 128 (gemm5.hip) where its geometry allows, else tile 14 / 13
+    const int rc = mmt_gemm5_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    if (rc != MMT_ERR_ARG) return rc;
+    tile = (N % 128 == 0 && !(epilogue == MMT_EPI_DGELU && e.colsum && M < 128)) ? 14 : 13;
   }
+#ifdef MMT_LAB_TILES
+  if ((tile & 0xff) == 23) return mmt_gemm4_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);  // producer / consumer 128 x 64 (gemm4.hip)
+#endif
   switch (epilogue) {
     case MMT_EPI_BF16: return pick2<MMT_EPI_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     case MMT_EPI_BIAS_BF16: return pick2<MMT_EPI_BIAS_BF16>(tile, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

@@ -8,6 +8,7 @@
 // five-deep ring of 24 KiB stages, three K-steps in flight, counted vmcnt), waves 0-3 (64 x 32 wave tiles, one per SIMD) do
 // nothing but read fragments and run MFMAs; one workgroup barrier per K-step hands a landed stage to the consumers and a
 // consumed one back to the producers.  The producers leave before the epilogue (finished waves do not count in barriers).
+#ifdef MMT_LAB_TILES  // (lab library only: python -m mmt_amd.build --lab)
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include "gemm_epi.h"
@@ -167,3 +168,4 @@ int mmt_gemm4_dispatch(int epilogue, const void* A, int64_t lda, const void* B, 
   }
   return MMT_ERR_ARG;
 }
+#endif  // MMT_LAB_TILES

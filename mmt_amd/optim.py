@@ -326,10 +326,17 @@ def load_merged_state_dict(model, optimizers, sd):
               raise ValueError('optimizer state for a parameter this optimizer has never stepped: load before the first step')
             continue
           for k in ('step', 'exp_avg', 'exp_avg_sq'):
-            if st is None:
-              cur[k].zero_()
+            if st is None:  # never stepped in the checkpoint: no moments of THIS run may survive
+              if torch.is_tensor(cur[k]):
+                cur[k].zero_()
+              else:
+                cur[k] = 0
             elif torch.is_tensor(cur[k]):
-              cur[k].copy_(torch.as_tensor(st[k]).to(cur[k].dtype))
+              src = torch.as_tensor(st[k])
+              if src.numel() != cur[k].numel() or (src.dim() and cur[k].dim() and tuple(src.shape) != tuple(cur[k].shape)):
+                raise ValueError("optimizer checkpoint: '%s' of parameter %d has shape %s, this optimizer holds %s"
+                                 % (k, local, tuple(src.shape), tuple(cur[k].shape)))
+              cur[k].copy_(src.to(cur[k].dtype).reshape(cur[k].shape))
             else:
               cur[k] = st[k]
         for k, v in g.items():

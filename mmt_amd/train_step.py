@@ -223,6 +223,13 @@ class GraphedTrainStep:
     self._wire = mdist.WireBuffer(grad_dtype, grad_algo)
     self.syncs = [mdist.GradSync(f, rest if i == 0 else (), group, grad_dtype=grad_dtype, algo=grad_algo)
                   for i, f in enumerate(flats)]
+    # sharded optimizer: flat buffer -> its optimizer, the whole-buffer spans of the un-staged step, the all-reduce
+    # bucket of the parameters outside the flat buffers -- built once (they used to be rebuilt on every step), and the
+    # (flat, offset, count) spans the shards of the last step were cut from (optimizer_state_dict gathers along them)
+    self._opt_of = {id(o.flat): o for o in self.opt_flats}
+    self._whole_regions = {'flat%d' % i: (o.flat, 0, o.flat.count) for i, o in enumerate(self.opt_flats)}
+    self._rest_sync = mdist.GradSync(None, rest, group) if self.shard_opt else None
+    self._shard_spans = []
     self._exposed = []  # (event before, event after) around the final wait for the staged reductions, last steps
     self.sync = self.syncs[0]
     self._extra_flats = flats[1:]
@@ -632,8 +639,9 @@ class GraphedTrainStep:
         fin()
       return
     seen = set()
+    self._shard_spans = [(r['flat'], r['off'], r['cnt']) for _, r in handles]
     for _, r in handles:
-      opt = self.opt_flats[[id(o.flat) for o in self.opt_flats].index(id(r['flat']))]
+      opt = self._opt_of[id(r['flat'])]
       grad = self._wire.shard_f32(r['span'], r['shard'])
       opt.step_shard(r['off'] + r['lo'], r['own'], grad, first=id(opt) not in seen)
       seen.add(id(opt))
@@ -661,11 +669,14 @@ class GraphedTrainStep:
 
   def _sync_all(self):
     if self.shard_opt:  # every flat buffer as ONE span; parameters outside them keep the all-reduce bucket
-      self._regions = {'flat%d' % i: (o.flat, 0, o.flat.count) for i, o in enumerate(self.opt_flats)}
+      # NOTE: in shard mode the flat gradient buffers are never reduced as a whole -- after the step a rank holds the
+      # global sum only inside the shard buffers of `_wire`; flat.current_grad() keeps the rank-LOCAL gradients (anything
+      # that reads gradients after the step -- norm logging, clipping -- must not assume they are global).
+      self._regions = self._whole_regions
       for o in self.opt_flats:
         mdist.gather_stray_grads(o.flat)
       self._finish(self._reduce_async(list(self._regions)))
-      mdist.GradSync(None, self.sync.other, self.group).sync(force=self._force_coll)
+      self._rest_sync.sync(force=self._force_coll)
       return
     for sy in self.syncs:
       sy.sync(force=self._force_coll)
@@ -674,7 +685,27 @@ class GraphedTrainStep:
     """The optimizer state of the step as the REFERENCE would have checkpointed it: one torch.optim.Adam state dict over
     filter(requires_grad, model.parameters()) (train.py:95-100, base/base_trainer.py:353-365)."""
     from .optim import merged_state_dict
+    self._gather_sharded_moments()
     return merged_state_dict(self.model, self.opt_flats + [self.opt_rest])
+
+  def _gather_sharded_moments(self):
+    """Sharded optimizer: a rank has updated exp_avg / exp_avg_sq only inside ITS shard of every span, so a checkpoint
+    written from one rank's buffers would pair a non-zero step count with stale moments for (N-1)/N of the parameters.
+    All-gather the moment shards along the geometry the last step cut them with (`WireBuffer.all_gather_span`: the same
+    rank * per offsets as the reduce-scatter).  COLLECTIVE: every rank of the group must call optimizer_state_dict()
+    (the one that writes the file is then free to be rank 0 alone, base/base_trainer.py:353-365)."""
+    if not (self.shard_opt and self._multi) or not self._shard_spans:
+      return
+    with torch.no_grad():
+      for flat, off, cnt in self._shard_spans:
+        opt = self._opt_of[id(flat)]
+        if opt.exp_avg is None:
+          continue
+        for buf in (opt.exp_avg, opt.exp_avg_sq):
+          work, fin = self._wire.all_gather_span(buf[off:off + cnt], self.group, async_op=False)
+          if work is not None:
+            work.wait()
+          fin()
 
   def load_optimizer_state_dict(self, sd):
     """Resume from a reference optimizer checkpoint (base/base_trainer.py:426-432); the captured graphs read the Adam

@@ -86,8 +86,11 @@ def _run(rank, world, dev, overlap=None, steps=STEPS, grad_dtype=None, batch=BAT
   for _ in range(steps):
     losses.append(float(runner.step().item()))
   torch.cuda.synchronize()
+  # the step's optimizer state as the reference would checkpoint it (collective in shard mode: every rank calls it)
+  osd = runner.optimizer_state_dict()
+  opt_state = {i: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in osd['state'].items()}
   return dict(grad=grad_after_warmup, losses=losses, master=model._flat.master.detach().clone().cpu(), seed=seed,
-              buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()})
+              buffers={k: v.detach().clone().cpu() for k, v in model.named_buffers()}, opt_state=opt_state)
 
 
 def _worker(rank, world, port, out, kw):
@@ -325,6 +328,15 @@ def test_sharded_optimizer_gives_the_all_reduce_paths_weights(tmp_path, overlap)
   assert torch.equal(outs['shard'][0]['master'], outs['shard'][1]['master'])  # replicas in lock-step
   assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
   assert torch.equal(a['master'], b['master']), (a['master'] - b['master']).abs().max().item()
+  # a checkpoint written by EITHER rank of the sharded run carries the all-reduce path's Adam state: step counts and both
+  # moments of every parameter, not just of the 1/N this rank updated (optimizer_state_dict all-gathers them)
+  for rank in (0, 1):
+    sa, sb = a['opt_state'], outs['shard'][rank]['opt_state']
+    assert sorted(sa) == sorted(sb) and len(sa) > 20
+    for i in sa:
+      assert float(sa[i]['step']) == float(sb[i]['step']) == 4.0
+      for k in ('exp_avg', 'exp_avg_sq'):
+        assert torch.equal(sa[i][k], sb[i][k]), (rank, i, k, (sa[i][k] - sb[i][k]).abs().max().item())
 
 
 def test_bench_two_ranks_sharded_optimizer_smoke(tmp_path):

@@ -1,5 +1,6 @@
 """GPU unit tests: every HIP kernel against a plain PyTorch fp32 reference of the same op."""
 import math
+import os
 
 import pytest
 import torch
@@ -96,13 +97,36 @@ def test_gemm_nt_fused_epilogues(tile):
   _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
 
 
-@pytest.mark.parametrize('tile', [3, 4, 5, 7, 10, 11, 12, 13, 14, 18, 19, 22, 23])
+# The product library holds the tiles the dispatcher selects on its own: 13 / 14 / 18 (gemm2.hip), 21 (gemm3.hip), 24
+# (gemm5.hip).  The tiles that were measured and lost live in the LAB library (python -m mmt_amd.build --lab, loaded through
+# MMT_HIP_LIB=mmt_amd/lib/libmmt_hip_lab.so); their parity cases run when that library is the one under test.
+_LAB = 'lab' in os.path.basename(os.environ.get('MMT_HIP_LIB', '')) or 'instr' in os.path.basename(os.environ.get('MMT_HIP_LIB', ''))
+_PRODUCT_TILES = [13, 14, 18, 24]
+_LAB_TILES = [3, 4, 5, 7, 10, 11, 12, 19, 22, 23]
+
+
+@pytest.mark.parametrize('tile', _PRODUCT_TILES + (_LAB_TILES if _LAB else []))
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (777, 512, 192), (7168, 1536, 512), (3583, 512, 3072), (640, 512, 64)])
 def test_gemm_nt_wide_tiles(tile, M, N, K):
-  """gemm2.hip (256x128 / 256x256 / 128x128 / 128x256 tiles, 32x32x16 MFMA, LDS-staged epilogue): every epilogue."""
+  """gemm2.hip (128x128 / 128x64 tiles, 32x32x16 MFMA, LDS-staged epilogue; lab: 256x128 / 256x256 / ...) and gemm5.hip
+  (tile 24: persistent, wave-specialised 128x128): every epilogue."""
   _wide_tile_case(tile, M, N, K)
 
 
+def test_lab_tiles_are_not_in_the_product_library():
+  """A lab tile id asked of the product library is an argument error, not a silent fallback."""
+  if _LAB:
+    pytest.skip('lab library under test')
+  from mmt_amd import ops
+  a = _rand((256, 64), seed=1, dtype=torch.bfloat16)
+  b = _rand((128, 64), seed=2, dtype=torch.bfloat16)
+  out = torch.zeros(256, 128, device=_dev(), dtype=torch.bfloat16)
+  for tile in (3, 16, 19, 23):
+    with pytest.raises(RuntimeError):
+      ops.gemm_nt(a, b, out, 'BF16', tile=tile)
+
+
+@pytest.mark.skipif(not _LAB, reason='192-wide tiles: lab library only')
 @pytest.mark.parametrize('tile', [15, 16, 17])
 @pytest.mark.parametrize('M,N,K', [(300, 384, 128), (777, 576, 192), (3583, 3072, 512), (7168, 1536, 512)])
 def test_gemm_nt_192_wide_tiles(tile, M, N, K):

@@ -92,6 +92,7 @@ def main():
     if tile < 3 or args.nocheck:
       continue
     for (M, N, K) in ([(300, 384, 128), (777, 576, 192), (1000, 768, 64)] if tile in (15, 16, 17, 20) else
+                      [(300, 256, 128), (777, 512, 192), (1000, 768, 64), (6976, 3072, 512), (3639, 1536, 512), (5000, 1024, 1024)] if tile == 24 else
                       [(300, 256, 128), (777, 512, 192), (1000, 768, 64)]):
       errs = check(tile, M, N, K)
       ok = errs[0] < 0.1 and errs[1] < 0.05 and errs[2] < 2e-3 and errs[3] < 2e-2 and errs[4] < 2e-2
