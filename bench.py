@@ -43,10 +43,13 @@ CONFIGS = {
 WORKLOAD = CONFIGS[1]['name']
 
 
-def select_config(n):
-  global BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS, WORKLOAD, PMC_CSV
+def select_config(n, dense=False):
+  global BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS, WORKLOAD, PMC_CSV, STATS_CSV
   c = CONFIGS[n]
-  PMC_CSV = os.path.join('profiles', PMC_CSVS[n])
+  # (--dense of configs[1] has its own passes: the packed shape's traffic beside dense algorithmic bytes is not evidence)
+  key = 'dense' if (dense and n == 1) else n
+  PMC_CSV = os.path.join('profiles', PMC_CSVS[key])
+  STATS_CSV = os.path.join('profiles', STATS_CSVS[key])
   BATCH, TOKENS, HIDDEN, LAYERS, HEADS, INTER, MAX_POS = (c[k] for k in ('batch', 'tokens', 'hidden', 'layers', 'heads',
                                                                          'inter', 'max_pos'))
   WORKLOAD = c['name']
@@ -111,8 +114,13 @@ class KernelProbe:
     return sum(ms) / max(1, len(ms)) * 1e-3, len(ms)
 
 
-PMC_CSVS = {1: 'r04_pmc_kernels.csv', 3: 'r04_pmc_config3.csv', 4: 'r04_pmc_config4.csv'}  # one set of passes per shape
+# rocprofv3 evidence the JSON line quotes (tools/final_profiles.sh writes them): one set of PMC passes per shape -- the
+# unpacked ('dense') timing of configs[1] has its own --, and the by-grid kernel-trace summary of the replayed graph
+PMC_CSVS = {1: 'r05_pmc_kernels.csv', 3: 'r05_pmc_config3.csv', 4: 'r05_pmc_config4.csv', 'dense': 'r05_pmc_dense.csv'}
+STATS_CSVS = {1: 'r05_kernel_stats_packed_by_grid.csv', 3: 'r05_kernel_stats_config3_by_grid.csv',
+              4: 'r05_kernel_stats_config4_by_grid.csv', 'dense': 'r05_kernel_stats_dense_by_grid.csv'}
 PMC_CSV = os.path.join('profiles', PMC_CSVS[1])
+STATS_CSV = os.path.join('profiles', STATS_CSVS[1])
 
 
 def pmc_traffic(kernel_subs, grid_sub=None):
@@ -139,14 +147,40 @@ def pmc_traffic(kernel_subs, grid_sub=None):
   return best
 
 
-def pmc_blob():
-  """git blob id of the PMC CSV the `traffic` figures come from (so a stale profile is visible in the JSON line)."""
+def _blob(rel):
   import hashlib
-  path = os.path.join(ROOT, PMC_CSV)
+  path = os.path.join(ROOT, rel)
   if not os.path.exists(path):
     return None
   data = open(path, 'rb').read()
   return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
+
+
+def pmc_blob():
+  """git blob id of the PMC CSV the `traffic` figures come from (so a stale profile is visible in the JSON line)."""
+  return _blob(PMC_CSV)
+
+
+def graph_launch_us(kernel_subs, grid_sub=None):
+  """Average duration of a kernel INSIDE the replayed step graph, from the committed rocprofv3 kernel-trace summary of this
+  same command (rocpd_stats.py --by-grid --csv): the HIP-event probes of `avg_launch_us` time eager launches between two
+  graphs, which run ~10 % longer than the same kernel as a node of the graph.  Of the grids a kernel ran with, the one that
+  holds most of its time.  None if the profile is not there."""
+  import csv
+  path = os.path.join(ROOT, STATS_CSV)
+  if not os.path.exists(path):
+    return None
+  best, best_time = None, -1.0
+  with open(path) as f:
+    for row in csv.DictReader(f):
+      if any(k in row['Name'] for k in kernel_subs) and (grid_sub is None or grid_sub in row['Name']):
+        try:
+          t = float(row['TotalDurationNs'])
+          if t > best_time:
+            best, best_time = float(row['AverageNs']) * 1e-3, t
+        except (KeyError, ValueError):
+          pass
+  return best
 
 
 def site_roofline(site, rows, sec, used, sq_sum=0.0):
@@ -167,7 +201,7 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
   elif site == 0:
     name, flops = 'FFN up-projection GEMM + bias + erf-GELU (N=%d, K=%d; gemm2_kernel, EPI BIAS_GELU)' % (i, d), 2.0 * rows * i * d
     nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
-    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2', 'gemm3_kernel<2>'], None
+    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2', 'gemm3_kernel<2>', 'gemm5_kernel<2>'], None
   elif site == 1:
     name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
     nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
@@ -178,6 +212,10 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
     nbytes = rows * (2 * i + 6 * d) * 2 + (2 * i * d + 4 * d * d) * 4
     subs, grid = ['wgrad3_kernel', 'wgrad_phased_kernel [grid 256 ', 'wgrad_phased_kernel [grid 1024 ', 'wgrad_grouped_kernel'], None
   tf = flops / sec / 1e12
+  g_us = graph_launch_us(subs, grid)
+  graph = dict(avg_launch_us_graph=g_us, frac_graph=None, graph_source=STATS_CSV, graph_source_git_blob=_blob(STATS_CSV))
+  if g_us:
+    graph['frac_graph'] = ((nbytes / (g_us * 1e-6) / 8e12) if site in (3, 4) else (flops / (g_us * 1e-6) / 1e12 / BF16_DENSE_PEAK_TFLOPS))
   if site in (3, 4):
     # at ~110 live tokens per sample neither roof is near (a few % of the MFMA peak, ~15 % of HBM): the launch is bound by
     # its per-tile instruction stream and latency; priced against HBM, the nearer of the two roofs
@@ -185,12 +223,12 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
     return dict(kernel=name, bound='hbm', achieved=gbs, peak=8000.0, unit='GB/s', frac=gbs / 8000.0, flops_per_launch=flops,
                 mfma_frac=tf / BF16_DENSE_PEAK_TFLOPS, algorithmic_bytes_per_launch=nbytes, avg_launch_us=sec * 1e6,
                 launches_timed=used, traffic=pmc_traffic(subs, grid),
-                traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV, traffic_source_git_blob=pmc_blob())
+                traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV, traffic_source_git_blob=pmc_blob(), **graph)
   return dict(kernel=name, bound='mfma', achieved=tf, peak=BF16_DENSE_PEAK_TFLOPS, unit='TFLOP/s',
               frac=tf / BF16_DENSE_PEAK_TFLOPS, flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes,
               hbm_frac_of_8TBps=nbytes / sec / 8e12, avg_launch_us=sec * 1e6, launches_timed=used,
               traffic=pmc_traffic(subs, grid), traffic_unit='bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)' % PMC_CSV,
-              traffic_source_git_blob=pmc_blob())
+              traffic_source_git_blob=pmc_blob(), **graph)
 
 
 def executed_flops_per_step(batch, live_rows, seq_lens_sq_sum, m_experts):
@@ -363,7 +401,7 @@ def main():
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
-  select_config(args.config)
+  select_config(args.config, args.dense)
   if args.config != 1:
     args.no_cpu_baseline = True  # the CPU port is timed on the headline shape only (a bounded sample of THAT workload)
   if args.ragged_inputs:
