@@ -160,6 +160,15 @@ int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int cols_ws, int 
  * layer_norm; z is the pre-LN sum written by MMT_EPI_BIAS_DROP_RES).  d % 256 == 0, d <= 1024. */
 int mmt_ln_fwd(const float* z, const float* gamma, const float* beta, float eps, float* h32, void* h16,
                float* mean, float* rstd, int rows, int d, const int32_t* n_rows_dev, void* stream);
+/* The hidden -> hidden projection of BertSelfOutput WITH its LayerNorm in one launch (gemm_ln.hip; r05):
+ *   z = dropout(A[M,K] . W[N,K]^T + bias) + res ;  h = LN(z)          bert.py:185-188
+ * = mmt_gemm_nt_bf16(MMT_EPI_BIAS_DROP_RES) followed by mmt_ln_fwd, same results.  N == 512 (a block owns 32 whole rows),
+ * K % 64 == 0.  res / z_out / h32 fp32 [M, 512] (z_out / h32 contiguous, h32 nullable), h16 bf16 [M, 512], mean / rstd [M];
+ * dropout element (row_index[row] or row, column) of the stream hash(drop_key, *seed_dev), drop_thr16 = 0: none. */
+int mmt_gemm_nt_ln_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* res,
+                       int64_t ldres, const int32_t* row_index, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
+                       const uint32_t* seed_dev, float* z_out, const float* gamma, const float* beta, float eps, float* h32,
+                       void* h16, float* mean, float* rstd, int M, int N, int K, const int32_t* n_rows_dev, void* stream);
 /* h = dropout(LN(features + type_emb[type_ids] + pos_emb[pos_ids]))   bert.py:87-105.
  * z_save receives the pre-LN sum (needed by backward). pos_ids may be NULL (pos_enc='none'). */
 int mmt_embed_ln_fwd(const float* features, const int32_t* type_ids, const int32_t* pos_ids,

@@ -145,6 +145,8 @@ SIGNATURES = {
     'mmt_reduce_slabs': (c_int, [c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'mmt_reduce_slabs_pair': (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
     'mmt_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'mmt_gemm_nt_ln_fwd': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp,
+                                   c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_embed_ln_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                  c_int, c_int, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp, c_vp]),
     'mmt_embed_ln_fwd_sched': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,

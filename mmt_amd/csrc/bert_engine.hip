@@ -221,6 +221,20 @@ static bool splitk_ffn(const Ws&, int rows, int d, int K) {
   return splitk_ffn_mode() > 0 && rows >= 2048 && K >= 2048 && d <= 512;
 }
 
+// r05: BertSelfOutput's projection + LayerNorm as one launch where the hidden size is the 512 of the video BERT (a block of
+// gemm_ln.hip owns 32 whole rows of 512 columns).  OPT-IN (MMT_FUSE_OUT_LN=1): it removes three graph nodes and three reads
+// of z per step, but every block streams the whole 512 KiB weight through its CU's ~21 B/clk ingest -- same-box A/B of the
+// whole step, three alternations: 1.2718 / 1.2719 / 1.2738 ms with the GEMM + LayerNorm pair, 1.2851 / 1.2863 / 1.2871 with
+// the fused launch.
+static bool fuse_out_ln(int d) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MMT_FUSE_OUT_LN");
+    on = e ? atoi(e) : 0;
+  }
+  return on && d == 512;
+}
+
 // the attention backward's block order (attn_sched.h) exists for packed batches whose (sample, head) pairs split over 8 XCDs
 static const int32_t* attn_work_of(const MmtBertModel* m, const MmtBertBatch* b, const Ws& w) {
   static int on = -1;
@@ -291,11 +305,17 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       TRY(mmt_attn_fwd(L.qkv, b->cu_seqlens, b->mask_bias, L.ctx, L.lse, b->batch, b->seq, m->heads, d, qk_scale,
                        site_key(l, SITE_PROBS), ta, sa, b->seed_dev, b->row_index, stream));
     }
+    if (fuse_out_ln(d)) {
+      // attention output projection + dropout + residual + LayerNorm in ONE launch (gemm_ln.hip: a block owns 32 whole rows)
+      TRY(mmt_gemm_nt_ln_fwd(L.ctx, d, P.wo, d, P.bo, hin32, d, b->row_index, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev,
+                             L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, d, b->n_rows_dev, stream));
+    } else {
     e = {};
     e.bias = P.bo; e.res = hin32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
     TRY(mmt_gemm_nt_bf16(L.ctx, d, P.wo, d, L.z1, d, rows, d, d, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
     TRY(mmt_ln_fwd(L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, b->n_rows_dev, stream));
+    }
     e = {};
     e.bias = P.b1; e.out2 = L.g; e.ldout2 = I;
     {

@@ -185,6 +185,25 @@ def ln_fwd(z, gamma, beta, eps, rows=None, n_rows_dev=None, want_h32=True):
   return h32, h16, mean, rstd
 
 
+def gemm_nt_ln_fwd(a, w, bias, res, gamma, beta, eps, m=None, row_index=None, drop_key=0, drop_p=0.0, seed_dev=None,
+                   n_rows_dev=None):
+  """z = dropout(a @ w^T + bias) + res ; h = LN(z) in ONE launch (model/bert.py:185-188).  -> z, h32, h16, mean, rstd"""
+  _need_cuda(a, w, res)
+  M = a.shape[0] if m is None else m
+  N, K = w.shape
+  R = res.shape[0]
+  z = torch.zeros(R, N, device=a.device, dtype=torch.float32)
+  h32 = torch.zeros(R, N, device=a.device, dtype=torch.float32)
+  h16 = torch.zeros(R, N, device=a.device, dtype=torch.bfloat16)
+  mean = torch.zeros(R, device=a.device, dtype=torch.float32)
+  rstd = torch.zeros(R, device=a.device, dtype=torch.float32)
+  thr, scale = dropout_params(drop_p)
+  check(_lib.lib().mmt_gemm_nt_ln_fwd(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res), res.stride(0), _p(row_index),
+                                      drop_key, thr, scale, _p(seed_dev), _p(z), _p(gamma), _p(beta), eps, _p(h32), _p(h16),
+                                      _p(mean), _p(rstd), M, N, K, _p(n_rows_dev), _stream()), 'mmt_gemm_nt_ln_fwd')
+  return z, h32, h16, mean, rstd
+
+
 def embed_ln_fwd(features, type_ids, pos_ids, type_emb, pos_emb, gamma, beta, eps, rows=None, drop_key=0,
                  drop_p=0.0, row_index=None, n_rows_dev=None, seed_dev=None):
   _need_cuda(features)

@@ -711,3 +711,38 @@ def test_wgrad_grouped_256x256_tiles(rows, live, per_item):
     assert (out - want).abs().max().item() <= 2e-3 * scale + 1e-3, (q, (out - want).abs().max().item(), scale)
     if bias is not None:
       assert (bias - wb).abs().max().item() <= 1e-3 * wb.abs().max().item() + 1e-3, q
+
+
+@pytest.mark.parametrize('M,K,live,drop', [(96, 512, None, 0.0), (300, 512, None, 0.1), (3639, 512, 3600, 0.1), (1000, 192, 777, 0.1)])
+def test_gemm_nt_ln_fwd_equals_gemm_then_layernorm(M, K, live, drop):
+  """gemm_ln.hip: z = dropout(A W^T + b) + res, h = LN(z) in ONE launch (model/bert.py:185-188) against the two launches it
+  replaces -- the N = hidden GEMM with MMT_EPI_BIAS_DROP_RES (un-phased tile: the same K order) + mmt_ln_fwd: z, mean,
+  rstd bit for bit (h within an fp32 ulp), with dropout keyed on ORIGINAL row numbers, on the live rows of a packed batch
+  only; and z against a torch fp32 reference."""
+  from mmt_amd import ops
+  N = 512
+  R = ops.pad_rows(M)
+  a = _rand((R, K), seed=71, dtype=torch.bfloat16)
+  w = _rand((N, K), 0.05, seed=72, dtype=torch.bfloat16)
+  bias, res = _rand((N,), seed=73), _rand((R, N), seed=74)
+  gamma, beta = 1.0 + 0.1 * _rand((N,), seed=75), 0.1 * _rand((N,), seed=76)
+  ridx = (torch.arange(R, device=_dev(), dtype=torch.int32) * 3 + 5) % 100000
+  seed = torch.tensor([9], device=_dev(), dtype=torch.int32)
+  nrd = torch.tensor([live], device=_dev(), dtype=torch.int32) if live is not None else None
+  rows = live if live is not None else M
+  z, h32, h16, mean, rstd = ops.gemm_nt_ln_fwd(a, w, bias, res, gamma, beta, 1e-12, m=M, row_index=ridx, drop_key=4321,
+                                                drop_p=drop, seed_dev=seed, n_rows_dev=nrd)
+  z2 = torch.zeros(R, N, device=_dev(), dtype=torch.float32)
+  ops.gemm_nt(a, w, z2, 'BIAS_DROP_RES', m=M, bias=bias, res=res, row_index=ridx, drop_key=4321, drop_p=drop, seed_dev=seed,
+              n_rows_dev=nrd, tile=13)
+  g32, g16, gmean, grstd = ops.ln_fwd(z2, gamma, beta, 1e-12, rows=M, n_rows_dev=nrd)
+  assert torch.equal(z[:rows], z2[:rows])
+  assert torch.equal(mean[:rows], gmean[:rows]) and torch.equal(rstd[:rows], grstd[:rows])
+  # (the normalisation itself may contract its multiply-adds differently in the two kernels: one fp32 ulp)
+  _close('h32', h32[:rows], g32[:rows], 2e-6, 1e-6)
+  _close('h16', h16[:rows], g16[:rows], 1e-6, 2 ** -7)
+  assert bool((z[rows:] == 0).all()) and bool((h16[rows:] == 0).all())  # rows past the live count are never written
+  if drop == 0.0:
+    ref = a[:rows].float() @ w.float().t() + bias + res[:rows]
+    _close('z', z[:rows], ref, 2e-3, 1e-4)
+    _close('h', h32[:rows], torch.nn.functional.layer_norm(ref, (N,), gamma, beta, 1e-12), 5e-3, 1e-3)
