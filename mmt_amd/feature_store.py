@@ -113,12 +113,34 @@ class FeatureStoreWriter:
     self._off = {e: [0] for e in self.experts}
     self._tok = open(os.path.join(path, 'captions.tok'), 'wb')
     self._cap_off, self._vid_cap = [0], [0]   # token offset of every caption, caption offset of every video
+    # word-level captions (for the caption sampling modes that cut / shuffle / concatenate WORDS before tokenising):
+    # UTF-8 words separated by \x1f, [start, end] seconds per word
+    self._words = open(os.path.join(path, 'captions.words'), 'wb')
+    self._wt = open(os.path.join(path, 'captions.wt'), 'wb')
+    self._wbyte, self._wcount, self._vid_wcap = [0], [0], [0]  # byte / word offset of every caption, caption offset per video
 
-  def add(self, vid, features, features_t=None, captions=None):
+  def add(self, vid, features, features_t=None, captions=None, caption_words=None, caption_times=None):
     """features: {expert: [n, D] float array}; features_t: {expert: [n, 2] start/end seconds} (optional per expert);
     captions: list of token-id sequences, one per caption of the video, tokenised as `tokenize_caption` does
-    (base_dataset.py:320-346: `caption_text(words)` through the tokenizer, [CLS] ... [SEP], NOT yet cut to max_text_words)."""
+    (base_dataset.py:320-346: `caption_text(words)` through the tokenizer, [CLS] ... [SEP], NOT yet cut to max_text_words).
+    caption_words / caption_times: the captions as the reference's files hold them (`raw_captions.<i>`: word strings,
+    `raw_captions_t.<i>`: [n_words, 2] seconds, base_dataset.py:446-458; times default to zeros, surplus rows are cut) --
+    what `RaggedCollator.collate_captions` samples from."""
     features_t = features_t or {}
+    for c, words in enumerate(caption_words or []):
+      words = [w if isinstance(w, str) else w.decode('UTF-8') for w in words]
+      if any('\x1f' in w for w in words):
+        raise ValueError('caption words must not contain the unit separator')
+      t = caption_times[c] if caption_times is not None and caption_times[c] is not None else np.zeros((len(words), 2))
+      t = np.asarray(t, dtype=np.float64).reshape(-1, 2)[:len(words)]
+      if t.shape[0] != len(words):
+        raise ValueError('fewer caption timings than words')
+      blob = '\x1f'.join(words).encode('UTF-8')
+      self._words.write(blob)
+      self._wt.write(np.ascontiguousarray(t).tobytes())
+      self._wbyte.append(self._wbyte[-1] + len(blob))
+      self._wcount.append(self._wcount[-1] + len(words))
+    self._vid_wcap.append(len(self._wcount) - 1)
     for ids in (captions or []):
       ids = np.asarray(ids, dtype=np.int32).reshape(-1)
       self._tok.write(ids.tobytes())
@@ -152,6 +174,10 @@ class FeatureStoreWriter:
     self._tok.close()
     np.asarray(self._cap_off, dtype=np.int64).tofile(os.path.join(self.path, 'captions.off'))
     np.asarray(self._vid_cap, dtype=np.int64).tofile(os.path.join(self.path, 'captions.vid'))
+    self._words.close()
+    self._wt.close()
+    np.asarray([self._wbyte, self._wcount], dtype=np.int64).tofile(os.path.join(self.path, 'captions.woff'))
+    np.asarray(self._vid_wcap, dtype=np.int64).tofile(os.path.join(self.path, 'captions.wvid'))
     with open(os.path.join(self.path, 'meta.json'), 'w') as f:
       json.dump({'version': 1, 'dtype': self.dtype, 'experts': self.experts, 'videos': self.videos}, f)
 
@@ -193,8 +219,32 @@ class FeatureStore:
     self._tok = (np.memmap(os.path.join(path, 'captions.tok'), mode='r', dtype=np.int32, shape=(ntok,)) if ntok
                  else np.zeros((0,), np.int32))
 
+    self._wblob, self._wtimes = b'', np.zeros((0, 2))
+    self._wbyte = self._wcount = np.zeros((1,), np.int64)
+    self._vid_wcap = np.zeros((len(self.videos) + 1,), np.int64)
+    if os.path.exists(os.path.join(path, 'captions.woff')):  # (stores written before r05 have no word-level captions)
+      woff = np.fromfile(os.path.join(path, 'captions.woff'), dtype=np.int64).reshape(2, -1)
+      self._wbyte, self._wcount = woff[0], woff[1]
+      self._vid_wcap = np.fromfile(os.path.join(path, 'captions.wvid'), dtype=np.int64)
+      nw = int(self._wcount[-1])
+      if nw:
+        self._wblob = np.memmap(os.path.join(path, 'captions.words'), mode='r', dtype=np.uint8, shape=(int(self._wbyte[-1]),))
+        self._wtimes = np.memmap(os.path.join(path, 'captions.wt'), mode='r', dtype=np.float64, shape=(nw, 2))
+
   def __len__(self):
     return len(self.videos)
+
+  def caption_words(self, i):
+    """-> (list of word lists, list of [n_words, 2] second arrays), one entry per stored caption of video i"""
+    i = self.index[i] if isinstance(i, str) else i
+    a, b = int(self._vid_wcap[i]), int(self._vid_wcap[i + 1])
+    words, times = [], []
+    for c in range(a, b):
+      blob = bytes(self._wblob[int(self._wbyte[c]):int(self._wbyte[c + 1])]).decode('UTF-8')
+      n = int(self._wcount[c + 1] - self._wcount[c])
+      words.append(blob.split('\x1f') if n else [])
+      times.append(np.array(self._wtimes[int(self._wcount[c]):int(self._wcount[c + 1])]))
+    return words, times
 
   def captions(self, i):
     """-> list of int32 token-id views, one per stored caption of video i"""
@@ -364,6 +414,92 @@ class RaggedCollator:
         tok[s, c] = crop_or_pad_tokens(caps[c] if have else pad_caption, max_text_words, sep_id)
         qm[s, c] = 1.0 if have else 0.0
     return torch.from_numpy(tok.astype(np.int32)), torch.from_numpy(qm.astype(np.int32))
+
+  def collate_captions(self, indices, captions_per_video, max_text_words, tokenizer, query_shuffling='indiv',
+                       caption_length=float('inf'), clip_duration=float('inf'), restrict_test_captions=None,
+                       py_random=None):
+    """The caption half of `BaseDataset.__getitem__` (base/base_dataset.py:569-757, n_pairs = 1) on the store's word-level
+    captions, for EVERY caption sampling mode of the reference:
+      query_shuffling  'indiv' (each caption on its own), 'cat' (all captions concatenated in order), 'shuf' (shuffled,
+                       then concatenated), 'shufk<N>' (shuffled, the first N concatenated)               :594-625
+      caption_length   inf, n or [min, max]: a window of that many consecutive "sentences" (= words: every word is its
+                       own sentence, :653-660) at a random start                                          :686-724
+      clip_duration    inf, seconds or [min, max]: returns the feature window centred on the kept words     :701-712, 757-767
+      words after 500 s dropped (:657), an empty caption becomes ".", a missing one the filler "0" with query mask 0
+      (:660-668), cut to max_text_words, tokenised by `tokenizer` as `tokenize_caption` does (:320-346: joined, a period
+      appended, capitalised, [CLS] ... [SEP], cut, last token forced to [SEP]).
+    Randomness is consumed exactly as the reference consumes it: the caption shuffles from Python's `random` (py_random,
+    default the global module), window lengths / clip lengths / window starts from `np.random` in training and from
+    RandomState(idx) per sample otherwise.  tokenizer: .tokenize(str) -> tokens, .convert_tokens_to_ids(tokens) -> ids,
+    .cls_token, .sep_token (a HuggingFace tokenizer).
+    -> token_ids [B, C, W, 2] int32, query_masks [B, C] int32, windows [(feat_start, feat_end)] per sample."""
+    import random as _random
+    import re
+    pyr = py_random if py_random is not None else _random
+    C, W = captions_per_video, max_text_words
+    z = re.match(r'shufk(\d*)', query_shuffling)
+    if query_shuffling not in ('indiv', 'cat', 'shuf') and not z:
+      raise ValueError('query_shuffling: indiv | cat | shuf | shufk<N>')
+    tok = np.zeros((len(indices), C, W, 2))
+    qm = np.zeros((len(indices), C))
+    windows = []
+    for s, i in enumerate(indices):
+      idx = self.store.index[i] if isinstance(i, str) else int(i)
+      captions, captions_t = self.store.caption_words(idx)
+      if not captions:
+        raise ValueError('video %r has no word-level captions in the store' % (i,))
+      captions = [np.array(c, dtype=object) for c in captions]
+      if restrict_test_captions and self.store.videos[idx] in restrict_test_captions:  # :577-582
+        keep = restrict_test_captions[self.store.videos[idx]]
+        captions, captions_t = [captions[keep]], [captions_t[keep]]
+      raw, raw_t = [], []
+      for cap_nb in range(min(len(captions), C)):  # :592-625
+        if query_shuffling == 'indiv':
+          raw.append(captions[cap_nb]); raw_t.append(captions_t[cap_nb])
+        elif query_shuffling == 'cat':
+          raw.append(np.concatenate(captions)); raw_t.append(np.concatenate(captions_t))
+        else:
+          c = list(zip(captions, captions_t))
+          pyr.shuffle(c)
+          captions, captions_t = zip(*c)
+          nb_keep = min(int(z.groups()[0]), len(captions)) if z else len(captions)
+          raw.append(np.concatenate(captions[:nb_keep])); raw_t.append(np.concatenate(captions_t[:nb_keep]))
+      sentences_of = []
+      for cap_idx in range(C):  # :648-668
+        if cap_idx < len(raw):
+          cap, cap_t = np.array([str(w) for w in raw[cap_idx]]), np.array(raw_t[cap_idx]).reshape(-1, 2)
+          keep_ids = cap_t[:, 0] < 500
+          cap, cap_t = np.expand_dims(cap[keep_ids], axis=-1), np.expand_dims(cap_t[keep_ids], axis=-1)
+          if len(cap) < 1:
+            cap, cap_t = np.array([['.']]), np.array([[[0, 0]]])
+        else:
+          cap, cap_t = np.array([['0']]), np.array([[[0, 0]]])
+        sentences_of.append((cap, cap_t))
+      qm[s, :len(raw)] = 1
+      clip_length, selected_t = float('inf'), None
+      for cap_idx in range(C):  # :679-748
+        rng = np.random if self.training else np.random.RandomState(idx)
+        lo, hi = (caption_length if isinstance(caption_length, (list, tuple)) else (caption_length, caption_length))
+        nb_sentences = float('inf') if lo == float('inf') else rng.randint(lo, hi + 1)
+        clo, chi = (clip_duration if isinstance(clip_duration, (list, tuple)) else (clip_duration, clip_duration))
+        clip_length = float('inf') if chi == float('inf') else rng.uniform(clo, chi)
+        sentences, sentences_t = sentences_of[cap_idx]
+        nb_sentences = min(nb_sentences, len(sentences))
+        choice = rng.randint(len(sentences) + 1 - nb_sentences)
+        selected = np.concatenate(sentences[choice:choice + nb_sentences])[:W]
+        selected_t = np.concatenate(sentences_t[choice:choice + nb_sentences])[:W]
+        tokens = [tokenizer.cls_token] + list(tokenizer.tokenize(caption_text(list(selected)))) + [tokenizer.sep_token]
+        tokens = tokens[:W]
+        tokens[-1] = tokenizer.sep_token
+        ids = tokenizer.convert_tokens_to_ids(tokens)
+        tok[s, cap_idx, :len(ids), 0] = ids
+        tok[s, cap_idx, :len(ids), 1] = 1
+      if clip_length == float('inf'):  # :757-767 (the window follows the LAST caption of the sample, as in the reference)
+        windows.append((0.0, float('inf')))
+      else:
+        c_time = np.mean((np.min(selected_t), np.max(selected_t)))
+        windows.append((c_time - clip_length / 2, c_time - clip_length / 2 + clip_length))
+    return torch.from_numpy(tok.astype(np.int32)), torch.from_numpy(qm.astype(np.int32)), windows
 
   def collate(self, indices, out=None, window=None):
     """Rows are drawn SAMPLE-major -- for every sample, every expert in turn -- as `BaseDataset.__getitem__` does

@@ -55,14 +55,14 @@ class _Tokenizer:
     return [101 if t == '[CLS]' else 102 if t == '[SEP]' else 1000 + sum(map(ord, t)) % 997 for t in tokens]
 
 
-def reference_dataset(training, clip_duration):
+def reference_dataset(training, clip_duration, videos=None):
   load_reference()
   sys.modules['h5py'].File = _FakeH5
   BD = importlib.import_module('base.base_dataset')
   cls = type('SyntheticDataset', (BD.BaseDataset,), dict(configure_train_test_splits=lambda s, *a: None,
                                                          sanity_checks=lambda s: None, load_features=lambda s: None))
   ds = cls.__new__(cls)
-  videos = DF.make_videos()
+  videos = DF.make_videos() if videos is None else videos
   _FakeH5.files = dict(videos)
   ds.train, ds.experts, ds.raw_input_dims = training, list(DF.DIMS), dict(DF.DIMS)   # (a list: fixed expert order)
   ds.vid_list = [v for v, _ in videos]
@@ -107,6 +107,45 @@ def main():
   out['timings/group'] = ds.get_feature_timings(6, 1.0, stride=2.0, group=2)
   np.savez_compressed(OUT, **out)
   print('wrote', OUT, os.path.getsize(OUT), 'bytes')
+  captions_golden()
+
+
+# ---- the caption sampling modes (r05): tests/golden/dataset_captions.npz -------------------------------------------------
+OUT_CAP = os.path.join(os.path.dirname(OUT), 'dataset_captions.npz')
+# name -> (training, captions_per_video, query_shuffling, caption_length, clip_duration); the seeds a case uses per item are
+# random.seed(1000 + idx) (the shuffles) and np.random.seed(2000 + idx) (training-mode draws), set right before __getitem__
+CAPTION_CASES = {
+    'cat2': (False, 2, 'cat', float('Inf'), float('Inf')),
+    'shuf2': (False, 2, 'shuf', float('Inf'), float('Inf')),
+    'shufk2': (False, 1, 'shufk2', float('Inf'), float('Inf')),
+    'indiv_window': (False, 1, 'indiv', [2, 4], float('Inf')),
+    'cat_window_clip': (False, 2, 'cat', 3, [4.0, 8.0]),
+    'train_window': (True, 1, 'indiv', [1, 3], float('Inf')),
+    'train_shuf_clip': (True, 2, 'shuf', [2, 5], 6.0),
+}
+
+
+def captions_golden():
+  import random
+  out = {}
+  videos = DF.make_caption_videos()
+  for name, (training, cpv, shuffling, cap_len, clip) in CAPTION_CASES.items():
+    ds, BD = reference_dataset(training, clip, videos=videos)
+    ds.captions_per_video, ds.query_shuffling, ds.caption_length = cpv, shuffling, cap_len
+    items = []
+    for i in range(len(ds.vid_list)):
+      random.seed(1000 + i)
+      np.random.seed(2000 + i)
+      items.append(ds[i])
+    mb = collate(ds, items)
+    out[name + '/token_ids'] = mb['token_ids']
+    out[name + '/query_masks'] = mb['query_masks']
+    if not training:  # (training-mode feature rows are a random choice that follows the caption draws on the SAME generator)
+      for e in DF.DIMS:
+        out['%s/features_t/%s' % (name, e)] = mb['features_t'][e]
+        out['%s/features_ind/%s' % (name, e)] = mb['features_ind'][e]
+  np.savez_compressed(OUT_CAP, **out)
+  print('wrote', OUT_CAP, os.path.getsize(OUT_CAP), 'bytes')
 
 
 if __name__ == '__main__':

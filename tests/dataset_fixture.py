@@ -49,3 +49,32 @@ def h5_features(h5):
   feats = {k[len('features.'):]: v for k, v in h5.items() if k.startswith('features.')}
   times = {k[len('features_t.'):]: v for k, v in h5.items() if k.startswith('features_t.')}
   return feats, times
+
+
+def make_caption_videos(seed=9):
+  """Videos with SEVERAL captions each (raw_captions.<i> / raw_captions_t.<i>, base_dataset.py:446-458) for the caption
+  sampling modes: captions of 2..6 words, word times spread over the video; video 2 has a caption spoken entirely after
+  500 s (dropped: the caption becomes "."), video 4 a single caption (a second one requested -> the filler "0"), video 5
+  three captions of EQUAL length (what 'shufk' needs under a NumPy that refuses ragged arrays: the reference stacks the
+  selected captions' times with np.array, :627)."""
+  rng = np.random.RandomState(seed)
+  videos = make_videos()
+  out = []
+  for v, (vid, h5) in enumerate(videos):
+    h5 = {k: val for k, val in h5.items() if not k.startswith('raw_captions')}
+    ncap = [3, 2, 2, 3, 1, 3, 2, 4][v]
+    for c in range(ncap):
+      n = 3 if v == 5 else 2 + (v + 2 * c) % 5
+      words = ['V%dc%dw%d' % (v, c, k) if (k + c) % 3 else 'x%d.' % k for k in range(n)]
+      start = np.cumsum(rng.uniform(0.4, 2.0, size=n)) + 3.0 * c
+      if v == 2 and c == 1:
+        start = start + 600.0
+      h5['raw_captions.%d' % c] = np.array(words, dtype=object)
+      h5['raw_captions_t.%d' % c] = np.stack([start, start + 0.5], axis=-1)
+    out.append((vid, h5))
+  return out
+
+
+def h5_captions(h5):
+  n = len([k for k in h5 if k.startswith('raw_captions.')])
+  return [list(h5['raw_captions.%d' % c]) for c in range(n)], [h5['raw_captions_t.%d' % c] for c in range(n)]

@@ -148,3 +148,82 @@ def test_collated_token_ids_equal_reference_pipeline(tmp_path):
   ids2, qm2 = coll.collate_tokens([0, 1], 2, DF.MAX_WORDS, pad_caption=tok.ids(['0']), sep_id=tok.SEP)
   assert qm2.tolist() == [[1, 0], [1, 0]] and ids2[0, 1, :, 1].sum() == 4 and torch.equal(ids2[:, 0], ids[:2, 0])
   assert [len(c) for c in store.captions('video3')] == [3 + 3 + 3]
+
+
+class FixtureHFTokenizer:
+  """the stand-in oracle/gen_dataset_golden.py gave the reference dataset, with a HuggingFace tokenizer's surface"""
+  cls_token, sep_token = '[CLS]', '[SEP]'
+
+  def tokenize(self, text):
+    return text.replace('.', ' .').split()
+
+  def convert_tokens_to_ids(self, tokens):
+    return [101 if t == '[CLS]' else 102 if t == '[SEP]' else 1000 + sum(map(ord, t)) % 997 for t in tokens]
+
+
+def build_caption_store(path):
+  with FS.FeatureStoreWriter(str(path), DF.DIMS, dtype='f32') as w:
+    for vid, h5 in DF.make_caption_videos():
+      feats, times = DF.h5_features(h5)
+      words, wt = DF.h5_captions(h5)
+      w.add(vid, feats, times, caption_words=words, caption_times=wt)
+  return FS.FeatureStore(str(path))
+
+
+@pytest.mark.parametrize('case', ['cat2', 'shuf2', 'shufk2', 'indiv_window', 'cat_window_clip', 'train_window', 'train_shuf_clip'])
+def test_caption_sampling_modes_equal_reference_pipeline(tmp_path, case):
+  """`RaggedCollator.collate_captions` against the REAL `BaseDataset.__getitem__` + `collate_data` (oracle/gen_dataset_golden.py
+  -> tests/golden/dataset_captions.npz) for every caption sampling mode of the reference: captions concatenated in order /
+  shuffled / shuffled and cut to the first N (base_dataset.py:594-625), windows of consecutive words of random length and
+  start (:686-724), words after 500 s dropped, empty and missing captions (:657-668), in evaluation (RandomState(idx)) and in
+  training (the global generators, seeded per item as the generator script seeded them); token ids and query masks equal
+  bit for bit, and where a clip duration is set the feature window the kept words centre selects the reference's rows."""
+  import random
+  from oracle.gen_dataset_golden import CAPTION_CASES
+  g = load_npz('dataset_captions')
+  training, cpv, shuffling, cap_len, clip = CAPTION_CASES[case]
+  store = build_caption_store(tmp_path / 'c')
+  coll = FS.RaggedCollator(store, list(DF.DIMS), len(store), DF.MAX_TOKENS, training=training,
+                           temporal_encoding_window=DF.WINDOW)
+  toks, masks, windows = [], [], []
+  for i in range(len(store)):
+    random.seed(1000 + i)
+    np.random.seed(2000 + i)
+    t, q, w = coll.collate_captions([i], cpv, DF.MAX_WORDS, FixtureHFTokenizer(), query_shuffling=shuffling,
+                                    caption_length=cap_len, clip_duration=clip)
+    toks.append(t); masks.append(q); windows.append(w[0])
+  toks, masks = torch.cat(toks).numpy(), torch.cat(masks).numpy()
+  assert toks.dtype == np.int32 and np.array_equal(toks, g[case + '/token_ids'])
+  assert np.array_equal(masks, g[case + '/query_masks'])
+  if case in ('cat2', 'shuf2'):
+    # as many concatenations as min(stored captions, requested): video 4 stores ONE caption (base_dataset.py:592)
+    assert masks[4].tolist() == [1, 0] and masks.sum() == 15
+  if case == 'cat_window_clip':
+    rag = coll.collate(list(range(len(store))), window=lambda i: windows[i])
+    _, ft, fi, _ = rag.to_dense()
+    for e in DF.DIMS:
+      assert np.array_equal(fi[e].numpy(), g['%s/features_ind/%s' % (case, e)]), e
+      assert np.array_equal(ft[e].numpy(), g['%s/features_t/%s' % (case, e)]), e
+  else:
+    assert all(w == (0.0, float('inf')) for w in windows) or clip != float('inf')
+
+
+def test_caption_words_round_trip_and_edge_cases(tmp_path):
+  store = build_caption_store(tmp_path / 'c')
+  videos = dict(DF.make_caption_videos())
+  for vid in ('video0', 'video4', 'video7'):
+    words, times = store.caption_words(vid)
+    want_w, want_t = DF.h5_captions(videos[vid])
+    assert words == [[str(x) for x in c] for c in want_w]
+    assert all(np.array_equal(a, b) for a, b in zip(times, want_t))
+  coll = FS.RaggedCollator(store, list(DF.DIMS), len(store), DF.MAX_TOKENS, training=False)
+  tok = FixtureHFTokenizer()
+  # video 2's second caption lies after 500 s: it becomes "." (base_dataset.py:660-664); video 4 has one caption: the filler "0"
+  ids, qm, _ = coll.collate_captions([2, 4], 2, DF.MAX_WORDS, tok)
+  assert qm.tolist() == [[1, 1], [1, 0]]
+  assert ids[0, 1, :, 0].tolist()[:3] == tok.convert_tokens_to_ids(['[CLS]', '.', '[SEP]']) and int(ids[0, 1, :, 1].sum()) == 3
+  assert ids[1, 1, :, 0].tolist()[:4] == tok.convert_tokens_to_ids(['[CLS]', '0', '.', '[SEP]'])
+  with pytest.raises(ValueError):
+    coll.collate_captions([0], 1, DF.MAX_WORDS, tok, query_shuffling='zigzag')
+  old = FS.FeatureStore(str(tmp_path / 'c'))
+  assert len(old.captions(0)) == 0  # (this store holds word-level captions only)
