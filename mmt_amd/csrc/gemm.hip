@@ -648,7 +648,9 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(MmtWgradGroup g) {
     // first pair's MFMAs: an LDS round trip (~150-200 cycles) then hides behind two pairs of MFMAs (in-order returns:
     // "at most N outstanding" = everything issued before the last N reads has landed).  Measured with the MFMAs compiled
     // out (tools/wgrad_instr.py, MMT_LAB_DEFINES=MMT_WGRAD_LAB_NOMFMA): the reads' latency chain alone is 1040 of the 1400
-    // cycles of a compute half-step when only one pair is in flight ahead of the MFMAs.
+    // cycles of a compute half-step when only one pair is in flight ahead of the MFMAs.  (r05: the opposite split -- A and
+    // the first B pair up front, pairs 1..3 behind the MFMAs of pairs 0 / 1, 12 instead of 20 reads in front of the first
+    // MFMA -- measured identical: 46.8-47.0 vs 45.5-46.9 us per launch in the step's eager probes, same step time.)
     // One base address per operand; every fragment's address is that XOR a constant, formed right at the read (the asm
     // barrier keeps the compiler from hoisting 24 loop-invariant addresses into registers the accumulators need).
     u32x2 alo[4], ahi[4], blo[4][2], bhi[4][2];
