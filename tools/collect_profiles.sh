@@ -1,13 +1,13 @@
-# gpurun_out/r04_final/* (scratch, merged back by gpurun) -> profiles/r04_* (tracked)
+# gpurun_out/final/* (scratch, merged back by gpurun) -> profiles/r05_* (tracked)
 set -e
 cd "$(dirname "$0")/.."
-for f in gpurun_out/r04_final/*.json gpurun_out/r04_final/*.txt gpurun_out/r04_final/*.csv; do
+for f in gpurun_out/final/*.json gpurun_out/final/*.txt gpurun_out/final/*.csv; do
+  [ -f "$f" ] || continue
   b=$(basename $f)
   case $b in
-    pmc_*) cp $f profiles/r04_$b ;;
-    gemm2_budget.txt) cp $f profiles/r04_gemm2_budget.txt ;;
-    attn_budget.txt) cp $f profiles/r04_attn_budget.txt ;;
-    *) cp $f profiles/r04_final_$b ;;
+    pmc_*|kernel_stats_*_by_grid.csv) cp $f profiles/r05_$b ;;
+    gemm2_budget.txt|g5_budget_*.txt) cp $f profiles/r05_$b ;;
+    *) cp $f profiles/r05_final_$b ;;
   esac
 done
-ls profiles | grep r04
+ls profiles | grep r05
