@@ -112,6 +112,20 @@ def _worker(rank, world, port, out, kw):
   dist.destroy_process_group()
 
 
+def _worker_multi(rank, world, port, out, kws):
+  """`_worker` for several configurations in ONE set of processes (process start-up and the first `import torch` of eight
+  ranks cost more than the steps): results in `<out>.<name>.<rank>`."""
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  for name, kw in kws:
+    torch.save(_run(rank, world, torch.device('cuda', 0), **kw), '%s.%s.%d' % (out, name, rank))
+    dist.barrier()
+  dist.destroy_process_group()
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL with 2 ranks needs 2 GPUs')
 
 
@@ -345,12 +359,11 @@ def test_eight_ranks_sharded_optimizer_and_split_bottom_stay_in_lock_step(tmp_pa
   offsets / counts of spans that are not multiples of 4 x 8 elements) + all-gather of the weights, against the all-reduce +
   full Adam path: identical losses on every rank, replicas in lock-step, weights equal to the all-reduce path's up to the
   summation order of an 8-rank reduction, and the optimizer checkpoint of ANY rank complete (moments all-gathered)."""
-  outs = {}
-  for name, kw in (('ar', dict()), ('shard', dict(grad_algo='rs_ag', shard_optimizer=True))):
-    out = str(tmp_path / name)
-    kw = dict(kw, txt_pro='gbn', dropout=0.1, layers=3, steps=2, batch=16)
-    mp.spawn(_worker, args=(8, _free_port(), out, kw), nprocs=8, join=True)
-    outs[name] = [torch.load('%s.%d' % (out, r)) for r in range(8)]
+  common = dict(txt_pro='gbn', dropout=0.1, layers=3, steps=2, batch=16)
+  kws = [('ar', dict(common)), ('shard', dict(common, grad_algo='rs_ag', shard_optimizer=True))]
+  out = str(tmp_path / 'w8')
+  mp.spawn(_worker_multi, args=(8, _free_port(), out, kws), nprocs=8, join=True)
+  outs = {name: [torch.load('%s.%s.%d' % (out, name, r)) for r in range(8)] for name, _ in kws}
   a, b = outs['ar'], outs['shard']
   for r in range(1, 8):
     assert torch.equal(b[0]['master'], b[r]['master']) and torch.equal(a[0]['master'], a[r]['master'])
