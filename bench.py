@@ -173,7 +173,8 @@ def graph_launch_us(kernel_subs, grid_sub=None):
   best, best_time = None, -1.0
   with open(path) as f:
     for row in csv.DictReader(f):
-      if any(k in row['Name'] for k in kernel_subs) and (grid_sub is None or grid_sub in row['Name']):
+      # (the PMC summary writes a launch geometry as '[grid 256 x 512]', the kernel-trace summary as '[256 x 512]')
+      if any(k.replace('[grid ', '[') in row['Name'] for k in kernel_subs) and (grid_sub is None or grid_sub in row['Name']):
         try:
           t = float(row['TotalDurationNs'])
           if t > best_time:
