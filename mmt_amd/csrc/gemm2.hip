@@ -598,9 +598,9 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
-  // (phased tile, K >= 2048: eight blocks past the last tile, which exit at once -- the FFN down-projection / its input gradient
-  // then differ from the K = hidden GEMMs of the same template in their GRID, so that a profile can tell them apart)
-  const int grid = ((M + BM - 1) / BM) * (N / BN) + (PH && K >= 2048 ? 8 : 0);
+  // (N <= 1024 with K >= 2048: eight blocks past the last tile, which exit at once -- the FFN down-projection / its input
+  // gradient then differ from the K = hidden GEMMs of the same template in their GRID, so that a profile can tell them apart)
+  const int grid = ((M + BM - 1) / BM) * (N / BN) + (N <= 1024 && K >= 2048 ? 8 : 0);
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN, PH>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
