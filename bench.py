@@ -682,6 +682,9 @@ def main():
       pass
     print(json.dumps(out), flush=True)
   if dist.is_initialized():
+    # ranks leave together and with an idle device: no communicator is torn down under a peer's pending kernel
+    dist.barrier()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 

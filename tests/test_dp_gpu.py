@@ -109,6 +109,7 @@ def _worker(rank, world, port, out, kw):
     dist.init_process_group(backend, rank=rank, world_size=world)
   torch.save(_run(rank, world, dev, **kw), '%s.%d' % (out, rank))
   dist.barrier()
+  torch.cuda.synchronize()  # RCCL's barrier is a kernel: let it finish before the communicator is torn down under it
   dist.destroy_process_group()
 
 
@@ -472,6 +473,7 @@ def _sharded_worker_rccl(rank, world, port, out):
   torch.save(dict(loss=float(loss.item()), dvid=lv[0].grad.cpu(), dtxt=lv[1].grad.cpu(), dtw=lv[2].grad.cpu()),
              '%s.%d' % (out, rank))
   dist.barrier()
+  torch.cuda.synchronize()
   dist.destroy_process_group()
 
 
