@@ -1013,6 +1013,23 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
     const char* lf = getenv("MMT_LIVE_FRACTION");
     const double frac = (lf && atof(lf) > 0.0) ? atof(lf) : 0.52;
     const bool one_round = (double)((M + 127) / 128) * frac * (N / 64) <= 256.0;
+    // r05: the wave-specialised kernel (gemm5.hip) for the long-K GEMMs with narrow outputs (FFN down-projection, FFN-up input
+    // gradient) once its 128 x 128 tiles fill a round of the chip (tile 24; unpacked rows: 220 tiles, one per CU): 30 vs 56 us
+    // per launch in the lab, unpacked step 1.840 -> 1.764 ms same box.  On the packed rows (116 such tiles) neither it nor
+    // the 128 x 64 variant with the five-deep ring (tile 25: 232 tiles, 21.3 vs 31.2 us in the lab) survives the step, where
+    // the operands come from Infinity Cache / HBM and a CU's K-step is bound by how many requests it may keep in flight
+    // (1.32 k cycles per K-step cold against 0.72 k warm: profiles/r05_g5_narrow_budget_*.txt; step 1.290-1.296 vs 1.281 ms).
+    // MMT_TILE_PPN = 0 off, 1 (default) as described, 2 / 3 force tile 24 / 25, 4 tile 24 or else 25.
+    static int ppn = -1;
+    if (ppn < 0) {
+      const char* q = getenv("MMT_TILE_PPN");
+      ppn = q ? atoi(q) : 1;
+    }
+    if (ppn && N < 1024 && N % 128 == 0 && K >= 1536 && EPI != MMT_EPI_BIAS_GELU && EPI != MMT_EPI_DGELU && e.dot_out == nullptr) {
+      const double t128 = (double)((M + 127) / 128) * (nr ? frac : 1.0) * (N / 128);
+      const int t = ppn == 2 ? 24 : ppn == 3 ? 25 : t128 >= 200.0 ? 24 : ppn == 4 ? 25 : 0;
+      if (t) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    }
     if (narrow && N < 1024 && nr != nullptr && (narrow != 18 || one_round))
       return mmt_gemm2_dispatch(longk && K >= 1536 && one_round ? longk : narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);

@@ -651,8 +651,8 @@ int mmt_gemm3_dispatch(int epilogue, const void* A, int64_t lda, const void* B, 
                        int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 int mmt_gemm4_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
                        int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
-int mmt_gemm5_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
-                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
+int mmt_gemm5_dispatch(int epilogue, int bn, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
+                       int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 
 // tile: 3 = 256x128, 4 = 256x256, 5 = 128x128, 6 = 128x256 (see MmtEpilogue.reserved); 21 = the 256x256 eight-phase kernel
 // of gemm3.hip
@@ -660,9 +660,14 @@ int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   if ((tile & 0xff) == 21) return mmt_gemm3_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   if ((tile & 0xff) == 24) {  // persistent, wave-specialised 128 x 128 (gemm5.hip) where its geometry allows, else tile 14 / 13
-    const int rc = mmt_gemm5_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    const int rc = mmt_gemm5_dispatch(epilogue, 128, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (rc != MMT_ERR_ARG) return rc;
     tile = (N % 128 == 0 && !(epilogue == MMT_EPI_DGELU && e.colsum && M < 128)) ? 14 : 13;
+  }
+  if ((tile & 0xff) == 25) {  // the same kernel on 128 x 64 tiles (long K, narrow outputs), else tile 13
+    const int rc = mmt_gemm5_dispatch(epilogue, 64, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    if (rc != MMT_ERR_ARG) return rc;
+    tile = 13;
   }
 #ifdef MMT_LAB_TILES
   if ((tile & 0xff) == 23) return mmt_gemm4_dispatch(epilogue, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);  // producer / consumer 128 x 64 (gemm4.hip)

@@ -23,6 +23,7 @@
 // before its tick), and the fragment addresses advance in the MFMA shadows (g5_tick below; budgets:
 // profiles/r05_g5_budget*.txt).  Blocks walk the live tiles in the XCD-aware band order of gemm2 (block b owns ids
 // slot(b), slot(b) + G, ...).
+#include <type_traits>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include "gemm_epi.h"
@@ -41,6 +42,19 @@
 #define G5_LDS (G5_BOFF + G5_RING * G5_HALF)
 
 static_assert(G5_LDS <= 163840 && G5_BOFF % 1024 == 0, "gemm5: LDS budget / alignment");
+// The 128 x 64 tile (a stage = 16 KiB of A + 8 KiB of B) runs a FIVE-deep ring: what bounds a long-K GEMM whose operands come
+// from HBM / Infinity Cache is the bytes a CU keeps in flight (ring - 2 stages: r05 budgets, 1.39 k cycles per K-step cold
+// with two 24 KiB stages in flight against 0.79 k warm).  LDS: [A slots 0..4 | B slots 0..4], both 16 KiB apart (one address
+// step for all fragment pointers); the unused upper 8 KiB of B slots 0..3 hold the four wave-private epilogue images.  No
+// GELU table, no column sums (the host refuses those epilogues for this tile).  10 x 16 KiB = all of a CU's LDS.
+template <int BN> struct G5Lay {
+  static constexpr int RING = BN == 64 ? 5 : 4;
+  static constexpr int BOFF = BN == 64 ? RING * G5_HALF : G5_BOFF;
+  static constexpr int LDS = BN == 64 ? 2 * RING * G5_HALF : G5_LDS;
+  static constexpr int ST_OFF = BN == 64 ? BOFF + G5_HALF / 2 : G5_ST_OFF;
+  static constexpr int ST_WAVE = BN == 64 ? G5_HALF : G5_ST_WAVE;
+};
+static_assert(G5Lay<64>::LDS <= 163840 && G5_ST_WAVE <= G5_HALF / 2, "gemm5: LDS budget of the 128 x 64 tile");
 template <int N> __device__ __forceinline__ void g5_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void g5_barrier() {
   asm volatile("" ::: "memory");
@@ -49,12 +63,33 @@ __device__ __forceinline__ void g5_barrier() {
 }
 
 // tile id -> (m0, n0): bands of 8 tile rows, column by column inside a band (gemm2.hip)
+template <int BN>
 __device__ __forceinline__ void g5_tile(int id, int tiles_n, int tile_rows, int& m0, int& n0) {
   const int band = id / (8 * tiles_n), first = band * 8;
   const int rows_here = min(8, tile_rows - first);
   const int within = id - band * 8 * tiles_n;
   m0 = (first + within % rows_here) * 128;
-  n0 = (within / rows_here) * 128;
+  n0 = (within / rows_here) * BN;
+}
+
+// Which tiles a block owns.  Round r of G tiles gives XCD x (= bid & 7: consecutive blocks go to consecutive XCDs) the ids
+// r G + x G/8 + (bid >> 3); the LAST, partial round is cut into eight equal chunks instead, so that a launch with fewer tiles
+// than blocks (the packed K = 3072 GEMMs: 116 or 232 tiles) still runs on all eight XCDs' L2s and memory paths rather than
+// on the first few (r05: 39-42 us inside the step against 28 us with everything in four XCDs' reach -- DESIGN section 7).
+struct G5Own {
+  int full, n, body0, tail_id, G;
+  __device__ __forceinline__ int id(int i) const { return i < full ? i * G + body0 : tail_id; }
+};
+__device__ __forceinline__ G5Own g5_own(int live, int G, int bid) {
+  G5Own o;
+  const int x = bid & 7, j = bid >> 3;
+  o.G = G;
+  o.full = live / G;
+  const int rem = live - o.full * G, per = (rem + 7) >> 3;
+  o.body0 = x * (G >> 3) + j;
+  o.tail_id = o.full * G + x * per + j;
+  o.n = o.full + ((j < per && x * per + j < rem) ? 1 : 0);
+  return o;
 }
 
 #ifdef MMT_G5_INSTR
@@ -74,8 +109,8 @@ __device__ __forceinline__ void g5_tile(int id, int tiles_n, int tile_rows, int&
 //   * Global accesses are MUBUF with a descriptor cut at the end of the matrix: rows past M are dropped (stores) / read as
 //     zero (loads) by the hardware's range check -- no predicates, no 64-bit address arithmetic (a per-lane 32-bit byte
 //     offset + a scalar step).  The host refuses matrices whose byte offsets do not fit 31 bits.
-template <int EPI>
-__device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* smem_raw, int row0, int col0, int grp, int w4,
+template <int EPI, int NJ>
+__device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][NJ], unsigned char* smem_raw, int row0, int col0, int grp, int w4,
                                             int lane, int M, int N, int nrows, void* __restrict__ Cout, int ldc,
                                             const MmtEpilogue& epi, int nbar, long long& t_work, long long& t_bar) {
   constexpr int P = G5_ST_P;
@@ -83,7 +118,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
   constexpr int ESZ = OUT16 ? 2 : 4;
   constexpr bool RES = EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_ADD_F32;
   constexpr bool BIAS = EPI == MMT_EPI_BIAS_BF16 || EPI == MMT_EPI_BIAS_GELU || EPI == MMT_EPI_BIAS_DROP_RES || EPI == MMT_EPI_BIAS_F32;
-  float* st = (float*)(smem_raw + G5_ST_OFF + w4 * G5_ST_WAVE);
+  float* st = (float*)(smem_raw + G5Lay<32 * NJ * 2>::ST_OFF + w4 * G5Lay<32 * NJ * 2>::ST_WAVE);
   const float* lut = (const float*)(smem_raw + G5_LUT_OFF);
   const int l31 = lane & 31, lh = lane >> 5;
   const int rq = lane >> 3, c4 = (lane & 7) * 4;  // sweep: row 8 t + rq of the 32-row image, columns c4 .. c4 + 3 of its 32
@@ -112,7 +147,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
   f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if constexpr (BIAS) {
     bias4[0] = *(const f32x4*)(epi.bias + col0 + c4);
-    bias4[1] = *(const f32x4*)(epi.bias + col0 + 32 + c4);
+    if constexpr (NJ == 2) bias4[1] = *(const f32x4*)(epi.bias + col0 + 32 + c4);
   }
   unsigned dkey = 0;
   if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
@@ -126,7 +161,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
   auto aux_index = [](int i, int j, int t) { return (i * 2 + j) * 4 + t; };
   if constexpr (EPI == MMT_EPI_DGELU) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         pf_aux[aux_index(0, j, t)] = __builtin_amdgcn_raw_buffer_load_b64(r2, (int)(off_2 + (unsigned)t * row8_2 + (unsigned)(j * 32 * 2)), 0, 0);
@@ -134,8 +169,8 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pass = i * 2 + j;
+    for (int j = 0; j < NJ; ++j) {
+      const int pass = i * NJ + j;
       // residual rows / original row numbers of this pass: all 4 steps' worth go out before the staging pass
       u32x4 pf_res[RES ? 4 : 1];
       int pf_orow[EPI == MMT_EPI_BIAS_DROP_RES ? 4 : 1];
@@ -158,7 +193,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
       if constexpr (EPI == MMT_EPI_DGELU) {
         if (pass == 0) {
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+          for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               pf_aux[aux_index(1, jj, t)] =
@@ -169,7 +204,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
       }
       if (pass == 0) {  // the bias has arrived HERE, on every path (else every later use waits vmcnt(0): stores too)
         asm volatile("" : "+v"(bias4[0]) :: "memory");
-        asm volatile("" : "+v"(bias4[1]) :: "memory");
+        if constexpr (NJ == 2) asm volatile("" : "+v"(bias4[1]) :: "memory");
       }
       f32x4 nxt[2] = {*(const f32x4*)(st + rq * P + c4), *(const f32x4*)(st + (8 + rq) * P + c4)};
 #pragma unroll
@@ -234,10 +269,10 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
           }
         }
         if constexpr (EPI == MMT_EPI_DGELU) {
-          if (pass == 3 && p == 1 && epi.colsum) {  // column sums of this wave's 64 rows -> LDS, in front of the last barrier
+          if (pass == 2 * NJ - 1 && p == 1 && epi.colsum) {  // column sums of this wave's 64 rows -> LDS, in front of the last barrier
             float* red = (float*)(smem_raw + G5_RED_OFF) + grp * 256 + (w4 >> 1) * 128 + (w4 & 1) * 64;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < NJ; ++jj) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 csum[jj][e] += __shfl_xor(csum[jj][e], 8, 64);
@@ -250,7 +285,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][2], unsigned char* 
             if (nbar == 0) g5_barrier();  // (the launch's last epilogue: only this group's waves are left to meet)
           }
         }
-        const int target = ((pass * 4 + 2 * p + 2) * nbar) >> 4;  // tick barriers owed after this pair of steps
+        const int target = ((pass * 4 + 2 * p + 2) * nbar) / (8 * NJ);  // tick barriers owed after this pair of steps
         if (done < target) {
           G5_TICK(t_work);
           while (done < target) { g5_barrier(); ++done; }
@@ -322,19 +357,60 @@ __device__ __forceinline__ void g5_tick(f32x16 (&acc)[2][2], G5Frags& fr, unsign
   else asm volatile(G5_SUB01 G5_SUB23_LAST G5_OPERANDS);
 }
 
-template <int EPI>
+// The same tick for the 128 x 64 tile (tile id 25: wave tile 64 x 32 = 2 x 1 fragments, 8 MFMAs and 12 reads per tick; a stage
+// is 24 KiB).  Operands: %0 %1 accumulators (a0, a1) | %2..%13 F0..F3 = {a0, a1, b0} | %14 %15 %16 addresses A0 A1 B0 |
+// %17..%19 temporaries | %20 ring-slot step.  Three reads per sub-step: lgkmcnt(3) in front of a sub-step leaves exactly the
+// NEXT sub-step's reads outstanding.
+#define G5N_AD(addr) "v_add_u32 " addr ", %20, " addr "\n\t"
+#define G5N_W3 "s_waitcnt lgkmcnt(3)\n\t"
+#define G5N_FILL01                                                                                                        \
+  G5_RD("%2", "%14") G5_RD("%4", "%16") G5_RD("%3", "%15")                                                                 \
+  G5_XR("%17", "32", "%14") G5_RD("%5", "%17") G5_XR("%19", "32", "%16") G5_RD("%7", "%19")                                \
+  G5_XR("%18", "32", "%15") G5_RD("%6", "%18")
+#define G5N_SUB01                                                                                                         \
+  G5N_W3 G5_MF("%0", "%4", "%2") G5_XR("%17", "64", "%14") G5_RD("%8", "%17") G5_XR("%19", "64", "%16") G5_RD("%10", "%19") \
+  G5_MF("%1", "%4", "%3") G5_XR("%18", "64", "%15") G5_RD("%9", "%18")                                                     \
+  G5N_W3 G5_MF("%0", "%7", "%5") G5_XR("%17", "96", "%14") G5_RD("%11", "%17") G5_XR("%19", "96", "%16") G5_RD("%13", "%19") \
+  G5_MF("%1", "%7", "%6") G5_XR("%18", "96", "%15") G5_RD("%12", "%18")
+#define G5N_SUB23_NEXT                                                                                                    \
+  G5N_W3 G5_MF("%0", "%10", "%8") G5N_AD("%14") G5_RD("%2", "%14") G5N_AD("%16") G5_RD("%4", "%16")                         \
+  G5_MF("%1", "%10", "%9") G5N_AD("%15") G5_RD("%3", "%15")                                                               \
+  G5N_W3 G5_MF("%0", "%13", "%11") G5_XR("%17", "32", "%14") G5_RD("%5", "%17") G5_XR("%19", "32", "%16") G5_RD("%7", "%19") \
+  G5_MF("%1", "%13", "%12") G5_XR("%18", "32", "%15") G5_RD("%6", "%18")
+#define G5N_SUB23_LAST                                                                                                    \
+  G5N_W3 G5_MF("%0", "%10", "%8") G5_MF("%1", "%10", "%9")                                                                 \
+  G5_W0 G5_MF("%0", "%13", "%11") G5_MF("%1", "%13", "%12") "s_nop 15\n\ts_nop 15\n\t"
+struct G5FragsN { u32x4 f[4][3]; };  // [k-sub-step][a0, a1, b0]
+#define G5N_OPERANDS                                                                                                       \
+  : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(fr.f[0][0]), "+v"(fr.f[0][1]), "+v"(fr.f[0][2]), "+v"(fr.f[1][0]), "+v"(fr.f[1][1]), \
+    "+v"(fr.f[1][2]), "=&v"(fr.f[2][0]), "=&v"(fr.f[2][1]), "=&v"(fr.f[2][2]), "=&v"(fr.f[3][0]), "=&v"(fr.f[3][1]),          \
+    "=&v"(fr.f[3][2]), "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2)                               \
+  : "s"(delta)                                                                                                             \
+  : "memory"
+template <int VARIANT>
+__device__ __forceinline__ void g5_tick(f32x16 (&acc)[2][1], G5FragsN& fr, unsigned (&ad)[3], int delta) {
+  unsigned t0, t1, t2;
+  if constexpr (VARIANT == 0) asm volatile(G5N_FILL01 G5N_SUB01 G5N_SUB23_NEXT G5N_OPERANDS);
+  else if constexpr (VARIANT == 1) asm volatile(G5N_SUB01 G5N_SUB23_NEXT G5N_OPERANDS);
+  else asm volatile(G5N_SUB01 G5N_SUB23_LAST G5N_OPERANDS);
+}
+
+template <int EPI, int BN>
 __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                     int64_t ldb, void* __restrict__ Cout, int64_t ldc, int M, int N, int K,
                                                     MmtEpilogue epi, const int32_t* __restrict__ n_rows_dev) {
   constexpr int NP = 4, PIECES = 32 / NP;  // producer waves; 1-KiB LDS-DMA pieces per producer wave and stage
+  constexpr int NJ = BN / 64;               // 32-column fragments of a consumer wave (wave tile 64 x 32 NJ)
+  static_assert(BN == 128 || BN == 64, "gemm5: tile width");
+  constexpr int RING = G5Lay<BN>::RING, BOFF = G5Lay<BN>::BOFF;
+  constexpr int LA = RING - 1;              // stages requested ahead of the tick that consumes them
   extern __shared__ __attribute__((aligned(256))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = (int)gridDim.x, bid = (int)blockIdx.x;
   const int nrows = n_rows_dev ? min(*n_rows_dev, M) : M;
-  const int tiles_n = N >> 7, tile_rows = (nrows + 127) >> 7, live = tile_rows * tiles_n;
-  // blocks on one XCD (bid & 7) own a contiguous chunk of ids in every round of G tiles
-  const int slot0 = (bid & 7) * (G >> 3) + (bid >> 3);
-  const int n = live > slot0 ? (live - slot0 + G - 1) / G : 0;  // tiles of this block
+  const int tiles_n = N / BN, tile_rows = (nrows + 127) >> 7, live = tile_rows * tiles_n;
+  const G5Own own = g5_own(live, G, bid);
+  const int n = own.n;  // tiles of this block
   const int KT = K >> 6;                                        // (>= 2: the host's check)
   if constexpr (EPI == MMT_EPI_DGELU) {
     if (epi.colsum) {  // row tiles past the live rows: their column sums are zero
@@ -353,6 +429,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
 
   if (wave >= 8) {  // ------------------------------------ producers ------------------------------------
     const int p = wave - 8;
+    if (BN == 64 && p == 3) return;  // (a stage has 24 pieces: two waves of A, one of B; an exited wave is not waited for)
     const int g0 = p * PIECES;         // this wave's first 8-row group: 0..15 = A rows, 16..31 = B rows
     const bool is_b = g0 >= 16;
     const int rg0 = g0 & 15;
@@ -364,7 +441,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
     const bf16_t* tile_base = base_g;
     auto setup = [&](int i) {
       int m0, n0;
-      g5_tile(slot0 + i * G, tiles_n, tile_rows, m0, n0);
+      g5_tile<BN>(own.id(i), tiles_n, tile_rows, m0, n0);
       const int r0 = is_b ? n0 : m0;
       tile_base = base_g + (int64_t)r0 * ld;
 #pragma unroll
@@ -377,7 +454,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
     int slot = 0;  // ring slot of the next stage to request
     auto issue = [&]() {
       const __amdgpu_buffer_rsrc_t desc = __builtin_amdgcn_make_buffer_rsrc((void*)tile_base, 0, 0x7fffffff, 0x00020000);
-      unsigned char* dst = smem_raw + slot * G5_HALF + (is_b ? G5_BOFF : 0) + rg0 * 1024;
+      unsigned char* dst = smem_raw + slot * G5_HALF + (is_b ? BOFF : 0) + rg0 * 1024;
 #ifndef G5_LAB_NO_DMA
 #pragma unroll
       for (int q = 0; q < PIECES; ++q)
@@ -385,28 +462,30 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
 #else
       (void)desc; (void)dst;
 #endif
-      slot = slot == G5_RING - 1 ? 0 : slot + 1;
+      slot = slot == RING - 1 ? 0 : slot + 1;
       if (++kt == KT) {
         kt = 0;
         if (++ti < n) setup(ti);
       }
     };
     // A consumer's tick tau reads stage tau and the first half of stage tau + 1: at the barrier that OPENS tick tau the
-    // stages <= tau + 1 have landed and the stages <= tau - 1 are free.  (S >= 2.)
+    // stages <= tau + 1 have landed and the stages <= tau - 1 are free, so the stages tau + 2 .. tau + LA are in flight or
+    // being requested.  (S >= 2.)
+    auto wait_all_but = [](int stages) {  // this wave's requests: PIECES per stage, answered in order
+      if (stages >= 2 && LA >= 4) g5_vmwait<2 * PIECES>();
+      else if (stages >= 1) g5_vmwait<PIECES>();
+      else g5_vmwait<0>();
+    };
     setup(0);
-    issue(); issue();
-    if (S > 2) { issue(); g5_vmwait<PIECES>(); }
-    else g5_vmwait<0>();
+    const int ahead = min(S, LA);
+    for (int q = 0; q < ahead; ++q) issue();
+    wait_all_but(ahead - 2);
     G5_TICK(t_a);
     g5_barrier();  // stages 0 and 1 have landed
     for (int tau = 0; tau < S; ++tau) {
-      if (tau + 3 < S) {  // the slot of stage tau - 1 takes stage tau + 3
-        issue();
-        G5_TICK(t_b);
-        g5_vmwait<PIECES>();  // stage tau + 2 has landed
-      } else {
-        g5_vmwait<0>();
-      }
+      if (tau + LA < S) issue();  // the slot of stage tau - 1 takes stage tau + LA
+      G5_TICK(t_b);
+      wait_all_but(min(LA - 2, S - 3 - tau));  // stage tau + 2 has landed (if there is one)
       G5_TICK(t_c);
       g5_barrier();
       G5_TICK(t_d);
@@ -431,7 +510,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   g5_barrier();  // stages 0 and 1 have landed; the GELU table is in LDS
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
   int slot = 0;  // ring slot of the stage the current tick consumes
   for (int i = 0; i <= n; ++i) {
     if ((i & 1) == grp) {
@@ -439,29 +518,33 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NJ; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
       // per-lane LDS addresses of this wave's sub-step-0 fragments in the current ring slot: row r, 16-byte chunk lh ^
       // ((r >> 1) & 7).  Rebuilt per tile (not live across this group's epilogue); the ticks move them from slot to slot.
-      unsigned ad[4];
+      unsigned ad[2 + NJ];
       {
         unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem_raw) + (unsigned)slot * G5_HALF;
         asm volatile("" : "+v"(lds0));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int ra = wm * 64 + h * 32 + l31, rb = wn * 64 + h * 32 + l31;
+          const int ra = wm * 64 + h * 32 + l31;
           ad[h] = lds0 + (unsigned)(ra * 128) + (unsigned)((lh ^ ((ra >> 1) & 7)) << 4);
-          ad[2 + h] = lds0 + (unsigned)G5_BOFF + (unsigned)(rb * 128) + (unsigned)((lh ^ ((rb >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int h = 0; h < NJ; ++h) {
+          const int rb = wn * 32 * NJ + h * 32 + l31;
+          ad[2 + h] = lds0 + (unsigned)BOFF + (unsigned)(rb * 128) + (unsigned)((lh ^ ((rb >> 1) & 7)) << 4);
         }
       }
-      G5Frags fr;
+      typename std::conditional<NJ == 2, G5Frags, G5FragsN>::type fr;
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) asm volatile("" : "=v"(fr.f[k][f]));  // (defined, not initialised: the first tick fills them)
-      auto delta_of = [](int s) { return __builtin_amdgcn_readfirstlane(s == G5_RING - 1 ? -(G5_RING - 1) * G5_HALF : G5_HALF); };
-      auto next = [](int s) { return s == G5_RING - 1 ? 0 : s + 1; };
+        for (int f = 0; f < 2 + NJ; ++f) asm volatile("" : "=v"(fr.f[k][f]));  // (defined, not initialised: the first tick fills them)
+      auto delta_of = [](int s) { return __builtin_amdgcn_readfirstlane(s == RING - 1 ? -(RING - 1) * G5_HALF : G5_HALF); };
+      auto next = [](int s) { return s == RING - 1 ? 0 : s + 1; };
       g5_tick<0>(acc, fr, ad, delta_of(slot));
       G5_TICK(t_a);
       g5_barrier();  // this stage may be overwritten; the next one has landed
@@ -482,10 +565,10 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
     } else {
       if (i >= 1) {
         int m0, n0;
-        g5_tile(slot0 + (i - 1) * G, tiles_n, tile_rows, m0, n0);
+        g5_tile<BN>(own.id(i - 1), tiles_n, tile_rows, m0, n0);
         const int nbar = i == n ? 0 : KT;
-        g5_epilogue<EPI>(acc, smem_raw, m0 + wm * 64, n0 + wn * 64, grp, w4, lane, M, N, nrows, Cout, (int)ldc, epi, nbar, t_c, t_d);
-        if constexpr (EPI == MMT_EPI_DGELU) {
+        g5_epilogue<EPI, NJ>(acc, smem_raw, m0 + wm * 64, n0 + wn * 32 * NJ, grp, w4, lane, M, N, nrows, Cout, (int)ldc, epi, nbar, t_c, t_d);
+        if constexpr (EPI == MMT_EPI_DGELU && NJ == 2) {
           if (epi.colsum && wm == 0 && lane < 16) {  // both wave rows' sums have crossed a barrier: one row of sums per 128 output rows
             const float* red = (const float*)(smem_raw + G5_RED_OFF) + grp * 256 + wn * 64 + lane * 4;
             const f32x4 s = *(const f32x4*)red + *(const f32x4*)(red + 128);
@@ -495,7 +578,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
       } else {
         for (int kt = 0; kt < KT; ++kt) g5_barrier();
       }
-      slot = (slot + KT) % G5_RING;
+      slot = (slot + KT) % RING;
 #ifdef MMT_G5_INSTR
       g5p = clock64();
 #endif
@@ -509,39 +592,53 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
 #endif
 }
 
-template <int EPI>
+template <int EPI, int BN>
 static int launch5(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
   static int cus = 0;
   if (!cus) {
-    if (hipFuncSetAttribute((const void*)gemm5_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS) != hipSuccess) return MMT_ERR_ARG;
+    if (hipFuncSetAttribute((const void*)gemm5_kernel<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G5Lay<BN>::LDS) != hipSuccess) return MMT_ERR_ARG;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MMT_ERR_ARG;
     cus = n > 8 ? (n & ~7) : 8;
   }
   // one block per CU (157 KiB of LDS each); a problem with fewer tiles than CUs starts a block per tile (rounded up to 8)
-  const int64_t tiles = (int64_t)((M + 127) / 128) * (N / 128);
+  const int64_t tiles = (int64_t)((M + 127) / 128) * (N / BN);
   const int grid = tiles >= cus ? cus : (int)((tiles + 7) & ~(int64_t)7);
-  hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3(grid), dim3(768), G5_LDS, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
+  hipLaunchKernelGGL((gemm5_kernel<EPI, BN>), dim3(grid), dim3(768), G5Lay<BN>::LDS, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
 
-// tile 24 of mmt_gemm2_dispatch: N % 128 == 0, K % 64 == 0, K >= 128; A / B rows are clamped to M - 1 / N - 1; the epilogue
-// addresses its matrices with 32-bit byte offsets (MUBUF range check instead of row predicates): each must stay below 2 GiB
-int mmt_gemm5_dispatch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N,
-                       int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-  if (N % 128 || K % 64 || K < 128) return MMT_ERR_ARG;
+// tiles 24 (bn = 128) / 25 (bn = 64) of mmt_gemm2_dispatch: N % bn == 0, K % 64 == 0, K >= 128; A / B rows are clamped to
+// M - 1 / N - 1; the epilogue addresses its matrices with 32-bit byte offsets (MUBUF range check instead of row predicates):
+// each must stay below 2 GiB.  The 64-wide tile is for the long-K GEMMs with narrow outputs (FFN down-projection, its input
+// gradient): no GELU epilogues, no row dots.
+int mmt_gemm5_dispatch(int epilogue, int bn, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M,
+                       int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
+  if ((bn != 128 && bn != 64) || N % bn || K % 64 || K < 128) return MMT_ERR_ARG;
   const int64_t lim = (int64_t)1 << 31, rows = (int64_t)M + 128;
   if (rows * ldc * 4 >= lim || rows * e.ldres * 4 >= lim || rows * e.ldout2 * 2 >= lim || rows * e.ldaux * 2 >= lim) return MMT_ERR_ARG;
+  if (bn == 64) {
+    if (e.dot_out) return MMT_ERR_ARG;
+    switch (epilogue) {
+      case MMT_EPI_BF16: return launch5<MMT_EPI_BF16, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      case MMT_EPI_BIAS_BF16: return launch5<MMT_EPI_BIAS_BF16, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      case MMT_EPI_BIAS_DROP_RES: return launch5<MMT_EPI_BIAS_DROP_RES, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      case MMT_EPI_ADD_F32: return launch5<MMT_EPI_ADD_F32, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      case MMT_EPI_F32: return launch5<MMT_EPI_F32, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+      case MMT_EPI_BIAS_F32: return launch5<MMT_EPI_BIAS_F32, 64>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    }
+    return MMT_ERR_ARG;
+  }
   switch (epilogue) {
-    case MMT_EPI_BF16: return launch5<MMT_EPI_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_BIAS_BF16: return launch5<MMT_EPI_BIAS_BF16>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_BIAS_GELU: return launch5<MMT_EPI_BIAS_GELU>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_BIAS_DROP_RES: return launch5<MMT_EPI_BIAS_DROP_RES>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_DGELU: return launch5<MMT_EPI_DGELU>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_ADD_F32: return launch5<MMT_EPI_ADD_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_F32: return launch5<MMT_EPI_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    case MMT_EPI_BIAS_F32: return launch5<MMT_EPI_BIAS_F32>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BF16: return launch5<MMT_EPI_BF16, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_BF16: return launch5<MMT_EPI_BIAS_BF16, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_GELU: return launch5<MMT_EPI_BIAS_GELU, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_DROP_RES: return launch5<MMT_EPI_BIAS_DROP_RES, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_DGELU: return launch5<MMT_EPI_DGELU, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_ADD_F32: return launch5<MMT_EPI_ADD_F32, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_F32: return launch5<MMT_EPI_F32, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+    case MMT_EPI_BIAS_F32: return launch5<MMT_EPI_BIAS_F32, 128>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   }
   return MMT_ERR_ARG;
 }

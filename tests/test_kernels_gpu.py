@@ -97,11 +97,11 @@ def test_gemm_nt_fused_epilogues(tile):
   _close('dgelu.colsum', colsum.sum(0), out.float().sum(0), 1e-2, 1e-4)
 
 
-# The product library holds the tiles the dispatcher selects on its own: 13 / 14 / 18 (gemm2.hip), 21 (gemm3.hip), 24
-# (gemm5.hip).  The tiles that were measured and lost live in the LAB library (python -m mmt_amd.build --lab, loaded through
+# The product library holds the tiles the dispatcher selects on its own: 13 / 14 / 18 (gemm2.hip), 21 (gemm3.hip), 24 / 25
+# (gemm5.hip: 128x128 / 128x64).  The tiles that were measured and lost live in the LAB library (python -m mmt_amd.build --lab, loaded through
 # MMT_HIP_LIB=mmt_amd/lib/libmmt_hip_lab.so); their parity cases run when that library is the one under test.
 _LAB = 'lab' in os.path.basename(os.environ.get('MMT_HIP_LIB', '')) or 'instr' in os.path.basename(os.environ.get('MMT_HIP_LIB', ''))
-_PRODUCT_TILES = [13, 14, 18, 24]
+_PRODUCT_TILES = [13, 14, 18, 24, 25]
 _LAB_TILES = [3, 4, 5, 7, 10, 11, 12, 19, 22, 23]
 
 
@@ -111,6 +111,36 @@ def test_gemm_nt_wide_tiles(tile, M, N, K):
   """gemm2.hip (128x128 / 128x64 tiles, 32x32x16 MFMA, LDS-staged epilogue; lab: 256x128 / 256x256 / ...) and gemm5.hip
   (tile 24: persistent, wave-specialised 128x128): every epilogue."""
   _wide_tile_case(tile, M, N, K)
+
+
+@pytest.mark.parametrize('tile', [24, 25])
+@pytest.mark.parametrize('M,N,K,live', [(6976, 512, 3072, 3639), (6976, 512, 3072, 1), (7168, 1536, 512, 3001), (2048, 512, 256, 2048),
+                                        (6976, 512, 3072, 6976)])
+def test_persistent_gemm_on_packed_rows(tile, M, N, K, live):
+  """gemm5.hip under token packing: the live row count is on the device, the grid is sized for the allocated rows.  Fewer live
+  tiles than blocks (the last, partial round is spread over the eight XCDs), several tiles per block plus a partial round,
+  one live row, every row live.  Tile rows past the live ones are not written; results agree with the 128x64 tile's."""
+  from mmt_amd import ops
+  R = ops.pad_rows(M)
+  a = _rand((R, K), seed=61, dtype=torch.bfloat16)
+  b = _rand((N, K), 0.05, seed=62, dtype=torch.bfloat16)
+  bias, res = _rand((N,), seed=63), _rand((R, N), seed=64)
+  nrd = torch.tensor([live], device=_dev(), dtype=torch.int32)
+  edge = min(R, (live + 127) // 128 * 128)
+  ref = a[:live].float() @ b.float().t()
+  for epi, kw, dt in (('BIAS_DROP_RES', dict(bias=bias, res=res, drop_key=99, drop_p=0.1), torch.float32),
+                      ('ADD_F32', dict(res=res), torch.float32), ('BF16', {}, torch.bfloat16)):
+    got = torch.full((R, N), 7.0, device=_dev(), dtype=dt)
+    want = torch.full((R, N), 7.0, device=_dev(), dtype=dt)
+    ops.gemm_nt(a, b, got, epi, m=M, n_rows_dev=nrd, tile=tile, **kw)
+    ops.gemm_nt(a, b, want, epi, m=M, n_rows_dev=nrd, tile=13, **kw)
+    if dt == torch.float32:  # same K order and dropout mask; the epilogues may contract their fp32 arithmetic differently
+      _close(epi + ' vs the 128x64 tile', got[:live], want[:live], 1e-5, 1e-5)
+    else:
+      _close(epi + ' vs the 128x64 tile', got[:live], want[:live], 1e-2, 1e-2)
+    assert bool((got[edge:] == 7.0).all()), epi
+    if epi == 'ADD_F32':
+      _close('add_f32 vs fp32 reference', got[:live], ref + res[:live], 2e-3, 2e-4)
 
 
 def test_lab_tiles_are_not_in_the_product_library():

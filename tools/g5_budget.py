@@ -58,12 +58,16 @@ def budget(name, live, dense, N, K, epi, tile=24, cold=False):
   e.record()
   torch.cuda.synchronize()
   us = s.elapsed_time(e) / 20 * 1e3
+  fl = 2.0 * live * N * K
+  if tile not in (24, 25):  # (a gemm2 tile beside it: the time only)
+    print('%-28s rows %d N %d K %d tile %d: %.1f us in a graph = %.0f TFLOP/s (%.3f of 2.5 PF)' %
+          (name, live, N, K, tile, us, fl / us / 1e6, fl / us / 1e6 / 2500))
+    return
   if cold:
     fill.fill_(1.0)
   go(dbg)
   torch.cuda.synchronize()
   d = dbg.cpu().double().view(256, 3, 8)
-  fl = 2.0 * live * N * K
   print('%-28s rows %d N %d K %d tile %d: %.1f us in a graph = %.0f TFLOP/s (%.3f of 2.5 PF)%s' %
         (name, live, N, K, tile, us, fl / us / 1e6, fl / us / 1e6 / 2500, '   [budget launch: operands COLD]' if cold else ''))
   for n_tiles in sorted(set(d[:, 2, 6].long().tolist())):
@@ -74,20 +78,27 @@ def budget(name, live, dense, N, K, epi, tile=24, cold=False):
     c0, c1, pr = d[sel, 0].mean(0), d[sel, 1].mean(0), d[sel, 2].mean(0)
     S = pr[5].item()
     kt = S / n_tiles
-    print('   %3d blocks with %d tiles (%d stages of 32 KiB): whole block %6.0f cycles = %5.0f per tile, %4.0f per K-step' %
-          (blocks, n_tiles, S, pr[4].item(), pr[4].item() / n_tiles, pr[4].item() / S))
+    stage = 24576 if tile == 25 else 32768
+    print('   %3d blocks with %d tiles (%d stages of %d KiB): whole block %6.0f cycles = %5.0f per tile, %4.0f per K-step' %
+          (blocks, n_tiles, S, stage >> 10, pr[4].item(), pr[4].item() / n_tiles, pr[4].item() / S))
     for name_, c in (('consumer group 0', c0), ('consumer group 1', c1)):
       print('      %s: K-loop work %6.0f + barrier %6.0f | epilogue work %6.0f + barrier %6.0f | alive %6.0f' %
             (name_, c[0].item(), c[1].item(), c[2].item(), c[3].item(), c[4].item()))
     print('      producer wave 0  : prologue %5.0f | issue %6.0f (%4.0f per stage) + vmcnt wait %6.0f + barrier %6.0f | alive %6.0f   -> %4.1f B/clk/CU over its life' %
           (pr[0].item(), pr[1].item(), pr[1].item() / max(S - 2, 1), pr[2].item(), pr[3].item(), pr[4].item(),
-           S * 32768 / max(pr[4].item(), 1)))
+           S * stage / max(pr[4].item(), 1)))
   sys.stdout.flush()
 
 
 if __name__ == '__main__':
   live = int(sys.argv[1]) if len(sys.argv) > 1 else 3639
   cold = '--cold' in sys.argv
+  if '--narrow' in sys.argv:  # the long-K GEMMs with narrow outputs: gemm2's phased 128x64 tile, gemm5 on 128x128 and 128x64 tiles
+    for rows in (live, 6976):
+      for tile in (18, 24, 25):
+        budget('FFN-down + bias + residual', rows, 6976, 512, 3072, 'BIAS_DROP_RES', tile=tile, cold=cold)
+        budget('FFN-up input gradient + res', rows, 6976, 512, 3072, 'ADD_F32', tile=tile, cold=cold)
+    sys.exit(0)
   budget('FFN-up + bias + GELU', live, 6976, 3072, 512, 'BIAS_GELU', cold=cold)
   budget('dGELU input gradient', live, 6976, 3072, 512, 'DGELU', cold=cold)
   budget('QKV + bias', live, 6976, 1536, 512, 'BIAS_BF16', cold=cold)
