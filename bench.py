@@ -202,11 +202,11 @@ def site_roofline(site, rows, sec, used, sq_sum=0.0):
   elif site == 0:
     name, flops = 'FFN up-projection GEMM + bias + erf-GELU (N=%d, K=%d; gemm2_kernel, EPI BIAS_GELU)' % (i, d), 2.0 * rows * i * d
     nbytes = rows * d * 2 + i * d * 2 + 2 * rows * i * 2
-    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2', 'gemm3_kernel<2>', 'gemm5_kernel<2>'], None
+    subs, grid = ['gemm2_kernel<256, 192, 4, 2, 2, 2', 'gemm2_kernel<128, 128, 2, 4, 2, 2', 'gemm3_kernel<2>', 'gemm5_kernel<2>', 'gemm5_kernel<2, 128>'], None
   elif site == 1:
-    name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
+    name, flops = 'FFN down-projection GEMM + bias + dropout + residual (N=%d, K=%d; gemm2_kernel<128,64> phased or gemm5_kernel, EPI BIAS_DROP_RES)' % (d, i), 2.0 * rows * d * i
     nbytes = rows * i * 2 + d * i * 2 + 2 * rows * d * 4
-    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3', 'gemm2_kernel<128, 128, 2, 4, 2, 3', 'gemm3_kernel<3>'], None
+    subs, grid = ['gemm2_kernel<128, 64, 2, 2, 4, 3', 'gemm2_kernel<128, 64, 4, 2, 3, 3', 'gemm2_kernel<128, 128, 2, 4, 2, 3', 'gemm3_kernel<3>', 'gemm5_kernel<3, 128>', 'gemm5_kernel<3, 64>'], None
   else:
     name = 'grouped weight gradients of one encoder layer (dW1, dW2, dWqkv, dWo + bias gradients; wgrad_phased_kernel)'
     flops = 2.0 * rows * (2 * i * d + 4 * d * d)

@@ -53,6 +53,11 @@ template <int BN> struct G5Lay {
   static constexpr int LDS = BN == 64 ? 2 * RING * G5_HALF : G5_LDS;
   static constexpr int ST_OFF = BN == 64 ? BOFF + G5_HALF / 2 : G5_ST_OFF;
   static constexpr int ST_WAVE = BN == 64 ? G5_HALF : G5_ST_WAVE;
+  // producer waves.  A wave gets its requests answered at ~1 piece per 120 cycles when the operands come from far memory
+  // (r05 cold budgets: 8 pieces per ~1000 cycles per wave, with three waves as with four), so the narrow tile -- whose
+  // consumers need < 128 registers -- spreads a stage over six waves of four pieces (sixteen waves per block).
+  static constexpr int NP = BN == 64 ? 8 : 4;
+  static constexpr int THREADS = 512 + 64 * NP;
 };
 static_assert(G5Lay<64>::LDS <= 163840 && G5_ST_WAVE <= G5_HALF / 2, "gemm5: LDS budget of the 128 x 64 tile");
 template <int N> __device__ __forceinline__ void g5_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -63,8 +68,17 @@ __device__ __forceinline__ void g5_barrier() {
 }
 
 // tile id -> (m0, n0): bands of 8 tile rows, column by column inside a band (gemm2.hip)
+// Narrow outputs (<= 8 tile columns: N = 512) go row by row instead: an XCD's chunk of consecutive ids is then a few WHOLE tile
+// rows, every A row-tile -- the long-K GEMMs' big operand -- is fetched from far memory by one XCD only and shared by its
+// column tiles through that XCD's L2 (column by column inside a band, 29 ids are 8 rows x 3.6 columns: A comes in 2.2 times).
 template <int BN>
 __device__ __forceinline__ void g5_tile(int id, int tiles_n, int tile_rows, int& m0, int& n0) {
+  if (tiles_n <= 8) {
+    const int r = id / tiles_n;
+    m0 = r * 128;
+    n0 = (id - r * tiles_n) * BN;
+    return;
+  }
   const int band = id / (8 * tiles_n), first = band * 8;
   const int rows_here = min(8, tile_rows - first);
   const int within = id - band * 8 * tiles_n;
@@ -396,10 +410,11 @@ __device__ __forceinline__ void g5_tick(f32x16 (&acc)[2][1], G5FragsN& fr, unsig
 }
 
 template <int EPI, int BN>
-__global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(G5Lay<BN>::THREADS) void gemm5_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                     int64_t ldb, void* __restrict__ Cout, int64_t ldc, int M, int N, int K,
                                                     MmtEpilogue epi, const int32_t* __restrict__ n_rows_dev) {
-  constexpr int NP = 4, PIECES = 32 / NP;  // producer waves; 1-KiB LDS-DMA pieces per producer wave and stage
+  constexpr int NP = G5Lay<BN>::NP, PIECES = 32 / NP;  // producer waves; 1-KiB LDS-DMA pieces per producer wave and stage
+  constexpr int THREADS = G5Lay<BN>::THREADS;
   constexpr int NJ = BN / 64;               // 32-column fragments of a consumer wave (wave tile 64 x 32 NJ)
   static_assert(BN == 128 || BN == 64, "gemm5: tile width");
   constexpr int RING = G5Lay<BN>::RING, BOFF = G5Lay<BN>::BOFF;
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
   if constexpr (EPI == MMT_EPI_DGELU) {
     if (epi.colsum) {  // row tiles past the live rows: their column sums are zero
       const int64_t dead = (int64_t)((M + 127) / 128 - tile_rows) * N;
-      for (int64_t i = (int64_t)bid * 768 + tid; i < dead; i += (int64_t)G * 768) epi.colsum[(int64_t)tile_rows * N + i] = 0.f;
+      for (int64_t i = (int64_t)bid * THREADS + tid; i < dead; i += (int64_t)G * THREADS) epi.colsum[(int64_t)tile_rows * N + i] = 0.f;
     }
   }
   if (n == 0) return;
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const bf16_t* __restrict__ A
 
   if (wave >= 8) {  // ------------------------------------ producers ------------------------------------
     const int p = wave - 8;
-    if (BN == 64 && p == 3) return;  // (a stage has 24 pieces: two waves of A, one of B; an exited wave is not waited for)
+    if (p * PIECES >= 16 + BN / 8) return;  // (128 x 64: a stage has 24 pieces, the last waves have none; an exited wave is not waited for)
     const int g0 = p * PIECES;         // this wave's first 8-row group: 0..15 = A rows, 16..31 = B rows
     const bool is_b = g0 >= 16;
     const int rg0 = g0 & 15;
@@ -605,7 +620,7 @@ static int launch5(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   // one block per CU (157 KiB of LDS each); a problem with fewer tiles than CUs starts a block per tile (rounded up to 8)
   const int64_t tiles = (int64_t)((M + 127) / 128) * (N / BN);
   const int grid = tiles >= cus ? cus : (int)((tiles + 7) & ~(int64_t)7);
-  hipLaunchKernelGGL((gemm5_kernel<EPI, BN>), dim3(grid), dim3(768), G5Lay<BN>::LDS, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
+  hipLaunchKernelGGL((gemm5_kernel<EPI, BN>), dim3(grid), dim3(G5Lay<BN>::THREADS), G5Lay<BN>::LDS, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
   return (int)hipGetLastError();
 }
 
