@@ -164,7 +164,23 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][NJ], unsigned char*
     if constexpr (NJ == 2) bias4[1] = *(const f32x4*)(epi.bias + col0 + 32 + c4);
   }
   unsigned dkey = 0;
-  if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) dkey = eff_key(epi.drop_key, epi.seed_dev);
+  // dropout: the original row numbers (RNG coordinate) of this wave's 8 sweep rows per lane, requested HERE -- before the
+  // first store of the epilogue and without a branch (a null table is a descriptor of zero records): a load behind a
+  // condition makes the compiler wait with vmcnt(0) at every use, which waits for every store issued so far as well (r05:
+  // 43 us for the FFN down-projection inside the unpacked step against 28 us for the same GEMM without dropout)
+  int orow_all[EPI == MMT_EPI_BIAS_DROP_RES ? 8 : 1];
+  if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+    dkey = eff_key(epi.drop_key, epi.seed_dev);
+    const bool use_ri = epi.drop_thr16 != 0 && epi.row_index != nullptr;
+    const __amdgpu_buffer_rsrc_t rri =
+        __builtin_amdgcn_make_buffer_rsrc(use_ri ? (void*)epi.row_index : (void*)Cout, 0, use_ri ? M * 4 : 0, FLAGS);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = row0 + (k >> 2) * 32 + 8 * (k & 3) + rq;
+      const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rri, row * 4, 0, 0);
+      orow_all[k] = use_ri ? v : row;
+    }
+  }
   float csum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float dotp[4] = {0.f, 0.f, 0.f, 0.f};  // BF16 + dot_out: the j = 0 half of a row's dot product waits for the j = 1 half
   int done = 0;
@@ -187,14 +203,9 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][NJ], unsigned char*
       const int pass = i * NJ + j;
       // residual rows / original row numbers of this pass: all 4 steps' worth go out before the staging pass
       u32x4 pf_res[RES ? 4 : 1];
-      int pf_orow[EPI == MMT_EPI_BIAS_DROP_RES ? 4 : 1];
       if constexpr (RES) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
-            const int row = min(row0 + i * 32 + 8 * t + rq, M - 1);
-            pf_orow[t] = (epi.drop_thr16 && epi.row_index) ? epi.row_index[row] : row;
-          }
           pf_res[t] = __builtin_amdgcn_raw_buffer_load_b128(r2, (int)(off_2 + (unsigned)(i * 4 + t) * row8_2 + (unsigned)(j * 32 * ESZ2)), 0, 0);
         }
       }
@@ -217,6 +228,10 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][NJ], unsigned char*
         }
       }
       if (pass == 0) {  // the bias has arrived HERE, on every path (else every later use waits vmcnt(0): stores too)
+        if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(orow_all[k]));
+        }
         asm volatile("" : "+v"(bias4[0]) :: "memory");
         if constexpr (NJ == 2) asm volatile("" : "+v"(bias4[1]) :: "memory");
       }
@@ -258,7 +273,7 @@ __device__ __forceinline__ void g5_epilogue(f32x16 (&acc)[2][NJ], unsigned char*
           } else if constexpr (EPI == MMT_EPI_BIAS_DROP_RES) {
             if (epi.drop_thr16) {
               bool k[4];
-              keep4(dkey, (unsigned long long)pf_orow[t] * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
+              keep4(dkey, (unsigned long long)orow_all[i * 4 + t] * (unsigned)N + (unsigned)col, epi.drop_thr16, k);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = k[e] ? v[e] * epi.drop_scale : 0.f;
             }

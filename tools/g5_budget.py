@@ -20,7 +20,7 @@ def rnd(*shape, dtype=bf, scale=1.0):
   return (torch.randn(*shape, device=dev) * scale).to(dtype)
 
 
-def budget(name, live, dense, N, K, epi, tile=24, cold=False):
+def budget(name, live, dense, N, K, epi, tile=24, cold=False, drop=0.0):
   R = ops.pad_rows(dense)
   a, b = rnd(R, K), rnd(N, K, scale=0.05)
   out = torch.zeros(R, N, device=dev, dtype=torch.float32 if epi in ('BIAS_DROP_RES', 'ADD_F32', 'F32') else bf)
@@ -34,6 +34,8 @@ def budget(name, live, dense, N, K, epi, tile=24, cold=False):
     extra['res'] = rnd(R, N, dtype=torch.float32)
   if epi == 'DGELU':
     extra['aux'] = rnd(R, N)
+  if drop:
+    extra.update(drop_key=1234, drop_p=drop)
   dbg = torch.zeros(256 * 3, 8, device=dev, dtype=torch.int64)
   fill = torch.empty(768 << 18, device=dev, dtype=torch.float32) if cold else None  # 768 MB: evicts L2 + Infinity Cache
 
@@ -94,6 +96,11 @@ if __name__ == '__main__':
   live = int(sys.argv[1]) if len(sys.argv) > 1 else 3639
   cold = '--cold' in sys.argv
   if '--narrow' in sys.argv:  # the long-K GEMMs with narrow outputs: gemm2's phased 128x64 tile, gemm5 on 128x128 and 128x64 tiles
+    if '--drop' in sys.argv:  # dropout on (as inside the step) against off
+      for d in (0.0, 0.1):
+        budget('FFN-down, dropout p = %.1f' % d, 6976, 6976, 512, 3072, 'BIAS_DROP_RES', tile=24, cold=cold, drop=d)
+        budget('FFN-down, dropout p = %.1f' % d, live, 6976, 512, 3072, 'BIAS_DROP_RES', tile=25, cold=cold, drop=d)
+      sys.exit(0)
     for rows in (live, 6976):
       for tile in (18, 24, 25):
         budget('FFN-down + bias + residual', rows, 6976, 512, 3072, 'BIAS_DROP_RES', tile=tile, cold=cold)
