@@ -40,6 +40,7 @@ region's gradients are final -- HBM-bound work under MFMA-bound work; the text h
 Everything data-dependent lives in device memory (live row count of the token packing, dropout seed,
 Adam step counter), so replays are correct for new minibatches copied into the static input buffers.
 """
+import time
 import torch
 import torch.distributed as dist
 
@@ -777,6 +778,16 @@ class GraphedTrainStep:
     self._opt()
 
   # ---- capture -----------------------------------------------------------------------------------
+  def _quiesce_watchdog(self):
+    """RCCL's process group keeps every eager collective on a list that its watchdog thread polls (an event query per entry,
+    every ~100 ms) until the collective has finished.  A poll that lands inside an open stream capture of THIS thread is legal
+    in thread-local capture mode, but has been seen to end the process on ROCm (one full-suite run in two: the watchdog
+    thread dies with a c10::Error while the step graph is being captured).  Before a capture: finish the device's work and
+    give the watchdog time for the poll that retires the finished entries -- nothing is left for it to query."""
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+      torch.cuda.synchronize()
+      time.sleep(0.35)
+
   def _capture(self):
     torch.cuda.synchronize()
     self._zero()
@@ -790,13 +801,15 @@ class GraphedTrainStep:
       return
     ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     e = g = pool = None
-    if self._multi or self.staged:
+    self._quiesce_watchdog()  # (the warm-up steps' collectives)
+    if (self._multi or self.staged) and not (self._multi and self.capture_collectives):
       with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
         e = self._forward()
         self._upload_branch_end()
       pool = ga.pool()
       with torch.cuda.stream(self._stream):
         g = self._gather(e)
+      self._quiesce_watchdog()  # (the eager all-gather just issued)
     if self._multi and self.capture_collectives:
       # EXPERIMENTAL (opt-in): the collectives are captured too, so a multi-rank step is ONE graph launch like the
       # single-rank one -- RCCL's stream joins the capture through the events torch.distributed records, the cross-stream
