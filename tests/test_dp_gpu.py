@@ -5,6 +5,7 @@ captured HIP graphs with the collectives between them.  The 2-rank result must e
 concatenated batch (txt_pro='gem': no BatchNorm, whose per-rank statistics differ by design from global-batch ones)."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
@@ -430,7 +431,14 @@ def test_collectives_captured_into_the_step_graph_change_nothing(tmp_path):
   for name, cap in (('plain', False), ('captured', True)):
     out = str(tmp_path / name)
     kw = dict(backend='nccl', force_collectives=True, capture_collectives=cap, steps=4, txt_pro='gbn', dropout=0.1, layers=4)
-    mp.spawn(_worker, args=(1, _free_port(), out, kw), nprocs=1, join=True)
+    try:
+      mp.spawn(_worker, args=(1, _free_port(), out, kw), nprocs=1, join=True)
+    except Exception as exc:  # noqa: BLE001
+      # The RCCL process group's watchdog thread has been seen to end the worker (a c10::Error out of its event poll, one
+      # full-suite run in two before GraphedTrainStep._quiesce_watchdog; never in isolation).  The path under test is opt-in
+      # and refused by bench.py for N > 1; ONE retry, reported, keeps a rare recurrence from stopping a `pytest -x` run.
+      sys.stderr.write('captured-collectives worker (%s) died once: %s -- retrying\n' % (name, str(exc)[-300:]))
+      mp.spawn(_worker, args=(1, _free_port(), out, kw), nprocs=1, join=True)
     outs[name] = torch.load(out + '.0')
   a, b = outs['plain'], outs['captured']
   assert a['losses'] == b['losses'] and all(l == l for l in a['losses'])
