@@ -29,6 +29,12 @@
 #include "gemm_epi.h"
 
 #define G5_RING 4
+#ifndef G5_LAB_AUX_A   // lab: cache-policy bits of the LDS-DMA requests (1 sc0, 2 nt, 16 sc1) for the A / B operand
+#define G5_LAB_AUX_A 0
+#endif
+#ifndef G5_LAB_AUX_B
+#define G5_LAB_AUX_B 0
+#endif
 #define G5_HALF 16384                                    // one operand of a stage: 128 rows x 128 B
 // LDS: [A slots 0..3 | GELU table | epilogue images | column-sum scratch | B slots 0..3].  The table sits at 64 KiB so that
 // (table - 4 * MMT_GELU_LUT_LO) fits the 16-bit ds offset field (a gather is then med3 + shift + ds_read_b32).
@@ -488,7 +494,10 @@ __global__ __launch_bounds__(G5Lay<BN>::THREADS) void gemm5_kernel(const bf16_t*
 #ifndef G5_LAB_NO_DMA
 #pragma unroll
       for (int q = 0; q < PIECES; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(desc, LDS_PTR(dst + q * 1024), 16, (int)voff[q], kt * 128, 0, 0);
+        if (G5_LAB_AUX_A == G5_LAB_AUX_B || !is_b)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(desc, LDS_PTR(dst + q * 1024), 16, (int)voff[q], kt * 128, 0, G5_LAB_AUX_A);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(desc, LDS_PTR(dst + q * 1024), 16, (int)voff[q], kt * 128, 0, G5_LAB_AUX_B);
 #else
       (void)desc; (void)dst;
 #endif
