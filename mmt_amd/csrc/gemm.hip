@@ -1025,6 +1025,10 @@ static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb,
       const char* q = getenv("MMT_TILE_PPN");
       ppn = q ? atoi(q) : 1;
     }
+    // (lab: 5 = tile 25 for EVERY packed narrow GEMM, 6 = for the K < 1536 ones only -- the K = hidden GEMMs with N = 512)
+    if (ppn >= 5 && N < 1024 && N % 64 == 0 && K >= 128 && K % 64 == 0 && nr != nullptr && EPI != MMT_EPI_BIAS_GELU &&
+        EPI != MMT_EPI_DGELU && e.dot_out == nullptr && (ppn == 5 || K < 1536))
+      return mmt_gemm2_dispatch(25, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
     if (ppn && N < 1024 && N % 128 == 0 && K >= 1536 && EPI != MMT_EPI_BIAS_GELU && EPI != MMT_EPI_DGELU && e.dot_out == nullptr) {
       const double t128 = (double)((M + 127) / 128) * (nr ? frac : 1.0) * (N / 128);
       const int t = ppn == 2 ? 24 : ppn == 3 ? 25 : t128 >= 200.0 ? 24 : ppn == 4 ? 25 : 0;
