@@ -1,4 +1,4 @@
-// Persistent wave-specialised NT GEMM for the wide K = hidden GEMMs (QKV, FFN up-projection + GELU, dGELU) on gfx950
+// Persistent wave-specialised NT GEMM on gfx950, written for the wide K = hidden GEMMs (QKV, FFN up-projection + GELU, dGELU)
 // (tile id 24 of the dispatcher):   C[M,N] = A[M,K] . B[N,K]^T (+ the fused epilogues of gemm2), 128 x 128 tiles.
 //
 // Why: profiles/r04_gemm2_budget.txt -- at 3.6 k live rows x N = 3072 x K = 512 a 128x128 block of gemm2.hip is prologue
@@ -21,8 +21,15 @@
 // statement: every MFMA is followed by one fragment read, TWO k-sub-steps ahead of the sub-step being multiplied, the last
 // two sub-steps read the first two of the NEXT stage (which is why the ring is four deep: a stage has landed a whole tick
 // before its tick), and the fragment addresses advance in the MFMA shadows (g5_tick below; budgets:
-// profiles/r05_g5_budget*.txt).  Blocks walk the live tiles in the XCD-aware band order of gemm2 (block b owns ids
-// slot(b), slot(b) + G, ...).
+// profiles/r05_g5_budget*.txt).  Blocks walk the live tiles in an XCD-aware order (g5_tile / g5_own below): bands of eight
+// tile rows for wide outputs, row by row for narrow ones, the last partial round of tiles spread over all eight XCDs.
+//
+// The same kernel serves the long-K GEMMs with narrow outputs (N = 512, K = 1536 / 3072: FFN down-projection, input
+// gradients): on 128 x 128 tiles where those fill a round of the chip, and as a second instantiation on 128 x 64 tiles
+// (tile id 25: wave tile 64 x 32, five-deep ring of 24 KiB stages, six producer waves, sixteen waves per block -- G5Lay<64>)
+// for row counts where they do not.  What bounds these inside a training step is not this file: with the operands coming
+// from Infinity Cache / HBM a CU gets ~18 B/clk whatever the ring depth, the number of producers or the tile order
+// (profiles/r05_g5_narrow_budget_cold.txt; DESIGN.md section 7, "r05 (late)").
 #include <type_traits>
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
