@@ -34,6 +34,7 @@
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include "gemm_epi.h"
+#include "g5_own.h"
 
 #define G5_RING 4
 #ifndef G5_LAB_AUX_A   // lab: cache-policy bits of the LDS-DMA requests (1 sc0, 2 nt, 16 sc1) for the A / B operand
@@ -78,45 +79,6 @@ __device__ __forceinline__ void g5_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-}
-
-// tile id -> (m0, n0): bands of 8 tile rows, column by column inside a band (gemm2.hip)
-// Narrow outputs (<= 8 tile columns: N = 512) go row by row instead: an XCD's chunk of consecutive ids is then a few WHOLE tile
-// rows, every A row-tile -- the long-K GEMMs' big operand -- is fetched from far memory by one XCD only and shared by its
-// column tiles through that XCD's L2 (column by column inside a band, 29 ids are 8 rows x 3.6 columns: A comes in 2.2 times).
-template <int BN>
-__device__ __forceinline__ void g5_tile(int id, int tiles_n, int tile_rows, int& m0, int& n0) {
-  if (tiles_n <= 8) {
-    const int r = id / tiles_n;
-    m0 = r * 128;
-    n0 = (id - r * tiles_n) * BN;
-    return;
-  }
-  const int band = id / (8 * tiles_n), first = band * 8;
-  const int rows_here = min(8, tile_rows - first);
-  const int within = id - band * 8 * tiles_n;
-  m0 = (first + within % rows_here) * 128;
-  n0 = (within / rows_here) * BN;
-}
-
-// Which tiles a block owns.  Round r of G tiles gives XCD x (= bid & 7: consecutive blocks go to consecutive XCDs) the ids
-// r G + x G/8 + (bid >> 3); the LAST, partial round is cut into eight equal chunks instead, so that a launch with fewer tiles
-// than blocks (the packed K = 3072 GEMMs: 116 or 232 tiles) still runs on all eight XCDs' L2s and memory paths rather than
-// on the first few (r05: 39-42 us inside the step against 28 us with everything in four XCDs' reach -- DESIGN section 7).
-struct G5Own {
-  int full, n, body0, tail_id, G;
-  __device__ __forceinline__ int id(int i) const { return i < full ? i * G + body0 : tail_id; }
-};
-__device__ __forceinline__ G5Own g5_own(int live, int G, int bid) {
-  G5Own o;
-  const int x = bid & 7, j = bid >> 3;
-  o.G = G;
-  o.full = live / G;
-  const int rem = live - o.full * G, per = (rem + 7) >> 3;
-  o.body0 = x * (G >> 3) + j;
-  o.tail_id = o.full * G + x * per + j;
-  o.n = o.full + ((j < per && x * per + j < rem) ? 1 : 0);
-  return o;
 }
 
 #ifdef MMT_G5_INSTR

@@ -244,3 +244,22 @@ def test_bench_refuses_captured_collectives_on_several_gpus():
   out = r.stdout + r.stderr
   assert 'refusing --gpus 2' in out and 'MMT_ALLOW_CAPTURED_COLLECTIVES' in out
   assert '"metric"' not in out  # no result line
+
+
+def test_persistent_gemm_tile_ownership_is_an_exact_cover(tmp_path):
+  """mmt_amd/csrc/g5_own.h (tile order + which block owns which tile of gemm5.hip's persistent launches), compiled for the
+  host with hipcc and swept over tile-grid shapes and launch sizes: every live tile is owned exactly once, maps to a distinct
+  in-range (row, column), and the last partial round never gives an XCD more than an eighth (rounded up) of what is left --
+  the r05 mapping left half the XCDs idle on the packed long-K GEMMs."""
+  import shutil
+  import subprocess
+  hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  if not os.path.exists(hipcc):
+    pytest.skip('hipcc not found')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  exe = str(tmp_path / 'g5_own_check')
+  r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', os.path.join(root, 'tests', 'helpers', 'g5_own_check.hip'),
+                      '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=str(tmp_path))
+  assert r.returncode == 0, r.stdout[-2000:]
+  r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+  assert r.returncode == 0 and r.stdout.startswith('ok '), r.stdout[-2000:]
