@@ -399,6 +399,9 @@ def main():
                   help='bit mask of the work that leaves the main stream for a parallel branch of the step graph '
                        '(mmt_amd.train_step.FORK_*: 1 weight gradients, 2 ... in two early launches, 4 LN/table reductions, '
                        '16 per-region Adam, 32 text heads, 64 ReduceDim weight gradients); default 0 = one serial chain (forked graphs measured slower, DESIGN section 7)')
+  ap.add_argument('--no-adam-riders', action='store_true',
+                  help='one rank: the optimizer as ONE launch after the backward (r01-r05) instead of riding in the '
+                       'backward\'s GEMM launches (GraphedTrainStep(adam_riders=))')
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
@@ -501,7 +504,8 @@ def main():
                               force_collectives=args.force_collectives, grad_dtype=grad_dtype,
                               capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
                               input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer,
-                              host_feed=batches if in_graph_feed else None)
+                              host_feed=batches if in_graph_feed else None,
+                              adam_riders=False if args.no_adam_riders else None)
     runner.measure_exposed = world > 1 or args.force_collectives
     runner.host_sync_uploads = not args.stream_wait_uploads
     nonlocal slots_used, in_graph_feed_used
@@ -593,6 +597,13 @@ def main():
   torch.cuda.synchronize()
   site_times = {st: pr.finish(stride=towers, offset=towers - 1) for st, pr in probes.items()}
   staged = runner.staged
+  # share of the optimizer's units of work that rode in the backward's GEMM launches (the rest ran in the optimizer launch)
+  riders = None
+  if runner._rider_on:
+    riders = []
+    for o in runner.opt_flats:
+      n_units, taken, nsteps = o.queue_stats()
+      riders.append(dict(units=n_units, ridden_per_step=taken / max(nsteps, 1), ridden_fraction=taken / max(nsteps, 1) / n_units))
   del runner, model, main_run
 
   # the fill-independent figure in the same invocation: the same step WITHOUT token packing (every padded token computed)
@@ -638,6 +649,8 @@ def main():
                    'text_tower': args.text_tower, 'grad_sync': 'staged' if staged else 'single',
                    'grad_wire_dtype': args.grad_dtype, 'grad_algo': args.grad_algo,
                    'optimizer_sharded': bool(args.shard_optimizer and world > 1), 'fill_arg': args.fill,
+                   # one rank: per flat buffer, how much of the Adam step ran as riders of the backward's GEMM launches
+                   'adam_riders': riders,
                    # mean ms per step between the end of the last backward stage and the last gradient reduction having
                    # landed (HIP events on the compute stream): what the staged overlap did not hide; null at N = 1
                    'exposed_collective_ms_rank0': exposed_ms,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 2  /* r04: MmtEpilogue.dot_*, MmtBertBatch / MmtTextHeadsOpts as of r03, mmt_attn_bwd*_ex, delta [rows, d/64] */
+#define MMT_ABI_VERSION 3  /* r06: MmtEpilogue.rider*, MmtBertBatch.rider* / live_rows_hint, MmtAdamQueue (r04: MmtEpilogue.dot_*, mmt_attn_bwd*_ex) */
 #define MMT_ROW_ALIGN 256
 
 #define MMT_ERR_ARG (-1)    /* unsupported shape / null pointer */
@@ -69,6 +69,14 @@ typedef struct MmtEpilogue {
   const void* dot_src;
   int64_t lddot;
   float* dot_out;
+  /* r06, nullable: an optimizer work queue (MmtAdamQueue in DEVICE memory, see "Adam riders" below).  Blocks of this
+   * launch that have no tile to compute -- tiles past the live row count, plus the extra blocks the launcher appends when
+   * a rider is attached -- take units [.., rider_limit) of the queue (parameters whose gradients are final before this
+   * launch) and run the Adam update on them for as long as the GEMM's own blocks are still running; rider_slot names the
+   * "finished blocks" counter of this launch inside the queue's state.  Tiles that do not host riders ignore the fields. */
+  const void* rider;
+  int32_t rider_limit;
+  int32_t rider_slot;
 } MmtEpilogue;
 
 /* C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous bf16, fp32 accumulate on MFMA).
@@ -362,6 +370,43 @@ int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float
                         const MmtAdamSeg* segs_host, const MmtAdamSeg* segs_dev, int n_segs, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int32_t* step_dev, const float* lr_dev,
                         int bump_step, void* stream);
+/* ---- Adam riders (r06): the optimizer step OFF the critical path of a single-rank step -------------------------------
+ * train.py:100 + trainer/trainer.py:203-204 run `optimizer.step()` after the whole backward; the fused kernel above is
+ * HBM-bound (0.8 GB per step at config B: 119 us of a 1.3 ms step) and strictly serial behind it.  Here the same update is
+ * cut into the fused kernel's units of work (one 64x64 tile of a shadowed matrix or 4096 elements of a plain span) and
+ * put in a QUEUE ordered by the stage of the backward at which a unit's gradients are final.  The GEMM launches of the
+ * backward carry the queue as a "rider" (MmtEpilogue.rider): blocks with no tile of their own take units off the queue
+ * while the launch's GEMM blocks are still running (idle CUs / the last partial round of tiles stream Adam's bytes under
+ * MFMA-bound work), and stop as soon as the first block of the launch's last round has finished.  mmt_adam_step_queue
+ * runs whatever is left (units nobody took, and units that are never ready early) and advances the step count: weights,
+ * moments and bf16 shadows after it are BIT-IDENTICAL to mmt_adam_step_fused (same per-element arithmetic, adam_unit.h).
+ * All fields of MmtAdamQueue are device pointers / values; the struct itself lives in device memory (kernels read it
+ * through MmtEpilogue.rider) with a host copy for the launcher. */
+#define MMT_RIDER_SLOTS 1024
+typedef struct MmtAdamQueue {
+  float *p, *m, *v;           /* flat master weights and Adam moments                                             */
+  const float* g;             /* flat gradients                                                                   */
+  const MmtAdamSeg* segs;     /* device segment table (as mmt_adam_step_fused)                                    */
+  const int32_t* unit_seg;    /* [n_units] queue entry k -> segment                                               */
+  const int32_t* unit_blk;    /* [n_units] queue entry k -> block inside the segment (tile / 4096-element chunk)  */
+  int32_t* state;             /* int32[4 + MMT_RIDER_SLOTS]: [0] entries taken this step, [1] ticket,
+                               * [2 .. 2 + MMT_RIDER_SLOTS) finished-block counters of the hosting launches -- all zero
+                               * between steps --, then two statistics words (entries riders took, steps; never reset) */
+  int32_t* step_dev;          /* int32[2] = {steps taken so far, unused}                                          */
+  const float* lr_dev;        /* nullable: device learning rate                                                   */
+  const struct MmtAdamQueue* chain;  /* nullable: a second queue (another flat buffer) whose entries [0, chain_limit)
+                               * a rider block drains FIRST (the text tower's leftovers under the video backward)  */
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t n_units;
+  int32_t chain_limit;
+  int32_t reserved;
+} MmtAdamQueue;
+/* The rest of the step's optimizer work + the step count: entries [state[0], n_units) of the queue, one block each
+ * (entries already taken exit at once); the last block to finish zeroes the queue state and stores steps + 1. */
+int mmt_adam_step_queue(const MmtAdamQueue* q_host, const MmtAdamQueue* q_dev, void* stream);
+/* Measurement / test hook: `blocks` rider blocks of 512 threads with nothing else to do drain entries [.., limit). */
+int mmt_adam_rider_probe(const MmtAdamQueue* q_dev, int limit, int blocks, void* stream);
+
 /* bump_step = 0: step_dev[0] is this launch's step number t (bias correction), as mmt_adam_step.
  * bump_step = 1: step_dev is int32[2] = {steps taken so far, 0}; the launch is step step_dev[0] + 1 and stores it.
  * bump_step = 2: the launch is step step_dev[0] + 1 as well but leaves the count alone: one optimizer step issued as
@@ -609,6 +654,16 @@ typedef struct MmtBertBatch {
    * captured into the SAME graph: the "weight gradients of layer l + 2 are done" events a range waits for must have been
    * recorded in the capture that waits (ranges captured as separate graphs pass MMT_FORK_JOIN on every call). */
   void* side_stream;
+  /* r06 (backward only, all nullable / 0): the optimizer queue the backward's GEMM launches carry (MmtAdamQueue in device
+   * memory), rider_limits[l] (HOST array [layers]) = queue entries whose gradients are final when layer l's backward
+   * starts, rider_slot0 = first finished-block counter this model's launches may use (layer l uses slots
+   * rider_slot0 + 8 l .. + 8 l + 7). */
+  const void* rider;
+  const int32_t* rider_limits;
+  int32_t rider_slot0;
+  /* r06: the live row count as the HOST knows it (the collator counts valid tokens before the upload), 0 = unknown.  Only
+   * the tile choice reads it (the kernels read n_rows_dev); without it a packed batch is priced at rows (every tile live). */
+  int32_t live_rows_hint;
 } MmtBertBatch;
 
 enum {

@@ -16,7 +16,8 @@ class MmtEpilogue(ctypes.Structure):
   _fields_ = [('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('out2', c_vp), ('ldout2', c_i64),
               ('aux', c_vp), ('ldaux', c_i64), ('colsum', c_vp), ('row_index', c_vp), ('seed_dev', c_vp),
               ('drop_key', c_u32), ('drop_thr16', c_u32), ('drop_scale', c_f32), ('reserved', ctypes.c_int32),
-              ('dot_src', c_vp), ('lddot', c_i64), ('dot_out', c_vp)]
+              ('dot_src', c_vp), ('lddot', c_i64), ('dot_out', c_vp),
+              ('rider', c_vp), ('rider_limit', ctypes.c_int32), ('rider_slot', ctypes.c_int32)]
 
 
 class MmtPackItem(ctypes.Structure):
@@ -28,6 +29,16 @@ class MmtPackItem(ctypes.Structure):
 class MmtAdamSeg(ctypes.Structure):
   _fields_ = [('offset', c_i64), ('count', c_i64), ('dst', c_vp), ('dst_t', c_vp), ('rows', ctypes.c_int32),
               ('cols', ctypes.c_int32), ('dst_ld', ctypes.c_int32), ('dst_t_ld', ctypes.c_int32)]
+
+
+RIDER_SLOTS = 1024
+
+
+class MmtAdamQueue(ctypes.Structure):
+  _fields_ = [('p', c_vp), ('m', c_vp), ('v', c_vp), ('g', c_vp), ('segs', c_vp), ('unit_seg', c_vp), ('unit_blk', c_vp),
+              ('state', c_vp), ('step_dev', c_vp), ('lr_dev', c_vp), ('chain', c_vp),
+              ('lr', c_f32), ('beta1', c_f32), ('beta2', c_f32), ('eps', c_f32), ('weight_decay', c_f32),
+              ('n_units', ctypes.c_int32), ('chain_limit', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class MmtGemmItem(ctypes.Structure):
@@ -86,7 +97,8 @@ class MmtBertBatch(ctypes.Structure):
                                    'n_rows_dev', 'seed_dev')] +
               [(n, ctypes.c_int32) for n in ('rows', 'rows_alloc', 'batch', 'seq')] +
               [('out_rows', c_vp), ('n_out_per_sample', ctypes.c_int32), ('fork', ctypes.c_int32),
-               ('side_stream', c_vp)])
+               ('side_stream', c_vp), ('rider', c_vp), ('rider_limits', c_vp), ('rider_slot0', ctypes.c_int32),
+               ('live_rows_hint', ctypes.c_int32)])
 
 
 FORK_WGRAD, FORK_EARLY, FORK_REDUCE, FORK_JOIN, RANGE_LAYERS_ONLY = 1, 2, 4, 8, 16
@@ -200,6 +212,8 @@ SIGNATURES = {
     'mmt_adam_fused_blocks': (c_int, [ctypes.POINTER(MmtAdamSeg)]),
     'mmt_adam_step_fused': (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtAdamSeg), c_vp, c_int, c_f32, c_f32, c_f32,
                                     c_f32, c_f32, c_vp, c_vp, c_int, c_vp]),
+    'mmt_adam_step_queue': (c_int, [ctypes.POINTER(MmtAdamQueue), c_vp, c_vp]),
+    'mmt_adam_rider_probe': (c_int, [c_vp, c_int, c_int, c_vp]),
     'mmt_video_plan': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(MmtVideoSrc), c_vp]),
     'mmt_video_cast': (c_int, [ctypes.POINTER(MmtExpertIO), c_int, c_int, c_int, ctypes.POINTER(MmtVideoSrc), c_vp]),
@@ -270,7 +284,7 @@ def lib():
       fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
       fn.restype = res
       fn.argtypes = args
-    if handle.mmt_abi_version() != 2:
+    if handle.mmt_abi_version() != 3:
       raise RuntimeError('libmmt_hip.so ABI mismatch')
     _lib = handle
   return _lib

@@ -300,7 +300,26 @@ class BertModel(nn.Module):
       b.out_rows, b.n_out_per_sample = batch.out_rows.data_ptr(), batch.n_out_per_sample
     if batch.side_stream is not None and batch.fork:
       b.side_stream, b.fork = batch.side_stream.cuda_stream, int(batch.fork)
+    r = self._rider
+    if r is not None:  # the optimizer queue this module's backward GEMMs carry (set_rider)
+      b.rider, b.rider_limits, b.rider_slot0 = r['ptr'], ctypes.addressof(r['limits']), r['slot0']
+    b.live_rows_hint = int(getattr(batch, 'live_rows_hint', 0) or 0)
     return b
+
+  _rider = None
+
+  def set_rider(self, queue_ptr=None, limits=None, slot0=0):
+    """Attach (queue_ptr = device address of an MmtAdamQueue) or detach (None) the optimizer queue the GEMM launches of
+    this module's BACKWARD carry; limits[l] = queue entries whose gradients are final when layer l's backward starts
+    (include/mmt_hip.h: MmtBertBatch.rider).  Only a caller that finishes the queue after every backward
+    (FlatAdam.step with an armed queue: train_step.GraphedTrainStep) may attach one -- riders UPDATE WEIGHTS."""
+    if queue_ptr is None:
+      self._rider = None
+      return
+    n = self.config.num_hidden_layers
+    if len(limits) != n:
+      raise ValueError('set_rider: one limit per layer')
+    self._rider = dict(ptr=int(queue_ptr), limits=(ctypes.c_int32 * n)(*[int(x) for x in limits]), slot0=int(slot0))
 
   def _workspace(self, rows_alloc, save, model_struct):
     key = (rows_alloc, bool(save))

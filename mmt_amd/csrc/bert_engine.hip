@@ -404,6 +404,18 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     return 0;
   };
   const int nc = tail_rows(b, w);
+  // r06: the backward's GEMM launches carry the caller's optimizer queue (MmtEpilogue.rider, include/mmt_hip.h "Adam
+  // riders"): their idle blocks run the Adam update of parameters whose gradients are final -- everything the layers above
+  // (and whatever ran before this call) have produced: rider_limits[l] entries while layer l's backward runs.  Launch j of
+  // layer l reports its finished blocks in counter rider_slot0 + 8 l + j.
+  int ride_j = 0;
+  auto ride = [&](MmtEpilogue& e, int l) {
+    if (!b->rider || !b->rider_limits || b->rider_limits[l] <= 0 || ride_j >= 8) return;
+    const int slot = b->rider_slot0 + 8 * l + ride_j;
+    if (slot < 0 || slot >= MMT_RIDER_SLOTS) return;
+    e.rider = b->rider; e.rider_limit = b->rider_limits[l]; e.rider_slot = slot;
+    ++ride_j;
+  };
   // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
   // (the buffer that holds the gradient wrt layer l's OUTPUT depends on l alone; "layer -1" = the embedding stage)
   float* dcur = ((m->layers - 1 - l_hi) & 1) ? w.dA : dlast;
@@ -412,6 +424,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     LayerWs& L = w.layer[l];
     const char* hin16 = l ? w.layer[l - 1].h16 : w.h16_in;
     const int par = fork_w ? (l & 1) : 0;  // one set unless weight gradients may still be running from two layers up
+    ride_j = 0;
     char *dy = w.dy_[par], *dy2 = w.dy2_[par], *dhpre = w.dhpre_[par], *dqkv = w.dqkv_[par];
     // the weight gradients of layer l + 2 read the buffers this layer is about to overwrite (only an issue when they
     // were forked and not joined since: with MMT_FORK_JOIN every range call ends with the side stream drained)
@@ -431,12 +444,15 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       add_job(w.ln_partials[2 * l + 2], cblocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
       MmtEpilogue e = {};
       e.aux = t.hpre; e.ldaux = I;
+      ride(e, l);
       TRY(mmt_gemm_nt_bf16(t.dy2, d, P.w2_t, d, t.dhpre, I, nc, I, d, MMT_EPI_DGELU, &e, nullptr, stream));
       {  // dA = dhpre . W1 + dz: the split-K slabs and the residual gradient are summed by the LayerNorm backward itself
         int sp = 0;
         int64_t sstride = 0;
         TRY(mmt_gemm_splitk_geometry(nc, d, I, 0, &sp, &sstride));
-        TRY(mmt_gemm_nt_splitk_ex(t.dhpre, I, P.w1_t, I, nullptr, d, nc, d, I, MMT_EPI_F32, nullptr, t.slabs, 0, 0, nullptr, 1,
+        MmtEpilogue er = {};
+        ride(er, l);
+        TRY(mmt_gemm_nt_splitk_ex(t.dhpre, I, P.w1_t, I, nullptr, d, nc, d, I, MMT_EPI_F32, &er, t.slabs, 0, 0, nullptr, 1,
                                   stream));
         // t.dz is read (residual gradient) and rewritten (LN1 input gradient) by the same lanes at the same elements
         TRY(mmt_ln_bwd_slabs(t.slabs, sp, sstride, t.dz, t.z1, t.mean1, t.rstd1, P.ln1_g, t.dz, t.dy, w.ln_partials[2 * l + 1],
@@ -448,6 +464,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       // slab-reducing epilogue launch goes away)
       // (the GEMM that forms dO also leaves rowsum(dO * O) per 64 columns = the attention backward's delta, in t.delta)
       e.dot_src = t.ctx; e.lddot = d; e.dot_out = t.delta;
+      ride(e, l);
       if (d <= 512) TRY(mmt_gemm_nt_bf16(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, nullptr, stream));
       else TRY(mmt_gemm_nt_splitk(t.dy, d, P.wo_t, d, t.dctx, d, nc, d, d, MMT_EPI_BF16, &e, t.slabs, stream));
       // dQ exists for the read-out rows only (the dq kernel zero-fills the rest of the Q section); the residual
@@ -473,6 +490,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         if (fork_w) { if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG; done_cap[par] = capture_id((hipStream_t)side); }
       }
       e = {};
+      ride(e, l);
       float* dnext = w.dA;
       TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
       TRY(mmt_rows_scatter(t.dz, b->out_rows, nc, d, dnext, 1, stream));
@@ -496,6 +514,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     add_job(w.ln_partials[2 * l + 2], ln_blocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
     MmtEpilogue e = {};
     e.aux = L.hpre; e.ldaux = I;
+    ride(e, l);
     TRY(mmt_gemm_nt_bf16(dy2, d, P.w2_t, d, dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
     if (fork_early) {  // dW1 / dW2 need nothing else: they start under the rest of this layer's input-gradient chain
       TRY(mmt_stream_fork(stream, side));
@@ -515,6 +534,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     } else {
     e = {};
     e.res = w.dz; e.ldres = d;
+    ride(e, l);
     TRY(gemm_hidden(w, rows, d, dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- BertSelfOutput: LN1 <- dropout <- dense(d->d) ---
     TRY(mmt_ln_bwd(w.dA, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1], rows, d, 1, nr, b->row_index,
@@ -523,6 +543,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
     e = {};
     e.dot_src = L.ctx; e.lddot = d; e.dot_out = w.delta;  // rowsum(dO * O) per 64 columns, while dO is in registers
+    ride(e, l);
     TRY(mmt_gemm_nt_bf16(dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
     // --- BertSelfAttention ---
     {
@@ -549,6 +570,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.
+    ride(e, l);
     TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- all four weight gradients + bias gradients of the layer: ONE grouped launch (256 tiles at d=512, I=3072) ---
     if (!fork_w) {

@@ -2,6 +2,7 @@
 // input-gradient GEMMs), bf16 column sums (bias gradients), padded slab reduction, fused Adam.
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
+#include "adam_unit.h"
 
 // ---- weight packing ----------------------------------------------------------------------------
 // One launch packs up to MMT_PACK_MAX matrices: dst[r][c] = bf16(src[r][c]) for c < cols, 0 for
@@ -98,23 +99,9 @@ extern "C" int mmt_reduce_slabs_2d(const float* ws, int splits, int rows, int co
 }
 
 // ---- fused Adam over a flat fp32 buffer (torch.optim.Adam semantics, train.py:100) --------------
-// The update of four elements, shared by the plain kernel (one span: a data-parallel rank's shard) and the fused one
-// (whole buffer + bf16 shadows): every multiply-add is an explicit fma and every product an explicit multiply, so that
-// both kernels round identically whatever the compiler would contract -- a sharded step must reproduce the full one bit
-// for bit (tests/test_dp_gpu.py).
-__device__ __forceinline__ void adam_update4(f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, float beta1, float beta2,
-                                             float eps, float weight_decay, float step_size, float inv_sqrt_bc2) {
-  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float gg = __builtin_fmaf(weight_decay, pv[k], gv[k]);
-    mv[k] = __builtin_fmaf(beta1, mv[k], __fmul_rn(omb1, gg));
-    vv[k] = __builtin_fmaf(beta2, vv[k], __fmul_rn(__fmul_rn(omb2, gg), gg));
-    const float denom = __builtin_fmaf(sqrtf(vv[k]), inv_sqrt_bc2, eps);
-    pv[k] = __builtin_fmaf(-step_size, __fdiv_rn(mv[k], denom), pv[k]);
-  }
-}
-
+// The update of four elements (adam_update4) and of one 4096-element unit live in adam_unit.h, shared by the plain kernel
+// (one span: a data-parallel rank's shard), the fused one (whole buffer + bf16 shadows), the queue kernel and the rider
+// blocks of the GEMM launches, so that all of them round identically.
 // p, m, v updated in place from g; `step_dev` holds the 1-based step count on the device (graph safe).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
@@ -166,7 +153,6 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
   // than a separate increment.
   // (a plain, cacheable load: a volatile one is 1.5 M uncached reads of one word -- measured 119 -> 560 us)
   const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)step_dev) + (bump_step ? 1 : 0);
-  const float t = (float)t_int;
   struct Bump {
     int32_t* s; int t, on;
     __device__ ~Bump() {
@@ -183,78 +169,72 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     }
   } bump{step_dev, t_int, bump_step == 1};  // bump_step == 2: this launch is step count + 1 too, but a later launch of
                                            // the same step stores the new count (per-region launches, FlatAdam.step_span)
-  const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay, t_int);
   int s = 0;
 #pragma unroll 1
   for (int q = 1; q < idx.n; ++q)
     if ((int)blockIdx.x >= idx.begin[q]) s = q;
   const MmtAdamSeg seg = segs[s];
   const int lb = (int)blockIdx.x - idx.begin[s];
-  const int tid = threadIdx.x;
-  if (!seg.dst) {  // plain span: 4096 elements per block, 16 B per lane, four sweeps
-    const int64_t base = seg.offset + (int64_t)lb * 4096;
-    const int64_t end = seg.offset + seg.count;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t e = base + (int64_t)(i * 256 + tid) * 4;
-      if (e < end) {
-        f32x4 pv = *(const f32x4*)(p + e), gv = __builtin_nontemporal_load((const f32x4*)(g + e));
-        f32x4 mv = __builtin_nontemporal_load((const f32x4*)(m + e)), vv = __builtin_nontemporal_load((const f32x4*)(v + e));
-        adam_update4(pv, gv, mv, vv, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2);
-        *(f32x4*)(p + e) = pv;
-        __builtin_nontemporal_store(mv, (f32x4*)(m + e));
-        __builtin_nontemporal_store(vv, (f32x4*)(v + e));
-      }
-    }
-    return;
-  }
-  // shadowed matrix: tile (tr, tc) of 64x64; thread (r = tid/16 + 16 i, c = 4 (tid%16))
-  const int tiles_c = (seg.cols + 63) >> 6;
-  const int r0 = (lb / tiles_c) * 64, c0 = (lb % tiles_c) * 64;
-  const int c = c0 + (tid & 15) * 4;
-  bf16_t* __restrict__ dst = (bf16_t*)seg.dst;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rl = (tid >> 4) + 16 * i, r = r0 + rl;
-    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
-    if (r < seg.rows && c < seg.cols) {  // cols % 4 == 0: a 4-group is inside or outside as a whole
-      const int64_t e = seg.offset + (int64_t)r * seg.cols + c;
-      pv = *(const f32x4*)(p + e);
-      const f32x4 gv = __builtin_nontemporal_load((const f32x4*)(g + e));
-      f32x4 mv = __builtin_nontemporal_load((const f32x4*)(m + e)), vv = __builtin_nontemporal_load((const f32x4*)(v + e));
-      adam_update4(pv, gv, mv, vv, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2);
-      *(f32x4*)(p + e) = pv;
-      __builtin_nontemporal_store(mv, (f32x4*)(m + e));
-      __builtin_nontemporal_store(vv, (f32x4*)(v + e));
-      u32x2 o = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
-      *(u32x2*)(dst + (int64_t)r * seg.dst_ld + c) = o;
-    }
-    if (seg.dst_t) {
-      const int cl = (tid & 15) * 4;
-      tile[rl][cl] = pv[0]; tile[rl][cl + 1] = pv[1]; tile[rl][cl + 2] = pv[2]; tile[rl][cl + 3] = pv[3];
-    }
-  }
-  if (!seg.dst_t) return;
+  if (!adam_unit_update(p, g, m, v, seg, lb, (int)threadIdx.x, tile, h)) return;
   __syncthreads();
-  // transposed copy: row = source column, 16 consecutive source rows (32 B) per thread
-  bf16_t* __restrict__ dst_t = (bf16_t*)seg.dst_t;
-  const int tcl = tid >> 2, rq = (tid & 3) * 16;
-  const int tcol = c0 + tcl;  // row of dst_t
-  if (tcol < seg.cols) {
-    unsigned w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = pack_bf2(tile[rq + 2 * k][tcl], tile[rq + 2 * k + 1][tcl]);
-    bf16_t* out = dst_t + (int64_t)tcol * seg.dst_t_ld + r0 + rq;
-    if (r0 + rq + 15 < seg.rows) {
-      *(u32x4*)out = (u32x4){w[0], w[1], w[2], w[3]};
-      *(u32x4*)(out + 8) = (u32x4){w[4], w[5], w[6], w[7]};
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (r0 + rq + k < seg.rows) out[k] = (bf16_t)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+  adam_unit_store_t(seg, lb, (int)threadIdx.x, tile);
+}
+
+// ---- the optimizer queue (include/mmt_hip.h, "Adam riders") ---------------------------------------------------------
+// What the riders of the backward's GEMM launches left of the step: entry k of the queue is block k's, entries below
+// state[0] were taken by a rider.  The LAST block to finish (ticket in state[1]) zeroes the queue state for the next step
+// and stores the new step count -- every block has read both by then.
+__global__ __launch_bounds__(256) void adam_queue_kernel(const MmtAdamQueue* __restrict__ qd) {
+  __shared__ float tile[64][65];
+  const MmtAdamQueue q = *qd;
+  const int taken = __builtin_amdgcn_readfirstlane(*(const int32_t*)q.state);
+  const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)q.step_dev) + 1;
+  struct Fin {
+    int32_t *st, *step; int t;
+    __device__ ~Fin() {
+      __syncthreads();
+      __shared__ int last;
+      if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(st + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+      __syncthreads();
+      if (!last) return;
+      // (statistics, never reset: entries the riders took over all steps, steps finished -- FlatAdam.queue_stats)
+      if (threadIdx.x == 0) { st[2 + MMT_RIDER_SLOTS] += st[0]; st[3 + MMT_RIDER_SLOTS] += 1; }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 2 + MMT_RIDER_SLOTS; i += blockDim.x) st[i] = 0;
+      if (threadIdx.x == 0) step[0] = t;
     }
-  }
+  } fin{q.state, q.step_dev, t_int};
+  const int k = (int)blockIdx.x;
+  if (k < taken) return;
+  const int si = __builtin_amdgcn_readfirstlane(q.unit_seg[k]), lb = __builtin_amdgcn_readfirstlane(q.unit_blk[k]);
+  const MmtAdamSeg seg = q.segs[si];
+  const AdamHyper h = adam_hyper(q.lr_dev ? *q.lr_dev : q.lr, q.beta1, q.beta2, q.eps, q.weight_decay, t_int);
+  if (!adam_unit_update(q.p, q.g, q.m, q.v, seg, lb, (int)threadIdx.x, tile, h)) return;
+  __syncthreads();
+  adam_unit_store_t(seg, lb, (int)threadIdx.x, tile);
+}
+
+extern "C" int mmt_adam_step_queue(const MmtAdamQueue* q_host, const MmtAdamQueue* q_dev, void* stream) {
+  if (!q_host || !q_dev || q_host->n_units <= 0 || !q_host->p || !q_host->g || !q_host->m || !q_host->v || !q_host->segs ||
+      !q_host->unit_seg || !q_host->unit_blk || !q_host->state || !q_host->step_dev)
+    return MMT_ERR_ARG;
+  hipLaunchKernelGGL(adam_queue_kernel, dim3(q_host->n_units), dim3(256), 0, (hipStream_t)stream, q_dev);
+  return (int)hipGetLastError();
+}
+
+// rider blocks with no hosting GEMM (tests, tools/adam_lab.py): drain entries [.., limit)
+__global__ __launch_bounds__(512) void adam_rider_probe_kernel(const MmtAdamQueue* __restrict__ qd, int limit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rider_smem[];
+  adam_rider_run<512>(qd, limit, 0, 0, rider_smem);
+}
+
+extern "C" int mmt_adam_rider_probe(const MmtAdamQueue* q_dev, int limit, int blocks, void* stream) {
+  if (!q_dev || limit < 0 || blocks <= 0) return MMT_ERR_ARG;
+  hipLaunchKernelGGL(adam_rider_probe_kernel, dim3(blocks), dim3(512), adam_rider_lds_bytes<512>(), (hipStream_t)stream, q_dev,
+                     limit);
+  return (int)hipGetLastError();
 }
 
 extern "C" int mmt_adam_fused_blocks(const MmtAdamSeg* seg) {

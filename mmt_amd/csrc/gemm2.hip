@@ -15,6 +15,7 @@
 #include "mmt_common.h"
 #include "../../include/mmt_hip.h"
 #include "gemm_epi.h"
+#include "adam_unit.h"
 
 #define BK 64
 template <int ROWS, int NW>
@@ -111,6 +112,11 @@ __device__ __forceinline__ void gemm2_body(
         for (int h = 0; h < BM / 128; ++h)
           if (dm0 + h * 128 < M && tid < BN) epi.colsum[(int64_t)(dm0 / 128 + h) * N + dn0 + tid] = 0.f;
       }
+    }
+    // r06: a block without a tile works on the optimizer queue the launch carries (adam_unit.h) until the launch's own
+    // blocks are in their last round -- Adam's HBM streaming under the MFMA-bound tiles, on CUs that would sit idle
+    if constexpr (NT % 256 == 0) {
+      if (epi.rider) adam_rider_run<NT>(epi.rider, epi.rider_limit, epi.rider_slot, live_tiles * (int)gridDim.y, smem_raw);
     }
     return;
   }
@@ -330,6 +336,7 @@ __device__ __forceinline__ void gemm2_body(
 #else
   gemm_tile_epilogue<BM, BN, WGM, WGN, NT, EPI, PH>(acc, smem_raw, m0, n0, M, N, nrows, Cout, ldc, epi, wm, wn, kg, tid, nullptr);
 #endif
+  if (epi.rider && tid == 0) adam_rider_host_done(epi.rider, epi.rider_slot);  // (riders stop when the last round finishes)
 #ifdef MMT_GEMM2_INSTR
   if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
     long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 16;
@@ -361,11 +368,13 @@ __global__ __launch_bounds__((PH ? 2 : 1) * WGM * WGN * 64) void gemm2_kernel(
 template <int BM, int BN, int WGM, int WGN, int NS, bool BKN = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ ws,
-    int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk, const int32_t* __restrict__ n_rows_dev) {
+    int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk, const int32_t* __restrict__ n_rows_dev,
+    const void* rider, int rider_limit, int rider_slot) {
   const int z = blockIdx.y;
   const int kb = z * kchunk;
   const int kl = min(kchunk, K - kb);
   MmtEpilogue e = {};
+  e.rider = rider; e.rider_limit = rider_limit; e.rider_slot = rider_slot;  // (blocks without a tile: adam_unit.h)
   gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32, BKN>(A + kb, lda, BKN ? B + (int64_t)kb * ldb : B + kb, ldb,
                                                       ws + (int64_t)z * slab_stride, ldws, M, N, kl, e, n_rows_dev,
                                                       (int)blockIdx.x, (int)gridDim.x);
@@ -440,8 +449,9 @@ extern "C" int64_t mmt_gemm_nt_splitk_workspace_floats(int M, int N, int K) {
 
 template <int BM, int BN, int WGM, int WGN, int NS, bool BKN = false>
 static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* ws, int64_t slab, int M, int Mpad,
-                         int N, int K, int splits, int per, const int32_t* nr, hipStream_t s) {
+                         int N, int K, int splits, int per, const int32_t* nr, const MmtEpilogue& e, hipStream_t s) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  constexpr int NT = WGM * WGN * 64;
   static bool configured = false;
   if (!configured) {
     hipError_t rc = hipFuncSetAttribute((const void*)gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>,
@@ -449,8 +459,20 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
     if (rc != hipSuccess) return (int)rc;
     configured = true;
   }
-  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3(((Mpad + BM - 1) / BM) * (N / BN), splits), dim3(WGM * WGN * 64),
-                     lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr);
+  int gx = ((Mpad + BM - 1) / BM) * (N / BN), slot = 0;
+  const void* rider = e.rider;
+  if (rider) {  // (as launch2: extra blocks -- per K-slice row of the grid -- that run optimizer queue entries)
+    if (NT % 256 || lds < (size_t)adam_rider_lds_bytes<(NT % 256 ? 256 : NT)>()) {
+      rider = nullptr;
+    } else {
+      const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
+      const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
+      slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
+      gx += (256 * per_cu + splits - 1) / splits;
+    }
+  }
+  hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3(gx, splits), dim3(NT),
+                     lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr, rider, e.rider_limit, slot);
   return 0;
 }
 
@@ -482,14 +504,14 @@ static int splitk_impl(const void* A, int64_t lda, const void* B, int64_t ldb, v
   const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)B;
   int rc;
   if (b_kn)
-    rc = wide ? launch_splitk<128, 128, 2, 4, 2, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
-              : launch_splitk<128, 64, 4, 2, 3, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
+    rc = wide ? launch_splitk<128, 128, 2, 4, 2, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s)
+              : launch_splitk<128, 64, 4, 2, 3, true>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
   else if (wide == 2)  // 256x128 tiles: half the L2 -> LDS bytes per MAC of the 128x128 tile (the N = 512 GEMMs re-read
                        // their operands from L2 ~10x; at ~15 TB/s aggregate that traffic is what bounds them)
-    rc = launch_splitk<256, 128, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
+    rc = launch_splitk<256, 128, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
   else
-    rc = wide ? launch_splitk<128, 128, 2, 4, 2>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s)
-              : launch_splitk<128, 64, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, s);
+    rc = wide ? launch_splitk<128, 128, 2, 4, 2>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s)
+              : launch_splitk<128, 64, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
   if (rc) return rc;
   if (no_epilogue) return (int)hipGetLastError();
   const int64_t items = (int64_t)M * (N / 4);
@@ -600,9 +622,23 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   }
   // (N <= 1024 with K >= 2048: eight blocks past the last tile, which exit at once -- the FFN down-projection / its input
   // gradient then differ from the K = hidden GEMMs of the same template in their GRID, so that a profile can tell them apart)
-  const int grid = ((M + BM - 1) / BM) * (N / BN) + (N <= 1024 && K >= 2048 ? 8 : 0);
+  int grid = ((M + BM - 1) / BM) * (N / BN) + (N <= 1024 && K >= 2048 ? 8 : 0);
+  // r06: with an optimizer queue attached (MmtEpilogue.rider) the launch gets one residency round of extra blocks: they (and
+  // the tiles past the live row count) run queue entries while the tiles compute; the slot word tells them how many blocks of
+  // this launch are resident at once, i.e. where its last round begins (adam_unit.h: adam_rider_run)
+  MmtEpilogue e2 = e;
+  if (e.rider) {
+    if (NT % 256 || lds < (size_t)adam_rider_lds_bytes<(NT % 256 ? 256 : NT)>()) {
+      e2.rider = nullptr;
+    } else {
+      const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
+      const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
+      e2.rider_slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
+      grid += 256 * per_cu;
+    }
+  }
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN, PH>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, M, N, K, e, nr);
+                     (const bf16_t*)B, ldb, C, ldc, M, N, K, e2, nr);
   return (int)hipGetLastError();
 }
 

@@ -156,6 +156,15 @@ class FlatAdam:
     self.sync_lr()
     g = self._grad()
     table = self._segment_table() if self.fuse_shadows else None
+    if self._queue is not None and self._queue['armed']:
+      # the backward's GEMM launches have been draining the queue (riders); whatever is left + the step count
+      if table is None or not self._queue_valid():
+        raise RuntimeError('FlatAdam: the armed optimizer queue no longer matches the flat buffers (rebuild it)')
+      q = self._queue
+      import ctypes
+      check(_lib.lib().mmt_adam_step_queue(ctypes.byref(q['host']), ops._p(q['dev']), ops._stream()), 'mmt_adam_step_queue')
+      f.shadows_fresh()
+      return
     if table is not None:
       # ONE launch: Adam over every segment of the flat buffer + the bf16 W / W^T shadows of the GEMM weights + the step
       # counter (the last block to finish stores steps + 1)
@@ -221,6 +230,122 @@ class FlatAdam:
           'mmt_adam_step_fused')
     if bump:
       f.shadows_fresh()
+
+  # ---- the optimizer as a work queue the backward's GEMM launches drain (include/mmt_hip.h, "Adam riders") -----------
+  _queue = None
+
+  def build_queue(self, stage_of, chain=None):
+    """The fused step cut into its units of work (one 64x64 tile of a shadowed matrix / 4096 elements of a plain span),
+    ordered by the stage of the backward after which a unit's gradients are final.
+
+    stage_of(param) -> int >= 0 (final once stage s of the caller's backward has run) or None (only final when the whole
+    backward has run: the unit stays for `step()`).  A unit that overlaps several parameters takes the latest of their
+    stages.  chain: another FlatAdam whose queue the rider blocks of THIS queue's launches drain first (all of it must be
+    final by then: the native text tower's leftovers under the video side's backward).
+    Returns the number of stages n; `queue_limit(s)` = entries final after stage s.  While a queue is armed, `step()`
+    runs mmt_adam_step_queue (the entries no rider took + the step count) instead of the single fused launch: weights,
+    moments and bf16 shadows come out bit-identical (tests/test_optim_gpu.py).  Reference: train.py:100,
+    trainer/trainer.py:203-204 (`optimizer.step()` after the whole backward)."""
+    import ctypes
+
+    import numpy as np
+
+    from ._lib import MmtAdamQueue, RIDER_SLOTS
+    f = self.flat
+    self._ensure_state()
+    if self._frozen_spans():
+      raise NotImplementedError('optimizer queue with frozen parameters in the flat buffer')
+    table = self._segment_table()
+    if table is None:
+      raise RuntimeError('FlatAdam.build_queue needs the fused kernel (bf16 shadows allocated: run a forward first)')
+    host, dev, n = table
+    L = _lib.lib()
+    # stage of every element range that belongs to a parameter
+    starts = np.array([f.offset(p) for p in f.params], dtype=np.int64)
+    ends = starts + np.array([p.numel() for p in f.params], dtype=np.int64)
+    NEVER = 1 << 30
+    pstage = np.array([NEVER if stage_of(p) is None else int(stage_of(p)) for p in f.params], dtype=np.int64)
+    order = np.argsort(starts)
+    starts, ends, pstage = starts[order], ends[order], pstage[order]
+
+    def stage_of_range(lo, hi):
+      i0 = int(np.searchsorted(ends, lo, side='right'))
+      i1 = int(np.searchsorted(starts, hi, side='left'))
+      return int(pstage[i0:i1].max()) if i1 > i0 else -1  # padding only: final from the start
+
+    seg_ids, blks, stages = [], [], []
+    for i in range(n):
+      sg = host[i]
+      nb = L.mmt_adam_fused_blocks(ctypes.byref(sg))
+      if sg.dst:  # a matrix: every tile belongs to the parameters of one shadow (same stage)
+        st = stage_of_range(sg.offset, sg.offset + sg.count)
+        seg_ids += [i] * nb
+        blks += list(range(nb))
+        stages += [st] * nb
+      else:
+        for b in range(nb):
+          lo = sg.offset + 4096 * b
+          seg_ids.append(i)
+          blks.append(b)
+          stages.append(stage_of_range(lo, min(lo + 4096, sg.offset + sg.count)))
+    stages = np.maximum(np.array(stages, dtype=np.int64), 0)
+    perm = np.argsort(stages, kind='stable')
+    stages = stages[perm]
+    devc = f.master.device
+    unit_seg = torch.from_numpy(np.array(seg_ids, dtype=np.int32)[perm].copy()).to(devc)
+    unit_blk = torch.from_numpy(np.array(blks, dtype=np.int32)[perm].copy()).to(devc)
+    state = torch.zeros(4 + RIDER_SLOTS, dtype=torch.int32, device=devc)
+    q = MmtAdamQueue()
+    q.p, q.m, q.v, q.g = f.master.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.current_grad().data_ptr()
+    q.segs, q.unit_seg, q.unit_blk = dev.data_ptr(), unit_seg.data_ptr(), unit_blk.data_ptr()
+    q.state, q.step_dev, q.lr_dev = state.data_ptr(), self._step_store.data_ptr(), self.lr_dev.data_ptr()
+    q.lr, q.beta1, q.beta2, q.eps, q.weight_decay = float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay
+    q.n_units = len(seg_ids)
+    if chain is not None:
+      if chain._queue is None:
+        raise ValueError('chain: build the other optimizer\'s queue first')
+      q.chain, q.chain_limit = chain._queue['dev'].data_ptr(), chain._queue['host'].n_units
+    qdev = torch.frombuffer(bytearray(bytes(q)), dtype=torch.uint8).clone().to(devc)
+    n_stages = int(stages[stages < NEVER].max()) + 1 if (stages < NEVER).any() else 0
+    limits = [int(np.searchsorted(stages, s, side='right')) for s in range(n_stages)]
+    self._queue = dict(host=q, dev=qdev, keep=(unit_seg, unit_blk, state, dev), limits=limits, state=state,
+                       key=(self._seg_key, f.current_grad().data_ptr()), armed=False)
+    return n_stages
+
+  def queue_limit(self, stage):
+    """Queue entries whose gradients are final once stage `stage` of the backward has run (-1: before any stage)."""
+    lim = self._queue['limits']
+    if stage < 0 or not lim:
+      return 0
+    return lim[min(stage, len(lim) - 1)]
+
+  def queue_stats(self):
+    """(queue entries, entries taken by riders over all finished steps, finished steps) -- synchronises."""
+    from ._lib import RIDER_SLOTS
+    st = self._queue['state'][2 + RIDER_SLOTS:].tolist()
+    return self._queue['host'].n_units, st[0], st[1]
+
+  def queue_ptr(self):
+    return self._queue['dev'].data_ptr()
+
+  def arm_queue(self, on=True):
+    """From now on `step()` finishes the queue (mmt_adam_step_queue) instead of launching the fused kernel.  The caller
+    guarantees that every backward between two steps carries the queue consistently (train_step.GraphedTrainStep)."""
+    if self._queue is None:
+      raise RuntimeError('arm_queue() without build_queue()')
+    self._queue['armed'] = bool(on)
+
+  def _queue_ok(self):
+    """A queue exists and still describes the flat buffers (master, shadows and the gradient buffer in use)."""
+    q = self._queue
+    if q is None:
+      return False
+    self._segment_table()
+    return q['key'] == (self._seg_key, self.flat.current_grad().data_ptr())
+
+  def _queue_valid(self):
+    q = self._queue
+    return q is not None and q['armed'] and q['key'] == (self._seg_key, self.flat.current_grad().data_ptr())
 
   fuse_shadows = True
   _seg_key = _seg_table = None

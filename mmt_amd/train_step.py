@@ -53,6 +53,17 @@ from .model import cross_view_similarity
 from .optim import FlatAdam
 
 
+def _layer_stage(name, n_layers, first):
+  """Optimizer-queue stage of an encoder parameter: `first` + k for the matrices and biases of layer n_layers-1-k (final
+  after that layer's weight-gradient launch); None (final only when the backward ends) for LayerNorm parameters --
+  their gradients come out of the batched reduction at the end of the backward --, embeddings and everything else."""
+  import re
+  z = re.search(r'encoder\.layer\.(\d+)\.', name)
+  if z is None or '.layer_norm.' in name or '.LayerNorm.' in name:
+    return None
+  return first + (n_layers - 1 - int(z.group(1)))
+
+
 class FlatMinibatch(dict):
   """A minibatch (dict of tensors / dicts of tensors) laid out in ONE device buffer, so that loading it into the
   static input buffers of the captured graphs is a single device-to-device (or host-to-device) copy instead of
@@ -139,7 +150,7 @@ class GraphedTrainStep:
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
                overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
                grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None, shard_optimizer=False,
-               host_feed=None):
+               host_feed=None, adam_riders=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -166,6 +177,12 @@ class GraphedTrainStep:
     r03 upload path ran 0.16 ms per step behind the resident one whatever the bytes); `prime()` uploads slot 0 once.
     Contract for the loader: pinned buffer (s + 1) % K holds minibatch i + 1 when step(s) is launched for minibatch i and is
     not rewritten before that step has finished (`step_done(slot)`).
+    adam_riders (one rank only; None = on unless MMT_ADAM_RIDERS=0): the optimizer leaves the critical path -- the step's
+    Adam update is a queue of 4096-element units ordered by when their gradients are final, the GEMM launches of the
+    backward carry it (blocks without a tile of their own -- idle CUs, the last partial round -- stream Adam's bytes under
+    the MFMA-bound tiles) and the optimizer launch at the end only runs what is left.  Bit-identical to the serial
+    fused step (tests/test_optim_gpu.py); needs the stage-by-stage backward (native text heads and losses).
+    Reference: train.py:100, trainer/trainer.py:203-204.
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
     self.model, self.loss_fn, self.group = model, loss_fn, group
@@ -174,6 +191,10 @@ class GraphedTrainStep:
     self.fork = int(fork)
     self._side = None
     self._fork_on = False  # decided after the first warm-up step (needs the model's stage handles)
+    if adam_riders is None:
+      adam_riders = os.environ.get('MMT_ADAM_RIDERS', '1') != '0'
+    self._want_riders = bool(adam_riders)
+    self._rider_on = False  # decided after the first warm-up step as well
     self._keep = []
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -245,6 +266,9 @@ class GraphedTrainStep:
       snap = self._snapshot() if warmup_steps > 0 else None
       for i in range(warmup_steps):  # allocates every lazily created buffer / optimizer state
         self._eager_step()
+        if i == 0 and self._want_riders and not self._multi and not self.fork and not self._want_stages:
+          self._rider_on = self._stageable([p for p in rest if p.grad is not None]) and \
+              all(not o._frozen_spans() for o in self.opt_flats)
         if i == 0 and (self._want_stages or self.fork):
           ok = self._stageable([p for p in rest if p.grad is not None])  # e.g. the unused pooler: no grad
           self.staged = ok and self._want_stages
@@ -256,6 +280,9 @@ class GraphedTrainStep:
               model.overlap_text_heads = True
               model._side_streams[next(model.parameters()).device] = self._side
             self._fork_on = True
+      if self._rider_on:  # the queues exist before anything is captured (building them copies tables to the device)
+        self._arm_riders()
+        self._disarm_riders()
       if snap is not None:
         self._restore(snap)
     torch.cuda.current_stream().wait_stream(self._stream)
@@ -320,6 +347,8 @@ class GraphedTrainStep:
         o.exp_avg.zero_()
         o.exp_avg_sq.zero_()
         o.step_dev.zero_()
+      if o._queue is not None:
+        o._queue['state'].zero_()
     if self.opt_rest is not None:
       for st in self.opt_rest.state.values():
         for v in st.values():
@@ -759,7 +788,67 @@ class GraphedTrainStep:
     if not self.fork & FORK_ADAM:
       self._opt()
 
+  # ---- the optimizer riding in the backward's GEMM launches (one rank) ------------------------------------------------
+  def _arm_riders(self):
+    """Build (once) the optimizer queues of the flat buffers and attach them to the encoders whose backward launches
+    carry them.  Stages of the video side's queue: 0 = text heads (their backward runs first), 1 + k = the matrices and
+    biases of encoder layer L-1-k (final after that layer's weight-gradient launch); LayerNorm parameters, embedding tables
+    and the expert projections are only final when the backward ends and stay for the optimizer launch.  The native text
+    tower's queue: stage k = its layer Lt-1-k; what its own backward leaves (embeddings, its bottom layer) rides in the
+    video side's launches (chain)."""
+    m = self.model
+    opt_v = self.opt_flats[0]
+    opt_t = self.opt_flats[1] if len(self.opt_flats) > 1 else None
+    vb = m.vid_bert
+    Lv = vb.config.num_hidden_layers
+    built = False
+    if opt_t is not None and not opt_t._queue_ok():
+      tb = m.txt_bert
+      Lt = tb.config.num_hidden_layers
+      names = dict((id(p), n) for n, p in zip(opt_t.flat.names, opt_t.flat.params))
+      opt_t.build_queue(lambda p: _layer_stage(names[id(p)], Lt, 0))
+      built = True
+    if built or not opt_v._queue_ok():
+      names = dict((id(p), n) for n, p in zip(opt_v.flat.names, opt_v.flat.params))
+
+      def stage_v(p):
+        n = names[id(p)]
+        if n.startswith('text_GU.') or n.startswith('moe_fc_txt.'):
+          return 0
+        return _layer_stage(n, Lv, 1)
+      opt_v.build_queue(stage_v, chain=opt_t)
+    for o in self.opt_flats:
+      o.arm_queue(True)
+    vb.set_rider(opt_v.queue_ptr(), [opt_v.queue_limit(Lv - 1 - l) for l in range(Lv)], 0)
+    if opt_t is not None:
+      tb = m.txt_bert
+      Lt = tb.config.num_hidden_layers
+      tb.set_rider(opt_t.queue_ptr(), [opt_t.queue_limit(Lt - 2 - l) for l in range(Lt)], 0)
+
+  def _disarm_riders(self):
+    self.model.vid_bert.set_rider(None)
+    if len(self.opt_flats) > 1:
+      self.model.txt_bert.set_rider(None)
+
+  def _rider_step(self):
+    """One rank: forward, the backward stage by stage (text heads first, then the encoder from the top layer down) with
+    the optimizer queues riding in its GEMM launches, then the optimizer launches for what is left.  ONE serial chain of
+    kernels, captured as one graph."""
+    self._zero()
+    e = self._forward()
+    g = self._gather(e)
+    self._regions = self._region_table()
+    self._arm_riders()
+    try:
+      for fn, _ in self._stage_list(e, g):
+        fn()
+    finally:
+      self._disarm_riders()
+    self._opt()
+
   def _eager_step(self):
+    if self._rider_on and not self._multi:
+      return self._rider_step()
     if self._fork_on and not self._multi:
       return self._fork_step()
     self._zero()
@@ -791,10 +880,13 @@ class GraphedTrainStep:
   def _capture(self):
     torch.cuda.synchronize()
     self._zero()
-    if not self._multi and self._fork_on:
+    if not self._multi and (self._fork_on or self._rider_on):
       ga = torch.cuda.CUDAGraph()
       with torch.cuda.graph(ga, pool=self._pool, stream=self._stream, capture_error_mode=self._cap_mode):
-        self._fork_step()  # ONE graph whose branches are the main and the side stream
+        if self._rider_on:
+          self._rider_step()  # ONE serial chain; the optimizer rides in the backward's GEMM launches
+        else:
+          self._fork_step()  # ONE graph whose branches are the main and the side stream
         self._upload_branch_end()
       self._graphs, self._e = (ga, None, None), None
       torch.cuda.synchronize()

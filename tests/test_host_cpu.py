@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
     assert name in _lib.SIGNATURES, 'no ctypes signature for ' + name
     assert len(_lib.SIGNATURES[name][1]) == nargs, 'arity mismatch for ' + name
   assert set(_lib.SIGNATURES) == set(decl)
-  assert _lib.lib().mmt_abi_version() == 2
+  assert _lib.lib().mmt_abi_version() == 3
   # struct layouts agree with the C side (sizes are what the kernels are compiled against)
   assert ctypes.sizeof(_lib.MmtEpilogue) == 120  # + dot_src / lddot / dot_out (r04)
   assert ctypes.sizeof(_lib.MmtPackItem) == 48

@@ -249,3 +249,99 @@ def test_graphed_step_optimizer_checkpoint_on_a_real_cenet():
   assert l1 == l2
   for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
     assert torch.equal(p.detach(), q.detach()), n
+
+
+def _queue_setup(seed):
+  """Two identical flat buffers with shadows (ragged tile edges, a fused q|k|v block, plain spans in between)."""
+  from mmt_amd.flat import FlatParams
+  from mmt_amd.optim import FlatAdam
+  dev = torch.device('cuda', 0)
+  shapes = [('a', (100, 72)), ('bias_a', (100,)), ('q', (64, 128)), ('k', (64, 128)), ('v', (64, 128)), ('ln', (128,)),
+            ('big', (9000,)), ('r', (96, 300)), ('w', (320, 256)), ('tail', (7,))]
+  out = []
+  for _ in range(2):
+    torch.manual_seed(seed)
+    params = [torch.nn.Parameter(torch.randn(*s) * 0.3) for _, s in shapes]
+    flat = FlatParams([(n, p) for (n, _), p in zip(shapes, params)])
+    P = dict(zip([n for n, _ in shapes], params))
+    flat.add_shadow('a', [P['a']], 100, 72, transpose=False)
+    flat.add_shadow('qkv', [P['q'], P['k'], P['v']], 192, 128, transpose=True)
+    flat.add_shadow('r', [P['r']], 96, 300, k_pad=384)
+    flat.add_shadow('w', [P['w']], 320, 256, transpose=True)
+    flat.ensure(dev)
+    flat.pack()
+    out.append((flat, params, FlatAdam(flat, lr=1e-2, weight_decay=0.0)))
+  return out
+
+
+@pytest.mark.parametrize('ridden', ['none', 'some', 'all'])
+def test_adam_queue_with_riders_is_bit_identical_to_the_fused_step(ridden):
+  """mmt_adam_step_queue (+ rider blocks draining part of the queue first, adam_unit.h) against mmt_adam_step_fused:
+  master weights, both moments, every bf16 shadow and the step count BIT for bit over three steps; the queue state is
+  zero between steps.  Stages: 'w' and 'big' are final first, then q|k|v, the rest only at the end."""
+  import ctypes
+  from mmt_amd import _lib, ops
+  (fa, pa, oa), (fb, pb, ob) = _queue_setup(11)
+  stage = {id(p): s for p, s in zip(pb, [None, None, 1, 1, 1, None, 0, None, 0, None])}
+  for step in range(3):
+    gen = torch.Generator(device='cuda').manual_seed(500 + step)
+    g = torch.randn(fa.current_grad().shape, device='cuda', generator=gen) * 0.1
+    fa.current_grad().copy_(g)
+    fb.current_grad().copy_(g)
+    oa.step()  # reference: ONE fused launch
+    if step == 0:
+      ob._ensure_state()
+      n_stages = ob.build_queue(lambda p: stage[id(p)])
+      assert n_stages == 2 and 0 < ob.queue_limit(0) < ob.queue_limit(1) < ob._queue['host'].n_units
+      ob.arm_queue(True)
+    lim = dict(none=0, some=ob.queue_limit(0), all=ob.queue_limit(1))[ridden]
+    if lim:  # rider blocks with no host launch: 3 blocks of 2 x 256 threads take entries [0, lim) two at a time
+      _lib.check(_lib.lib().mmt_adam_rider_probe(ob.queue_ptr(), lim, 3, ops._stream()), 'mmt_adam_rider_probe')
+      assert int(ob._queue['state'][0]) == lim
+    ob.step()  # the rest of the queue + the step count
+    assert int(ob._queue['state'][:2 + _lib.RIDER_SLOTS].abs().sum()) == 0
+    assert torch.equal(fa.master, fb.master)
+    assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    assert int(oa.step_dev) == int(ob.step_dev) == step + 1
+    for k in ('a', 'qkv', 'r', 'w'):
+      for x, y in zip(fa.shadow(k), fb.shadow(k)):
+        assert (x is None and y is None) or torch.equal(x, y), k
+  n, taken, steps = ob.queue_stats()
+  assert steps == 3 and taken == 3 * dict(none=0, some=ob.queue_limit(0), all=ob.queue_limit(1))[ridden]
+
+
+def test_graphed_step_with_adam_riders_trains_bit_identically():
+  """GraphedTrainStep(adam_riders=True): the optimizer's units ride in the GEMM launches of the backward (blocks without a
+  tile run Adam on parameters whose gradients are final) -- same losses, weights, moments and bf16 shadows, bit for bit, as
+  the step whose optimizer is one launch after the backward (dropout on: same masks), and the riders really took work."""
+  from mmt_amd import synthetic
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
+  from tests.test_dp_gpu import BATCH, MODS, TOKENS, _build, _slice_batch
+  dev = torch.device('cuda', 0)
+
+  def make(riders):
+    torch.manual_seed(0)
+    model = _build(dev, txt_pro='gbn', dropout=0.1, layers=3)
+    mb, text = synthetic.make_batch(33, BATCH, MODS, TOKENS)
+    static = FlatMinibatch(_slice_batch(mb, text, slice(0, BATCH)), dev)
+    model.txt_bert.text = static['text']
+    return model, GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=1e-3, warmup_steps=2,
+                                   adam_riders=riders)
+
+  ma, ra = make(False)
+  mb_, rb = make(True)
+  assert rb._rider_on and not ra._rider_on
+  assert int(ma.vid_bert._seed_dev) == int(mb_.vid_bert._seed_dev)
+  for i in range(4):
+    la, lb = ra.step(), rb.step()
+    assert torch.equal(la, lb), (i, float(la), float(lb))
+  torch.cuda.synchronize()
+  assert torch.equal(ma._flat.master, mb_._flat.master)
+  assert torch.equal(ra.opt_flat.exp_avg, rb.opt_flat.exp_avg) and torch.equal(ra.opt_flat.exp_avg_sq, rb.opt_flat.exp_avg_sq)
+  assert int(ra.opt_flat.step_dev) == int(rb.opt_flat.step_dev) == 4
+  for sa, sb in zip(ma._flat.shadows, mb_._flat.shadows):
+    assert torch.equal(sa['dst'], sb['dst'])
+    assert sa['dst_t'] is None or torch.equal(sa['dst_t'], sb['dst_t'])
+  n, taken, steps = rb.opt_flat.queue_stats()
+  assert steps == 4 and 0 < taken <= 4 * rb.opt_flat.queue_limit(99), (n, taken, steps)
