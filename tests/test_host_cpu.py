@@ -22,6 +22,11 @@ def _header_functions():
   return out
 
 
+def _header_define(name):
+  src = open(os.path.join(ROOT, 'include', 'mmt_hip.h')).read()
+  return int(re.search(r'#define\s+%s\s+(\d+)' % name, src).group(1))
+
+
 def test_library_exports_every_declared_symbol_and_bindings_match():
   from mmt_amd import _lib
   decl = _header_functions()
@@ -34,11 +39,12 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
   assert set(_lib.SIGNATURES) == set(decl)
   assert _lib.lib().mmt_abi_version() == 3
   # struct layouts agree with the C side (sizes are what the kernels are compiled against)
-  assert ctypes.sizeof(_lib.MmtEpilogue) == 120  # + dot_src / lddot / dot_out (r04)
+  assert ctypes.sizeof(_lib.MmtEpilogue) == 136  # + dot_src / lddot / dot_out (r04), rider / rider_limit / rider_slot (r06)
   assert ctypes.sizeof(_lib.MmtPackItem) == 48
   assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
-  assert ctypes.sizeof(_lib.MmtBertBatch) == 104  # + side_stream (r03)
+  assert ctypes.sizeof(_lib.MmtBertBatch) == 128  # + side_stream (r03), rider / rider_limits / rider_slot0 / live_rows_hint (r06)
+  assert ctypes.sizeof(_lib.MmtAdamQueue) == 120 and _header_define('MMT_RIDER_SLOTS') == _lib.RIDER_SLOTS
   assert ctypes.sizeof(_lib.MmtVideoFront) == 8 + 6 * 4 + 11 * 8  # experts | M B T pack max_pos do_cast | 11 pointers
   assert ctypes.sizeof(_lib.MmtTextHeadsOpts) == 16 + 4 * 8          # + video_front (r03)
 
