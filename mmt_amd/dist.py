@@ -149,9 +149,11 @@ class WireBuffer:
     out.copy_(shard)
     return out
 
-  def all_gather_span(self, span, group, async_op=True):
+  def all_gather_span(self, span, group, async_op=True, scratch=False):
     """span (fp32 view of a flat buffer) holds valid values in this rank's shard [rank * per, ...) only: all-gather the
-    shards so that every rank holds the whole span.  -> (work, finish)."""
+    shards so that every rank holds the whole span.  -> (work, finish).  scratch=True: a one-off exchange (an optimizer
+    checkpoint's moment gather) -- the padded gather / send buffers are temporaries that die with `finish` instead of
+    being cached per span for the life of the run (they would add ~2x the Adam-moment footprint to device memory)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = span.numel()
     per = self._shard_geometry(n, world)
@@ -161,11 +163,15 @@ class WireBuffer:
         return dist.all_gather_into_tensor(span, mine, group=group, async_op=async_op), (lambda: None)
       mine = mine.clone()  # (gloo: no in-place form)
       return dist.all_gather_into_tensor(span, mine, group=group, async_op=async_op), (lambda: None)
-    buf = self._buf(span, per * world, torch.float32)
-    key = ('wshard', span.data_ptr(), per)
-    mine = self._bufs.get(key)
-    if mine is None:
-      mine = self._bufs[key] = torch.zeros(per, device=span.device, dtype=torch.float32)
+    if scratch:
+      buf = torch.empty(per * world, device=span.device, dtype=torch.float32)
+      mine = torch.zeros(per, device=span.device, dtype=torch.float32)
+    else:
+      buf = self._buf(span, per * world, torch.float32)
+      key = ('wshard', span.data_ptr(), per)
+      mine = self._bufs.get(key)
+      if mine is None:
+        mine = self._bufs[key] = torch.zeros(per, device=span.device, dtype=torch.float32)
     lo = rank * per
     cnt = max(0, min(per, n - lo))
     if cnt:

@@ -234,6 +234,10 @@ class FeatureStore:
   def __len__(self):
     return len(self.videos)
 
+  def has_caption_words(self):
+    """Does the store hold word-level captions (`FeatureStoreWriter.add(caption_words=...)`, r05) for any video?"""
+    return int(self._vid_wcap[-1]) > 0
+
   def caption_words(self, i):
     """-> (list of word lists, list of [n_words, 2] second arrays), one entry per stored caption of video i"""
     i = self.index[i] if isinstance(i, str) else i
@@ -417,9 +421,11 @@ class RaggedCollator:
 
   def collate_captions(self, indices, captions_per_video, max_text_words, tokenizer, query_shuffling='indiv',
                        caption_length=float('inf'), clip_duration=float('inf'), restrict_test_captions=None,
-                       py_random=None):
-    """The caption half of `BaseDataset.__getitem__` (base/base_dataset.py:569-757, n_pairs = 1) on the store's word-level
-    captions, for EVERY caption sampling mode of the reference:
+                       py_random=None, remove_stop_words=False, n_pairs=1):
+    """The caption half of `BaseDataset.__getitem__` (base/base_dataset.py:569-757) on the store's word-level captions, for
+    the caption sampling modes of the reference's published configurations (`remove_stop_words=False`, `n_pairs=1`:
+    utils/util.py:431, base/base_dataset.py:165,732-734 -- either option set raises NotImplementedError instead of silently
+    producing other tokens and feature windows than the reference would):
       query_shuffling  'indiv' (each caption on its own), 'cat' (all captions concatenated in order), 'shuf' (shuffled,
                        then concatenated), 'shufk<N>' (shuffled, the first N concatenated)               :594-625
       caption_length   inf, n or [min, max]: a window of that many consecutive "sentences" (= words: every word is its
@@ -435,6 +441,15 @@ class RaggedCollator:
     -> token_ids [B, C, W, 2] int32, query_masks [B, C] int32, windows [(feat_start, feat_end)] per sample."""
     import random as _random
     import re
+    if remove_stop_words:
+      raise NotImplementedError('collate_captions: remove_stop_words=True (base/base_dataset.py:118-147, 732-734) is not '
+                                'ported -- the published configurations leave it off (utils/util.py:431)')
+    if n_pairs != 1:
+      raise NotImplementedError('collate_captions: n_pairs = %r (base/base_dataset.py:569-757 with several clip / caption '
+                                'pairs per item); the published configurations use 1' % (n_pairs,))
+    if not self.store.has_caption_words():
+      raise ValueError('collate_captions: this feature store holds no word-level captions (written before r05, or without '
+                       'captions=): rebuild it with FeatureStoreWriter(..., captions=...)')
     pyr = py_random if py_random is not None else _random
     C, W = captions_per_video, max_text_words
     z = re.match(r'shufk(\d*)', query_shuffling)

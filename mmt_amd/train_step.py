@@ -64,6 +64,27 @@ def _layer_stage(name, n_layers, first):
   return first + (n_layers - 1 - int(z.group(1)))
 
 
+_QUIESCE_WARNED = False
+
+
+def _pending_nccl_works():
+  """Collectives the NCCL/RCCL process group's watchdog still holds (issued, not yet retired), from the flight recorder;
+  None when the recorder cannot tell (disabled, or this torch build has no such hook)."""
+  import pickle
+  try:
+    from torch._C._distributed_c10d import _dump_nccl_trace
+    if int(os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000')) <= 0:
+      return None
+    active = pickle.loads(_dump_nccl_trace(True, False, True)).get('entries', [])
+    if active:
+      return len(active)
+    # "nothing active" only means something if the recorder records at all: it must know the collectives issued so far
+    seen = pickle.loads(_dump_nccl_trace(True, False, False)).get('entries', [])
+    return 0 if seen else None
+  except Exception:  # noqa: BLE001 -- any failure of the introspection hook: the caller falls back to the time-based wait
+    return None
+
+
 class FlatMinibatch(dict):
   """A minibatch (dict of tensors / dicts of tensors) laid out in ONE device buffer, so that loading it into the
   static input buffers of the captured graphs is a single device-to-device (or host-to-device) copy instead of
@@ -670,6 +691,7 @@ class GraphedTrainStep:
       return
     seen = set()
     self._shard_spans = [(r['flat'], r['off'], r['cnt']) for _, r in handles]
+    self._moments_stale = True  # (until gather_optimizer_state())
     for _, r in handles:
       opt = self._opt_of[id(r['flat'])]
       grad = self._wire.shard_f32(r['span'], r['shard'])
@@ -713,18 +735,29 @@ class GraphedTrainStep:
 
   def optimizer_state_dict(self):
     """The optimizer state of the step as the REFERENCE would have checkpointed it: one torch.optim.Adam state dict over
-    filter(requires_grad, model.parameters()) (train.py:95-100, base/base_trainer.py:353-365)."""
+    filter(requires_grad, model.parameters()) (train.py:95-100, base/base_trainer.py:353-365).  LOCAL (no collective): any
+    one rank may call it, as the reference's rank-0-only `_save_checkpoint` does.  Under `shard_optimizer=True` a rank
+    holds current Adam moments for its own shards only, so every rank must have called `gather_optimizer_state()` since
+    the last step -- otherwise this raises instead of pairing a non-zero step count with stale moments (or hanging in a
+    collective the other ranks never enter)."""
     from .optim import merged_state_dict
-    self._gather_sharded_moments()
+    if self.shard_opt and self._multi and self._moments_stale:
+      raise RuntimeError('GraphedTrainStep.optimizer_state_dict(): the Adam moments are sharded over the ranks '
+                         '(shard_optimizer=True) and have not been gathered since the last step -- call '
+                         'gather_optimizer_state() on EVERY rank first (a collective), then optimizer_state_dict() on the '
+                         'rank that writes the checkpoint')
     return merged_state_dict(self.model, self.opt_flats + [self.opt_rest])
 
-  def _gather_sharded_moments(self):
-    """Sharded optimizer: a rank has updated exp_avg / exp_avg_sq only inside ITS shard of every span, so a checkpoint
-    written from one rank's buffers would pair a non-zero step count with stale moments for (N-1)/N of the parameters.
-    All-gather the moment shards along the geometry the last step cut them with (`WireBuffer.all_gather_span`: the same
-    rank * per offsets as the reduce-scatter).  COLLECTIVE: every rank of the group must call optimizer_state_dict()
-    (the one that writes the file is then free to be rank 0 alone, base/base_trainer.py:353-365)."""
+  _moments_stale = False
+
+  def gather_optimizer_state(self):
+    """COLLECTIVE (every rank of the group calls it; a no-op without the sharded optimizer): a rank has updated exp_avg /
+    exp_avg_sq only inside ITS shard of every span, so a checkpoint written from one rank's buffers would pair a non-zero
+    step count with stale moments for (N-1)/N of the parameters.  All-gather the moment shards along the geometry the last
+    step cut them with (`WireBuffer.all_gather_span`: the same rank * per offsets as the reduce-scatter), through
+    temporaries that are freed again.  Afterwards `optimizer_state_dict()` is local on every rank until the next step."""
     if not (self.shard_opt and self._multi) or not self._shard_spans:
+      self._moments_stale = False
       return
     with torch.no_grad():
       for flat, off, cnt in self._shard_spans:
@@ -732,10 +765,11 @@ class GraphedTrainStep:
         if opt.exp_avg is None:
           continue
         for buf in (opt.exp_avg, opt.exp_avg_sq):
-          work, fin = self._wire.all_gather_span(buf[off:off + cnt], self.group, async_op=False)
+          work, fin = self._wire.all_gather_span(buf[off:off + cnt], self.group, async_op=False, scratch=True)
           if work is not None:
             work.wait()
           fin()
+    self._moments_stale = False
 
   def load_optimizer_state_dict(self, sd):
     """Resume from a reference optimizer checkpoint (base/base_trainer.py:426-432); the captured graphs read the Adam
@@ -868,14 +902,32 @@ class GraphedTrainStep:
 
   # ---- capture -----------------------------------------------------------------------------------
   def _quiesce_watchdog(self):
-    """RCCL's process group keeps every eager collective on a list that its watchdog thread polls (an event query per entry,
-    every ~100 ms) until the collective has finished.  A poll that lands inside an open stream capture of THIS thread is legal
-    in thread-local capture mode, but has been seen to end the process on ROCm (one full-suite run in two: the watchdog
-    thread dies with a c10::Error while the step graph is being captured).  Before a capture: finish the device's work and
-    give the watchdog time for the poll that retires the finished entries -- nothing is left for it to query."""
-    if dist.is_initialized() and dist.get_backend() == 'nccl':
-      torch.cuda.synchronize()
-      time.sleep(0.35)
+    """RCCL's process group keeps every eager collective on a list that its watchdog thread polls (an event query per entry)
+    until the collective has finished, and only then RETIRES the entry.  A poll that lands inside an open stream capture of
+    THIS thread is legal in thread-local capture mode, but has been seen to end the process on ROCm (the watchdog thread
+    dies with a c10::Error while the step graph is being captured).  Before a capture, therefore: finish the device's work,
+    then WAIT until the watchdog has retired every entry -- observed through the process group's flight recorder
+    (`_dump_nccl_trace(onlyActive=True)` lists exactly the collectives the watchdog still holds) -- so that it has nothing
+    left to query while the capture is open.  Deterministic as long as the recorder is on (TORCH_NCCL_TRACE_BUFFER_SIZE > 0,
+    the default); with the recorder off it falls back to waiting out a few of the watchdog's 100 ms poll periods, and says
+    so once."""
+    if not (dist.is_initialized() and dist.get_backend() == 'nccl'):
+      return
+    torch.cuda.synchronize()
+    state = _pending_nccl_works()
+    deadline = time.monotonic() + 10.0
+    while state is not None and state > 0 and time.monotonic() < deadline:
+      time.sleep(0.005)
+      state = _pending_nccl_works()
+    if state == 0:
+      return  # every finished collective has left the watchdog's list
+    global _QUIESCE_WARNED
+    if not _QUIESCE_WARNED:
+      _QUIESCE_WARNED = True
+      import warnings
+      warnings.warn('GraphedTrainStep: cannot observe the process group\'s pending collectives (%s); sleeping 0.35 s before '
+                    'each capture instead' % ('flight recorder off' if state is None else 'entries still active after 10 s'))
+    time.sleep(0.35)
 
   def _capture(self):
     torch.cuda.synchronize()

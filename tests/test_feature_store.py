@@ -227,3 +227,17 @@ def test_caption_words_round_trip_and_edge_cases(tmp_path):
     coll.collate_captions([0], 1, DF.MAX_WORDS, tok, query_shuffling='zigzag')
   old = FS.FeatureStore(str(tmp_path / 'c'))
   assert len(old.captions(0)) == 0  # (this store holds word-level captions only)
+
+
+def test_collate_captions_rejects_what_it_does_not_port(tmp_path):
+  """`remove_stop_words=True` / `n_pairs > 1` (base/base_dataset.py:118-147, 732-734) are not ported -- they
+  must raise, not silently yield other tokens than the reference; a store without word-level captions says so up front."""
+  with FS.FeatureStoreWriter(str(tmp_path / 's'), {'vggish': 128}) as w:
+    w.add('v0', {'vggish': np.zeros((3, 128), np.float32)}, captions=[[101, 5, 102]])
+  col = FS.RaggedCollator(FS.FeatureStore(str(tmp_path / 's')), ['vggish'], 1, 4, training=False)
+  with pytest.raises(NotImplementedError, match='remove_stop_words'):
+    col.collate_captions([0], 1, 8, tokenizer=None, remove_stop_words=True)
+  with pytest.raises(NotImplementedError, match='n_pairs'):
+    col.collate_captions([0], 1, 8, tokenizer=None, n_pairs=2)
+  with pytest.raises(ValueError, match='no word-level captions'):
+    col.collate_captions([0], 1, 8, tokenizer=None)
