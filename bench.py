@@ -476,6 +476,11 @@ def main():
     # one contiguous buffer per minibatch (HBM, or pinned host memory with --host-inputs): load = ONE copy
     batches.append(FlatMinibatch(mb, 'cpu', pin_memory=True) if args.host_inputs else FlatMinibatch(mb, dev))
 
+  # packed token rows of every minibatch as a loader counts them on the host before the upload (CENet.count_live_rows; the
+  # ragged wire format carries the count itself): the GEMM dispatcher prices a packed launch at its live size
+  live_hints = [None] * NBATCH
+  if not args.ragged_inputs:
+    live_hints = [CENet.count_live_rows(b['features_ind']) for b in batches]
   slots_used = 1
   in_graph_feed_used = False
 
@@ -505,7 +510,8 @@ def main():
                               capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
                               input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer,
                               host_feed=batches if in_graph_feed else None,
-                              adam_riders=False if args.no_adam_riders else None)
+                              adam_riders=False if args.no_adam_riders else None,
+                              live_rows=live_hints[0] if pack else None)
     runner.measure_exposed = world > 1 or args.force_collectives
     runner.host_sync_uploads = not args.stream_wait_uploads
     nonlocal slots_used, in_graph_feed_used
@@ -552,8 +558,16 @@ def main():
         nonlocal it
         runner.load(batches[it % NBATCH]); it += 1
         return 0
+    # the minibatch in slot s is batches[s % NBATCH] in the resident arrangement; the other arrangements rotate through all
+    # of them, whose counts select the same tiles (checked here: a loader would pass each minibatch's own count)
+    sigs = {runner._tile_signature(h) for h in live_hints} if pack else {None}
+    assert len(sigs) == 1, 'the synthetic minibatches fall into different tile-policy buckets: %r' % (sigs,)
+
+    def hint(slot):
+      return live_hints[slot % NBATCH] if (pack and slots > 1 and not args.host_inputs) else (live_hints[0] if pack else None)
     for _ in range(warmup):
-      l = runner.step(feed())
+      s_ = feed()
+      l = runner.step(s_, live_rows=hint(s_))
       if first is None:
         first = float(l.item())  # loss of the FIRST optimisation step (the runner's warm-up does not train)
     if world > 1:
@@ -561,7 +575,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-      loss = runner.step(feed())
+      s_ = feed()
+      loss = runner.step(s_, live_rows=hint(s_))
     torch.cuda.synchronize()
     if world > 1:
       dist.barrier()

@@ -71,12 +71,16 @@ typedef struct MmtEpilogue {
   float* dot_out;
   /* r06, nullable: an optimizer work queue (MmtAdamQueue in DEVICE memory, see "Adam riders" below).  Blocks of this
    * launch that have no tile to compute -- tiles past the live row count, plus the extra blocks the launcher appends when
-   * a rider is attached -- take units [.., rider_limit) of the queue (parameters whose gradients are final before this
-   * launch) and run the Adam update on them for as long as the GEMM's own blocks are still running; rider_slot names the
-   * "finished blocks" counter of this launch inside the queue's state.  Tiles that do not host riders ignore the fields. */
+   * a rider is attached -- take entries of the queue's first rider_limit STAGES (parameters whose gradients are final before
+   * this launch) and run the Adam update on them for as long as the GEMM's own blocks are still running; rider_slot names
+   * the "finished blocks" counter of this launch inside the queue's state.  Tiles that do not host riders ignore the fields. */
   const void* rider;
   int32_t rider_limit;
   int32_t rider_slot;
+  /* r06: with n_rows_dev set, the live row count as the HOST knows it (0 = unknown: the tile choice then prices the problem
+   * at all M rows).  Only mmt_gemm_select_tile reads it; the kernels read n_rows_dev. */
+  int32_t live_rows_hint;
+  int32_t rider_cap;        /* rider blocks at work in this launch, chip-wide (0 = the library's default, 64) */
 } MmtEpilogue;
 
 /* C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous bf16, fp32 accumulate on MFMA).
@@ -86,6 +90,13 @@ typedef struct MmtEpilogue {
 int mmt_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, int epilogue, const MmtEpilogue* epi,
                      const int32_t* n_rows_dev, void* stream);
+
+/* The tile mmt_gemm_nt_bf16 runs a problem on (13 / 14 / 18: gemm2.hip, 21: gemm3.hip, 24 / 25: gemm5.hip, 1 / 2: the 4-wave
+ * 128x128 / 128x64 kernel of gemm.hip): a pure function of the shape, the epilogue and the live row count the host knows
+ * (packed != 0: n_rows_dev given; live_rows_hint as MmtEpilogue.live_rows_hint; has_colsum / has_dot_out: the epilogue's
+ * optional outputs; reserved as MmtEpilogue.reserved).  Host-only, no GPU needed (tests/test_host_cpu.py pins the policy). */
+int mmt_gemm_select_tile(int epilogue, int M, int N, int K, int packed, int live_rows_hint, int has_colsum, int has_dot_out,
+                         int reserved);
 
 /* Split-K form for skinny problems (M up to a few hundred rows, long K): K-slices run as independent blocks writing fp32
  * partial slabs into `ws`, a second kernel sums them in a fixed order and applies the epilogue
@@ -383,28 +394,34 @@ int mmt_adam_step_fused(float* params, const float* grads, float* exp_avg, float
  * All fields of MmtAdamQueue are device pointers / values; the struct itself lives in device memory (kernels read it
  * through MmtEpilogue.rider) with a host copy for the launcher. */
 #define MMT_RIDER_SLOTS 1024
+#define MMT_RIDER_STAGES 72
+#define MMT_RIDER_STATE_WORDS (MMT_RIDER_STAGES + 1 + MMT_RIDER_SLOTS + 64 + 64 * 64)
 typedef struct MmtAdamQueue {
   float *p, *m, *v;           /* flat master weights and Adam moments                                             */
   const float* g;             /* flat gradients                                                                   */
   const MmtAdamSeg* segs;     /* device segment table (as mmt_adam_step_fused)                                    */
   const int32_t* unit_seg;    /* [n_units] queue entry k -> segment                                               */
   const int32_t* unit_blk;    /* [n_units] queue entry k -> block inside the segment (tile / 4096-element chunk)  */
-  int32_t* state;             /* int32[4 + MMT_RIDER_SLOTS]: [0] entries taken this step, [1] ticket,
-                               * [2 .. 2 + MMT_RIDER_SLOTS) finished-block counters of the hosting launches -- all zero
-                               * between steps --, then two statistics words (entries riders took, steps; never reset) */
+  int32_t* state;             /* int32[MMT_RIDER_STATE_WORDS]: [s] entries of stage s CLAIMED this step (a plain
+                               * fetch-add: may overshoot the stage's size), [MMT_RIDER_STAGES] ticket, then the
+                               * finished-block counters of the hosting launches, two statistics words (entries riders
+                               * ran, steps; never reset) and 64 first-level ticket words on lines of their own; all but
+                               * the statistics are zero between steps                                             */
   int32_t* step_dev;          /* int32[2] = {steps taken so far, unused}                                          */
   const float* lr_dev;        /* nullable: device learning rate                                                   */
-  const struct MmtAdamQueue* chain;  /* nullable: a second queue (another flat buffer) whose entries [0, chain_limit)
+  const struct MmtAdamQueue* chain;  /* nullable: a second queue (another flat buffer) whose first chain_stages stages
                                * a rider block drains FIRST (the text tower's leftovers under the video backward)  */
   float lr, beta1, beta2, eps, weight_decay;
   int32_t n_units;
-  int32_t chain_limit;
-  int32_t reserved;
+  int32_t chain_stages;
+  int32_t n_stages;           /* stages whose entries may be ridden; entries [stage_begin[n_stages], n_units) are only
+                               * final when the backward ends and always run in mmt_adam_step_queue                */
+  int32_t stage_begin[MMT_RIDER_STAGES + 1];  /* entries of stage s: [stage_begin[s], stage_begin[s + 1])        */
 } MmtAdamQueue;
 /* The rest of the step's optimizer work + the step count: entries [state[0], n_units) of the queue, one block each
  * (entries already taken exit at once); the last block to finish zeroes the queue state and stores steps + 1. */
 int mmt_adam_step_queue(const MmtAdamQueue* q_host, const MmtAdamQueue* q_dev, void* stream);
-/* Measurement / test hook: `blocks` rider blocks of 512 threads with nothing else to do drain entries [.., limit). */
+/* Measurement / test hook: `blocks` rider blocks of 512 threads with nothing else to do drain the first `limit` stages. */
 int mmt_adam_rider_probe(const MmtAdamQueue* q_dev, int limit, int blocks, void* stream);
 
 /* bump_step = 0: step_dev[0] is this launch's step number t (bias correction), as mmt_adam_step.
@@ -655,12 +672,12 @@ typedef struct MmtBertBatch {
    * recorded in the capture that waits (ranges captured as separate graphs pass MMT_FORK_JOIN on every call). */
   void* side_stream;
   /* r06 (backward only, all nullable / 0): the optimizer queue the backward's GEMM launches carry (MmtAdamQueue in device
-   * memory), rider_limits[l] (HOST array [layers]) = queue entries whose gradients are final when layer l's backward
-   * starts, rider_slot0 = first finished-block counter this model's launches may use (layer l uses slots
+   * memory), rider_limits[l] (HOST array [layers]) = leading stages of the queue whose gradients are final when layer l's
+   * backward starts, rider_slot0 = first finished-block counter this model's launches may use (layer l uses slots
    * rider_slot0 + 8 l .. + 8 l + 7). */
   const void* rider;
   const int32_t* rider_limits;
-  int32_t rider_slot0;
+  int32_t rider_slot0;       /* (bits 16..31: rider blocks at work per launch, 0 = the library's default) */
   /* r06: the live row count as the HOST knows it (the collator counts valid tokens before the upload), 0 = unknown.  Only
    * the tile choice reads it (the kernels read n_rows_dev); without it a packed batch is priced at rows (every tile live). */
   int32_t live_rows_hint;

@@ -17,7 +17,8 @@ class MmtEpilogue(ctypes.Structure):
               ('aux', c_vp), ('ldaux', c_i64), ('colsum', c_vp), ('row_index', c_vp), ('seed_dev', c_vp),
               ('drop_key', c_u32), ('drop_thr16', c_u32), ('drop_scale', c_f32), ('reserved', ctypes.c_int32),
               ('dot_src', c_vp), ('lddot', c_i64), ('dot_out', c_vp),
-              ('rider', c_vp), ('rider_limit', ctypes.c_int32), ('rider_slot', ctypes.c_int32)]
+              ('rider', c_vp), ('rider_limit', ctypes.c_int32), ('rider_slot', ctypes.c_int32),
+              ('live_rows_hint', ctypes.c_int32), ('rider_cap', ctypes.c_int32)]
 
 
 class MmtPackItem(ctypes.Structure):
@@ -31,14 +32,17 @@ class MmtAdamSeg(ctypes.Structure):
               ('cols', ctypes.c_int32), ('dst_ld', ctypes.c_int32), ('dst_t_ld', ctypes.c_int32)]
 
 
-RIDER_SLOTS = 1024
+RIDER_SLOTS, RIDER_STAGES = 1024, 72
+RIDER_STAT0 = RIDER_STAGES + 1 + RIDER_SLOTS              # first statistics word of MmtAdamQueue.state
+RIDER_STATE_WORDS = RIDER_STAT0 + 64 + 64 * 64
 
 
 class MmtAdamQueue(ctypes.Structure):
   _fields_ = [('p', c_vp), ('m', c_vp), ('v', c_vp), ('g', c_vp), ('segs', c_vp), ('unit_seg', c_vp), ('unit_blk', c_vp),
               ('state', c_vp), ('step_dev', c_vp), ('lr_dev', c_vp), ('chain', c_vp),
               ('lr', c_f32), ('beta1', c_f32), ('beta2', c_f32), ('eps', c_f32), ('weight_decay', c_f32),
-              ('n_units', ctypes.c_int32), ('chain_limit', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+              ('n_units', ctypes.c_int32), ('chain_stages', ctypes.c_int32), ('n_stages', ctypes.c_int32),
+              ('stage_begin', ctypes.c_int32 * (RIDER_STAGES + 1))]
 
 
 class MmtGemmItem(ctypes.Structure):
@@ -142,6 +146,7 @@ SIGNATURES = {
     'mmt_build_info': (ctypes.c_char_p, []),
     'mmt_gemm_nt_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(MmtEpilogue), c_vp, c_vp]),
+    'mmt_gemm_select_tile': (c_int, [c_int] * 9),
     'mmt_gemm_tn_bf16': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mmt_gemm_nt_splitk_workspace_floats': (c_i64, [c_int, c_int, c_int]),
     'mmt_gemm_nt_splitk': (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int,

@@ -113,79 +113,110 @@ __device__ __forceinline__ void adam_unit_store_t(const MmtAdamSeg& seg, int lb,
 // ---- riders ------------------------------------------------------------------------------------------------------
 // LDS a rider block of NT threads needs at `smem`: a control word line + one fp32 tile per group of 256 threads.
 #define MMT_RIDER_TILE_BYTES (64 * 65 * 4)
+#define MMT_RIDER_CHUNK 2  // queue entries a rider block claims per pop (one fetch-add per chunk; a claimed chunk is always run)
+#define MMT_RIDER_CAP 64   // rider blocks at work per launch, chip-wide, unless MmtEpilogue.rider_cap says otherwise: a pass of one
+                           // block moves 256 KB, ~20 block-passes per microsecond is what HBM delivers beside the GEMM
 template <int NT>
 constexpr int adam_rider_lds_bytes() { return 64 + (NT / 256) * MMT_RIDER_TILE_BYTES; }
+
+// queue state words (MmtAdamQueue.state): [0, STAGES) claim counters, [STAGES] ticket, the hosts' finished-block counters,
+// two statistics words (+ padding), the first-level tickets
+#define MMT_RIDER_TICKET MMT_RIDER_STAGES
+#define MMT_RIDER_SLOT0 (MMT_RIDER_STAGES + 1)
+#define MMT_RIDER_STAT0 (MMT_RIDER_STAGES + 1 + MMT_RIDER_SLOTS)
+#define MMT_RIDER_SUBTICKET0 (MMT_RIDER_STAT0 + 64)  // 64 first-level ticket words of mmt_adam_step_queue, one 256-byte line each
+static_assert(MMT_RIDER_STATE_WORDS == MMT_RIDER_SUBTICKET0 + 64 * 64, "queue state layout (include/mmt_hip.h)");
 
 // the hosting launch's own blocks report here when they are done (thread 0 of a finished block)
 __device__ __forceinline__ void adam_rider_host_done(const void* rider, int slot_word) {
   const MmtAdamQueue* q = (const MmtAdamQueue*)rider;
-  __hip_atomic_fetch_add(q->state + 2 + (slot_word & 0xffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(q->state + MMT_RIDER_SLOT0 + (slot_word & 0xffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ bool adam_rider_grab(int32_t* st, int lim, int group, int& base, int& n) {
-  int cur = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while (cur < lim) {
-    const int take = lim - cur < group ? lim - cur : group;
-    if (__hip_atomic_compare_exchange_weak(st, &cur, cur + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-      base = cur; n = take;
+// Claim up to MMT_RIDER_CHUNK entries of the first `stages` stages of `q`: ONE fetch-add on the claim counter of the first
+// stage that is not known to be exhausted (s0: block-local memory of that; a counter only grows within a step, so an
+// exhausted stage stays exhausted).  A compare-and-swap pop serialises: with 512 blocks contending for one word a pop took
+// ~1.3 us (first r06 version: 713 us for a 9 us host launch); a fetch-add never retries, and overshooting a stage's size is
+// harmless -- mmt_adam_step_queue clamps.
+__device__ __forceinline__ bool adam_rider_claim(const MmtAdamQueue* __restrict__ q, int stages, int& s0, int& first, int& n) {
+  while (s0 < stages) {
+    const int lo = q->stage_begin[s0], size = q->stage_begin[s0 + 1] - lo;
+    const int k = size > 0 ? __hip_atomic_fetch_add(q->state + s0, MMT_RIDER_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : size;
+    if (k < size) {
+      first = lo + k;
+      n = size - k < MMT_RIDER_CHUNK ? size - k : MMT_RIDER_CHUNK;
       return true;
     }
+    ++s0;
   }
   return false;
 }
 
-// A block of NT threads (NT a multiple of 256) with no tile of the hosting launch: take queue entries -- NT / 256 at a
-// time, one per group of 256 threads -- until the queue is empty up to `limit` or the host launch is in its tail.
+// A block of NT threads (NT a multiple of 256) with no tile of the hosting launch: claim chunks of queue entries and run
+// them, NT / 256 entries at a time (one per group of 256 threads), until the stages that are ready are exhausted or the
+// host launch is in its tail.
+//   stages: leading stages of the queue whose gradients are final (MmtEpilogue.rider_limit)
 //   slot_word: low 16 bits = the launch's finished-block counter, high 16 bits = how many of the launch's blocks are resident
-//   at once (chip-wide); live_total = blocks of the launch that compute a tile.  The launch's LAST round of blocks is
-//   live_total mod resident (or a full round): once the first of those has finished, a rider stops taking entries -- a unit is
-//   ~2 us of streaming, the launch must not wait for it.
+//   at once (chip-wide); live_total = blocks of the launch that compute a tile; rank = this block's number among the
+//   launch's tile-less blocks (they are dispatched in this order, after every block with a tile); cap = rider blocks at work.
+// Blocks are dispatched in grid order, so the launch's LAST round of tiles is live_total mod resident blocks (or a full
+// round) and leaves resident - last_round residency slots free: tile-less blocks of higher rank than that are only dispatched
+// when the launch is ending and return without touching memory.  The others work until the first block of the last round
+// reports the end of its K-loop -- a pass is ~2 us of streaming, the launch must not wait for it.
 template <int NT>
-__device__ __forceinline__ void adam_rider_run(const void* rider, int limit, int slot_word, int live_total, unsigned char* smem) {
+__device__ __forceinline__ void adam_rider_run(const void* rider, int stages, int slot_word, int live_total, int rank, int cap,
+                                               unsigned char* smem) {
   static_assert(NT % 256 == 0, "rider groups are 256 threads");
   constexpr int G = NT / 256;
+  int resident = (slot_word >> 16) & 0xffff;
+  if (resident <= 0) resident = 256;
+  const int last_round = live_total > 0 ? ((live_total - 1) % resident) + 1 : 0;
+  const int free_slots = resident - last_round;
+  if (cap <= 0) cap = MMT_RIDER_CAP;
+  if (rank >= (free_slots < cap ? free_slots : cap)) return;  // (no memory access: most tile-less blocks leave here)
   const MmtAdamQueue* __restrict__ qd = (const MmtAdamQueue*)rider;
   const int tid = threadIdx.x, grp = tid >> 8, t256 = tid & 255;
   volatile int* ctl = (volatile int*)smem;
   float (*tile)[65] = (float (*)[65])(smem + 64 + grp * MMT_RIDER_TILE_BYTES);
   const int slot = slot_word & 0xffff;
-  int resident = (slot_word >> 16) & 0xffff;
-  if (resident <= 0) resident = 256;
-  const int last_round = live_total > 0 ? ((live_total - 1) % resident) + 1 : 0;
-  const int thresh = live_total - last_round + 1;  // finished host blocks at which the tail has begun (>= 1 with live blocks)
+  const int thresh = live_total - last_round + 1;  // reports at which the last round is ending (>= 1 with live blocks)
   const MmtAdamQueue* __restrict__ chain = qd->chain;
-  const int chain_limit = qd->chain_limit;
+  const int chain_stages = chain ? qd->chain_stages : 0;
+  if (stages > qd->n_stages) stages = qd->n_stages;
+  int s_own = 0, s_chain = 0;  // (thread 0's) first stages not known to be exhausted
   for (;;) {
     if (tid == 0) {
-      int base = -1, n = 0, which = 0;
+      int first = -1, n = 0, which = 0;
       const int done = live_total > 0
-          ? __hip_atomic_fetch_add(qd->state + 2 + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          ? __hip_atomic_load(qd->state + MMT_RIDER_SLOT0 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       if (live_total <= 0 || done < thresh) {
-        if (chain && adam_rider_grab(chain->state, chain_limit, G, base, n)) which = 1;
-        else if (!adam_rider_grab(qd->state, limit, G, base, n)) base = -1;
+        if (chain && adam_rider_claim(chain, chain_stages, s_chain, first, n)) which = 1;
+        else if (!adam_rider_claim(qd, stages, s_own, first, n)) first = -1;
       }
-      ctl[0] = base; ctl[1] = n; ctl[2] = which;
+      ctl[0] = first; ctl[1] = n; ctl[2] = which;
     }
     __syncthreads();
-    const int base = ctl[0], n = ctl[1], which = ctl[2];
-    if (base < 0) break;  // (block-uniform)
+    const int first = ctl[0], n = ctl[1], which = ctl[2];
+    if (first < 0) break;  // (block-uniform)
     const MmtAdamQueue* __restrict__ q = which ? chain : qd;
-    const bool valid = grp < n;
-    bool tr = false;
-    MmtAdamSeg seg = {};
-    int lb = 0;
-    if (valid) {
-      const int k = base + grp;
-      const int si = __builtin_amdgcn_readfirstlane(q->unit_seg[k]);
-      lb = __builtin_amdgcn_readfirstlane(q->unit_blk[k]);
-      seg = q->segs[si];
-      const float lr = q->lr_dev ? *q->lr_dev : q->lr;
-      const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)q->step_dev) + 1;  // the step in progress
-      const AdamHyper h = adam_hyper(lr, q->beta1, q->beta2, q->eps, q->weight_decay, t_int);
-      tr = adam_unit_update(q->p, q->g, q->m, q->v, seg, lb, t256, tile, h);
+    const float lr = q->lr_dev ? *q->lr_dev : q->lr;
+    const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)q->step_dev) + 1;  // the step in progress
+    const AdamHyper h = adam_hyper(lr, q->beta1, q->beta2, q->eps, q->weight_decay, t_int);
+    for (int u = 0; u < n; u += G) {  // the claimed chunk, G entries per pass
+      const bool valid = u + grp < n;
+      bool tr = false;
+      MmtAdamSeg seg = {};
+      int lb = 0;
+      if (valid) {
+        const int k = first + u + grp;
+        const int si = __builtin_amdgcn_readfirstlane(q->unit_seg[k]);
+        lb = __builtin_amdgcn_readfirstlane(q->unit_blk[k]);
+        seg = q->segs[si];
+        tr = adam_unit_update(q->p, q->g, q->m, q->v, seg, lb, t256, tile, h);
+      }
+      __syncthreads();
+      if (tr) adam_unit_store_t(seg, lb, t256, tile);
+      __syncthreads();  // ctl and the tiles are free again
     }
-    __syncthreads();
-    if (tr) adam_unit_store_t(seg, lb, t256, tile);
-    __syncthreads();  // ctl and the tiles are free again
   }
 }

@@ -257,6 +257,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
   const int d = m->hidden, I = m->inter, rows = b->rows;
   const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
   const float sh = scale_of(th), sa = scale_of(ta);
+  const int lh = b->n_rows_dev ? b->live_rows_hint : 0;  // the host's live row count (tile choice only: gemm.hip select_tile)
   const float qk_scale = m->hidden == m->heads * 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(head dim)
 
   TRY(mmt_embed_ln_fwd_sched(b->features, b->type_ids, b->pos_ids, m->type_emb, m->pos_emb, w.z0, m->emb_ln_g,
@@ -269,7 +270,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
   for (int l = 0; l < m->layers; ++l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
-    MmtEpilogue e = {};
+    MmtEpilogue e = {}; e.live_rows_hint = lh;
     e.bias = P.bqkv;
     TRY(mmt_gemm_nt_bf16(hin16, d, P.wqkv, d, L.qkv, 3 * d, rows, 3 * d, d, MMT_EPI_BIAS_BF16, &e, b->n_rows_dev, stream));
     if (nc && l == m->layers - 1) {
@@ -289,7 +290,7 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       TRY(mmt_splitk_ln_fwd(t.slabs, sp, sstride, P.bo, hin32, b->out_rows, nullptr, b->row_index, t.rowidx,
                             site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, t.z1, P.ln1_g, P.ln1_b, m->ln_eps, t.a32, t.a16,
                             t.mean1, t.rstd1, nc, d, stream));
-      e = {};
+      e = {}; e.live_rows_hint = lh;
       e.bias = P.b1; e.out2 = t.g; e.ldout2 = I;
       TRY(mmt_gemm_nt_bf16(t.a16, d, P.w1, d, t.hpre, I, nc, I, d, MMT_EPI_BIAS_GELU, &e, nullptr, stream));
       TRY(mmt_gemm_splitk_geometry(nc, d, I, 0, &sp, &sstride));
@@ -310,19 +311,19 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
       TRY(mmt_gemm_nt_ln_fwd(L.ctx, d, P.wo, d, P.bo, hin32, d, b->row_index, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev,
                              L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, d, b->n_rows_dev, stream));
     } else {
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.bias = P.bo; e.res = hin32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_ATTN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
     TRY(mmt_gemm_nt_bf16(L.ctx, d, P.wo, d, L.z1, d, rows, d, d, MMT_EPI_BIAS_DROP_RES, &e, b->n_rows_dev, stream));
     TRY(mmt_ln_fwd(L.z1, P.ln1_g, P.ln1_b, m->ln_eps, L.a32, L.a16, L.mean1, L.rstd1, rows, d, b->n_rows_dev, stream));
     }
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.bias = P.b1; e.out2 = L.g; e.ldout2 = I;
     {
       ProbeScope probe(0, l == 0, stream);
       TRY(mmt_gemm_nt_bf16(L.a16, d, P.w1, d, L.hpre, I, rows, I, d, MMT_EPI_BIAS_GELU, &e, b->n_rows_dev, stream));
     }
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
     float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
@@ -371,6 +372,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   const int d = m->hidden, I = m->inter, rows = b->rows;
   const uint32_t th = training ? thr16_of(m->p_hidden) : 0u, ta = training ? thr16_of(m->p_attn) : 0u;
   const float sh = scale_of(th), sa = scale_of(ta);
+  const int lh = b->n_rows_dev ? b->live_rows_hint : 0;  // the host's live row count (tile choice only: gemm.hip select_tile)
   const float qk_scale = m->hidden == m->heads * 128 ? 0.08838834764831845f : 0.125f;
   const int rpb = mmt_ln_bwd_rows_per_block(rows);
   const int ln_blocks = (rows + rpb - 1) / rpb;
@@ -411,9 +413,9 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   int ride_j = 0;
   auto ride = [&](MmtEpilogue& e, int l) {
     if (!b->rider || !b->rider_limits || b->rider_limits[l] <= 0 || ride_j >= 8) return;
-    const int slot = b->rider_slot0 + 8 * l + ride_j;
+    const int slot = (b->rider_slot0 & 0xffff) + 8 * l + ride_j;
     if (slot < 0 || slot >= MMT_RIDER_SLOTS) return;
-    e.rider = b->rider; e.rider_limit = b->rider_limits[l]; e.rider_slot = slot;
+    e.rider = b->rider; e.rider_limit = b->rider_limits[l]; e.rider_slot = slot; e.rider_cap = (b->rider_slot0 >> 16) & 0xffff;
     ++ride_j;
   };
   // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
@@ -442,7 +444,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       TRY(mmt_ln_bwd(dlast, t.z2, t.mean2, t.rstd2, P.ln2_g, t.dz, t.dy2, w.ln_partials[2 * l + 2], nc, d, 1, nullptr,
                      t.rowidx, site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
       add_job(w.ln_partials[2 * l + 2], cblocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
-      MmtEpilogue e = {};
+      MmtEpilogue e = {}; e.live_rows_hint = lh;
       e.aux = t.hpre; e.ldaux = I;
       ride(e, l);
       TRY(mmt_gemm_nt_bf16(t.dy2, d, P.w2_t, d, t.dhpre, I, nc, I, d, MMT_EPI_DGELU, &e, nullptr, stream));
@@ -450,7 +452,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         int sp = 0;
         int64_t sstride = 0;
         TRY(mmt_gemm_splitk_geometry(nc, d, I, 0, &sp, &sstride));
-        MmtEpilogue er = {};
+        MmtEpilogue er = {}; er.live_rows_hint = lh;
         ride(er, l);
         TRY(mmt_gemm_nt_splitk_ex(t.dhpre, I, P.w1_t, I, nullptr, d, nc, d, I, MMT_EPI_F32, &er, t.slabs, 0, 0, nullptr, 1,
                                   stream));
@@ -459,7 +461,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
                              nc, d, 1, t.rowidx, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
       }
       add_job(w.ln_partials[2 * l + 1], cblocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
-      e = {};
+      e = {}; e.live_rows_hint = lh;
       // (K = hidden: 8..16 K-steps -- one pass on 16+ tiles costs what the split-K slab kernel alone does, and the
       // slab-reducing epilogue launch goes away)
       // (the GEMM that forms dO also leaves rowsum(dO * O) per 64 columns = the attention backward's delta, in t.delta)
@@ -489,7 +491,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
         TRY(mmt_reduce_slabs_pair(t.wslab, (int64_t)3 * d * d, P.g_wqkv, t.bslab, (int64_t)3 * d, P.g_bqkv, TAIL_WSPLIT, wstream));
         if (fork_w) { if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG; done_cap[par] = capture_id((hipStream_t)side); }
       }
-      e = {};
+      e = {}; e.live_rows_hint = lh;
       ride(e, l);
       float* dnext = w.dA;
       TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_F32, &e, nr, stream));
@@ -512,7 +514,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
     add_job(w.ln_partials[2 * l + 2], ln_blocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
-    MmtEpilogue e = {};
+    MmtEpilogue e = {}; e.live_rows_hint = lh;
     e.aux = L.hpre; e.ldaux = I;
     ride(e, l);
     TRY(mmt_gemm_nt_bf16(dy2, d, P.w2_t, d, dhpre, I, rows, I, d, MMT_EPI_DGELU, &e, nr, stream));
@@ -532,7 +534,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       TRY(mmt_ln_bwd_slabs_ex(w.kslab, sp, sstride, w.dz, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1],
                               rows, d, 1, nr, b->row_index, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
     } else {
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.res = w.dz; e.ldres = d;
     ride(e, l);
     TRY(gemm_hidden(w, rows, d, dhpre, I, P.w1_t, I, w.dA, d, I, MMT_EPI_ADD_F32, &e, nr, stream));
@@ -541,7 +543,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
                    site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
     }
     add_job(w.ln_partials[2 * l + 1], ln_blocks, 3, 2, d, P.g_ln1_g, P.g_ln1_b);
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.dot_src = L.ctx; e.lddot = d; e.dot_out = w.delta;  // rowsum(dO * O) per 64 columns, while dO is in registers
     ride(e, l);
     TRY(mmt_gemm_nt_bf16(dy, d, P.wo_t, d, w.dctx, d, rows, d, d, MMT_EPI_BF16, &e, nr, stream));
@@ -566,7 +568,7 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       if (hipEventRecord(done[par], (hipStream_t)side) != hipSuccess) return MMT_ERR_ARG;
       done_cap[par] = capture_id((hipStream_t)side);
     }
-    e = {};
+    e = {}; e.live_rows_hint = lh;
     e.res = w.dz; e.ldres = d;
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.

@@ -182,43 +182,62 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
 }
 
 // ---- the optimizer queue (include/mmt_hip.h, "Adam riders") ---------------------------------------------------------
-// What the riders of the backward's GEMM launches left of the step: entry k of the queue is block k's, entries below
-// state[0] were taken by a rider.  The LAST block to finish (ticket in state[1]) zeroes the queue state for the next step
-// and stores the new step count -- every block has read both by then.
+// What the riders of the backward's GEMM launches left of the step: entry k of the queue is block k's; of stage s the first
+// min(claimed[s], size[s]) entries were run by riders, their blocks exit at once.  The last block to finish zeroes the queue
+// state for the next step and stores the new step count.  EVERY block must have read the claim counters and the step count
+// by then -- also the blocks that exit at once, and those may be dispatched late -- so every block takes a ticket; 6 074
+// tickets on ONE word, most of them within a few microseconds, serialise (~30 ns each: the first r06 version took 164 us
+// for a launch with 37 % of its blocks working), so the tickets form a two-level tree: block k counts on word k % 64 (one
+// 256-byte line each), the block that completes a word counts on the top word, the block that completes that one finishes.
 __global__ __launch_bounds__(256) void adam_queue_kernel(const MmtAdamQueue* __restrict__ qd) {
   __shared__ float tile[64][65];
-  const MmtAdamQueue q = *qd;
-  const int taken = __builtin_amdgcn_readfirstlane(*(const int32_t*)q.state);
-  const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)q.step_dev) + 1;
-  struct Fin {
-    int32_t *st, *step; int t;
-    __device__ ~Fin() {
-      __syncthreads();
-      __shared__ int last;
-      if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(st + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-      __syncthreads();
-      if (!last) return;
-      // (statistics, never reset: entries the riders took over all steps, steps finished -- FlatAdam.queue_stats)
-      if (threadIdx.x == 0) { st[2 + MMT_RIDER_SLOTS] += st[0]; st[3 + MMT_RIDER_SLOTS] += 1; }
-      __syncthreads();
-      for (int i = threadIdx.x; i < 2 + MMT_RIDER_SLOTS; i += blockDim.x) st[i] = 0;
-      if (threadIdx.x == 0) step[0] = t;
-    }
-  } fin{q.state, q.step_dev, t_int};
+  __shared__ int s_last;
   const int k = (int)blockIdx.x;
-  if (k < taken) return;
-  const int si = __builtin_amdgcn_readfirstlane(q.unit_seg[k]), lb = __builtin_amdgcn_readfirstlane(q.unit_blk[k]);
-  const MmtAdamSeg seg = q.segs[si];
-  const AdamHyper h = adam_hyper(q.lr_dev ? *q.lr_dev : q.lr, q.beta1, q.beta2, q.eps, q.weight_decay, t_int);
-  if (!adam_unit_update(q.p, q.g, q.m, q.v, seg, lb, (int)threadIdx.x, tile, h)) return;
+  const int n_units = qd->n_units, n_stages = qd->n_stages;
+  int32_t* __restrict__ st = qd->state;
+  int ridden = 0;
+  bool mine_taken = false;
+#pragma unroll 1
+  for (int s = 0; s < n_stages; ++s) {  // (uniform: scalar loads)
+    const int lo = qd->stage_begin[s], size = qd->stage_begin[s + 1] - lo;
+    const int c = *(const int32_t*)(st + s);
+    const int taken = c < size ? c : size;
+    ridden += taken;
+    if (k >= lo && k - lo < taken) mine_taken = true;
+  }
+  const int t_int = __builtin_amdgcn_readfirstlane(*(const int32_t*)qd->step_dev) + 1;
+  if (!mine_taken) {
+    const int si = __builtin_amdgcn_readfirstlane(qd->unit_seg[k]), lb = __builtin_amdgcn_readfirstlane(qd->unit_blk[k]);
+    const MmtAdamSeg seg = qd->segs[si];
+    const AdamHyper h = adam_hyper(qd->lr_dev ? *qd->lr_dev : qd->lr, qd->beta1, qd->beta2, qd->eps, qd->weight_decay, t_int);
+    if (adam_unit_update(qd->p, qd->g, qd->m, qd->v, seg, lb, (int)threadIdx.x, tile, h)) {
+      __syncthreads();
+      adam_unit_store_t(seg, lb, (int)threadIdx.x, tile);
+    }
+  }
   __syncthreads();
-  adam_unit_store_t(seg, lb, (int)threadIdx.x, tile);
+  if (threadIdx.x == 0) {
+    const int j = k & 63, expect = n_units / 64 + (j < (n_units & 63) ? 1 : 0);
+    int last = 0;
+    if (__hip_atomic_fetch_add(st + MMT_RIDER_SUBTICKET0 + j * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
+      const int words = n_units < 64 ? n_units : 64;
+      last = __hip_atomic_fetch_add(st + MMT_RIDER_TICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == words - 1;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // (statistics, never reset: entries the riders ran over all steps, steps finished -- FlatAdam.queue_stats)
+  if (threadIdx.x == 0) { st[MMT_RIDER_STAT0] += ridden; st[MMT_RIDER_STAT0 + 1] += 1; }
+  for (int i = threadIdx.x; i < MMT_RIDER_STAT0; i += blockDim.x) st[i] = 0;
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) st[MMT_RIDER_SUBTICKET0 + i * 64] = 0;
+  if (threadIdx.x == 0) qd->step_dev[0] = t_int;
 }
 
 extern "C" int mmt_adam_step_queue(const MmtAdamQueue* q_host, const MmtAdamQueue* q_dev, void* stream) {
   if (!q_host || !q_dev || q_host->n_units <= 0 || !q_host->p || !q_host->g || !q_host->m || !q_host->v || !q_host->segs ||
-      !q_host->unit_seg || !q_host->unit_blk || !q_host->state || !q_host->step_dev)
+      !q_host->unit_seg || !q_host->unit_blk || !q_host->state || !q_host->step_dev || q_host->n_stages < 0 ||
+      q_host->n_stages > MMT_RIDER_STAGES)
     return MMT_ERR_ARG;
   hipLaunchKernelGGL(adam_queue_kernel, dim3(q_host->n_units), dim3(256), 0, (hipStream_t)stream, q_dev);
   return (int)hipGetLastError();
@@ -227,11 +246,11 @@ extern "C" int mmt_adam_step_queue(const MmtAdamQueue* q_host, const MmtAdamQueu
 // rider blocks with no hosting GEMM (tests, tools/adam_lab.py): drain entries [.., limit)
 __global__ __launch_bounds__(512) void adam_rider_probe_kernel(const MmtAdamQueue* __restrict__ qd, int limit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rider_smem[];
-  adam_rider_run<512>(qd, limit, 0, 0, rider_smem);
+  adam_rider_run<512>(qd, limit, (int)(gridDim.x << 16), 0, (int)blockIdx.x, (int)gridDim.x, rider_smem);
 }
 
 extern "C" int mmt_adam_rider_probe(const MmtAdamQueue* q_dev, int limit, int blocks, void* stream) {
-  if (!q_dev || limit < 0 || blocks <= 0) return MMT_ERR_ARG;
+  if (!q_dev || limit < 0 || limit > MMT_RIDER_STAGES || blocks <= 0) return MMT_ERR_ARG;
   hipLaunchKernelGGL(adam_rider_probe_kernel, dim3(blocks), dim3(512), adam_rider_lds_bytes<512>(), (hipStream_t)stream, q_dev,
                      limit);
   return (int)hipGetLastError();

@@ -911,165 +911,141 @@ static int launch_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
 
-// Wide outputs whose width is a multiple of 192 (QKV: 1536, FFN: 3072): a 192-column tile can cover the live rows in ONE
-// round of <= 256 blocks where the 128x128 tile needs 1.3 rounds at 2 blocks per CU (config B, ~3600 live rows of 6976:
-// 14 x 16 = 224 tiles of 256x192 for N = 3072, 28 x 8 = 224 tiles of 128x192 for N = 1536).  Under token packing the
-// live row count is only known on the device; MMT_LIVE_FRACTION (default 0.52 = the synthetic MSRVTT fill, U{0..30} valid
-// tokens of 30) is the host's estimate for choosing the tile.  MMT_TILE_N3072 / MMT_TILE_N1536 force a tile (lab).
-static int wide192_tile(int M, int N, bool packed) {
-  static int forced3072 = -1, forced1536 = -1, enabled = -1;
-  static double live_fraction = 0.52;
-  if (enabled < 0) {
-    const char* a = getenv("MMT_TILE_N3072");
-    const char* b = getenv("MMT_TILE_N1536");
+// ---- tile policy ---------------------------------------------------------------------------------------------------
+// Which kernel runs a GEMM is a pure function of its shape, its epilogue and the number of LIVE rows (token packing: the
+// tiles past the live row count exit, so the launch's real size is the live one).  The live count is on the device; the
+// host's figure is MmtEpilogue.live_rows_hint -- what the collator counted before the upload (MmtBertBatch.live_rows_hint)
+// -- and WITHOUT a hint a packed batch is priced at its allocated rows (every tile live).  r01-r05 guessed
+// M x MMT_LIVE_FRACTION with a default of 0.52 = the fill of the benchmark's synthetic generator: no default of this file
+// is tied to a dataset's fill any more; MMT_LIVE_FRACTION survives as a LAB override only (it replaces the hint).
+// The switches below are read from the environment ONCE (lab / same-box A-B use); mmt_gemm_select_tile exposes the policy
+// to tests (tests/test_host_cpu.py asserts the tile of every shipped (shape, live rows) class).
+struct TilePolicy {
+  int big = 1;      // MMT_TILE_BIG   : 256x256 eight-phase kernel (gemm3.hip, tile 21) where it fills the chip
+  int narrow = 18;  // MMT_TILE_NARROW: tile of the packed N < 1024 GEMMs (18 = phased 128x64 while one round covers them; 13)
+  int wide = 0;     // MMT_TILE_WIDE  : lab, tile for N >= 1024
+  int longk = 0;    // MMT_TILE_LONGK : lab (23 = gemm4.hip), packed narrow GEMMs with K >= 1536
+  int ppn = 1;      // MMT_TILE_PPN   : gemm5.hip on the narrow GEMMs: 0 off, 1 tile 24 on long K once 128x128 tiles fill a round,
+                    //                  2 / 3 force 24 / 25 there, 4 = 24 or else 25, 5 = tile 25 for every packed narrow GEMM,
+                    //                  6 = 1 + tile 25 for the packed K < 1536 ones
+  int pp = 1;       // MMT_TILE_PP    : gemm5.hip (tile 24) on the wide K = hidden GEMMs: 0 off, 1 from 1024 live tiles, 2 from 512
+  int t192 = 0, forced3072 = 0, forced1536 = 0;  // MMT_TILE_192 / _N3072 / _N1536: lab (192-wide tiles)
+  double live_fraction = 0.0;                    // MMT_LIVE_FRACTION: lab override of the live-row estimate (0 = unset)
+};
+static const TilePolicy& tile_policy() {
+  static const TilePolicy pol = [] {
+    TilePolicy p;
+    auto geti = [](const char* name, int def) { const char* v = getenv(name); return v ? atoi(v) : def; };
+    p.big = geti("MMT_TILE_BIG", p.big);
+    p.narrow = geti("MMT_TILE_NARROW", p.narrow);
+    p.wide = geti("MMT_TILE_WIDE", p.wide);
+    p.ppn = geti("MMT_TILE_PPN", p.ppn);
+    p.pp = geti("MMT_TILE_PP", p.pp);
     const char* f = getenv("MMT_LIVE_FRACTION");
-    const char* en = getenv("MMT_TILE_192");
-    forced3072 = a ? atoi(a) : 0;
-    forced1536 = b ? atoi(b) : 0;
-    if (f && atof(f) > 0.0) live_fraction = atof(f);
-    enabled = en ? atoi(en) : 0;  // the r02 one-block-per-CU tiles 15 / 16 (whole-step A/B: 1.473 ms off vs 1.485 ms on); MMT_TILE_192=3: tile 20 below
-#ifndef MMT_LAB_TILES
-    forced3072 = forced1536 = enabled = 0;  // (the 192-wide tiles exist in the lab library only)
+    if (f && atof(f) > 0.0) p.live_fraction = atof(f);
+#ifdef MMT_LAB_TILES  // (tile 23 = gemm4.hip and the 192-wide tiles exist in the lab library only)
+    p.longk = geti("MMT_TILE_LONGK", 0);
+    p.t192 = geti("MMT_TILE_192", 0);
+    p.forced3072 = geti("MMT_TILE_N3072", 0);
+    p.forced1536 = geti("MMT_TILE_N1536", 0);
 #endif
-  }
-  if (N == 3072 && forced3072) return forced3072;
-  if (N == 1536 && forced1536) return forced1536;
-  const int est = packed ? (int)(M * live_fraction) : M;
+    return p;
+  }();
+  return pol;
+}
+
+// rows of the problem that hold live tokens, as far as the host knows
+static int live_rows_of(const TilePolicy& pol, int M, bool packed, int hint) {
+  if (!packed) return M;
+  if (pol.live_fraction > 0.0) return (int)(M * pol.live_fraction);
+  return hint > 0 && hint < M ? hint : M;
+}
+
+// Wide outputs whose width is a multiple of 192 (QKV: 1536, FFN: 3072), LAB library only: a 192-column tile can cover the live
+// rows in ONE round of <= 256 blocks where the 128x128 tile needs 1.3 rounds at 2 blocks per CU (measured: whole-step A/B
+// 1.473 ms off vs 1.485 ms on; tile 20 = a two-deep 128x192 ring: step 1.302 -> 1.339 ms -- opt-in).
+static int wide192_tile(const TilePolicy& pol, int live, int N) {
+  if (N == 3072 && pol.forced3072) return pol.forced3072;
+  if (N == 1536 && pol.forced1536) return pol.forced1536;
   const int cols = N / 192;
-  const int big = ((est + 255) / 256) * cols, mid = ((est + 127) / 128) * cols;
-  if (enabled == 1) {
+  const int big = ((live + 255) / 256) * cols, mid = ((live + 127) / 128) * cols;
+  if (pol.t192 == 1) {
     if (big > 128 && big <= 256) return 15;   // 256x192, one block per CU, one round
     if (mid > 128 && mid <= 256) return 16;   // 128x192
     return 0;
   }
-  // r04 (tools/gemm2_budget.py): a launch of these GEMMs lasts as long as the blocks one residency slot runs back to back
-  // (two slots per CU; blocks resident together move in lock-step through K-loop and epilogue).  3 639 live rows x N = 3072
-  // are 696 tiles of 128x128 on 512 slots: two blocks deep; the same rows are 464 tiles of 128x192 -- every tile resident at
-  // once (tile 20 = tile 16 with a two-deep ring, 80 KiB: two blocks per CU).  Measured: the block gets 1.37x longer (its
-  // GELU sweep is VALU-bound and scales with the tile), FFN-up 29.5 -> 27.6 us, the dGELU variant 30.5 -> 34.6 us (its
-  // registers allow one block per CU), whole step 1.302 -> 1.339 ms: opt-in only (MMT_TILE_192=3).
-  if (enabled == 3) {
-    const int sq = ((est + 127) / 128) * (N / 128);
+  if (pol.t192 == 3) {
+    const int sq = ((live + 127) / 128) * (N / 128);
     if (sq > 512 && mid <= 512) return 20;
   }
   return 0;
 }
 
+// -> tile id: 13 / 14 / 18 (gemm2.hip), 21 (gemm3.hip), 24 / 25 (gemm5.hip), lab tiles, or 1 / 2 = this file's 4-wave
+// 128x128 / 128x64 kernel.  Measured on MI355X (tools/gemm_lab.py, tools/gemm_instr.py, profiles/r01_gemm_lab.txt):
+//   * wide outputs (N >= 1024: QKV, FFN up-projection, dGELU) run best on gemm2's 128x128 tile with 8 waves (wave tile 64x32)
+//     at 2 blocks/CU -- from 1024 live tiles on (>= 4 per CU) on the persistent wave-specialised kernel (tile 24: its first
+//     K-loop and last epilogue are not overlapped with anything: headline, 696 live tiles: 1.2934 vs 1.2816 ms with it; dense
+//     rows, 1320+ tiles: 1.8355 vs 1.8680 ms);
+//   * packed N < 1024 GEMMs: the phased 128x64 tile (18; a 96 KiB ring = ONE block per CU) while the live tiles fit one round
+//     of 256 CUs, else the 8-wave staggered tile at two blocks per CU (13; tools/splitk_lab.py: 38 vs 49 us at 440 tiles);
+//   * long-K narrow GEMMs (FFN down-projection, FFN-up input gradient) on gemm5's 128x128 tiles once those fill a round of
+//     the chip (tile 24, >= 200 live tiles: 30 vs 56 us per launch, unpacked step 1.840 -> 1.764 ms);
+//   * the 256x256 eight-phase kernel (21) from ~one round of such tiles with K >= 1024 (220 of 256 CUs), or 160 with K >= 3072
+//     (at K = 512 prologue and epilogue eat the gain: configs[3] 3.00 -> 3.26 ms with it);
+//   * short batches (M <= 1024: the text tower's ~560..960 token rows) and few-row problems: the 128x64 8-wave tile (13);
+//   * the dense N = 512 GEMMs stay on this file's 128x64 4-wave tile (both saturate the CU's LDS ingest).
+static int select_tile(int EPI, int M, int N, int K, bool packed, int live_hint, bool colsum, bool dot_out, int reserved) {
+  const TilePolicy& pol = tile_policy();
+  if ((reserved & 0xff) >= 3) return reserved & 0xff;  // forced (tests / tuning)
+  const bool dgelu_sums = EPI == MMT_EPI_DGELU && colsum;
+  const int live = live_rows_of(pol, M, packed, live_hint);
+  const long rt128 = (live + 127) / 128;  // live row tiles of 128
+  if (pol.big && reserved == 0 && N % 256 == 0 && M > 1024) {
+    const long t21 = (long)((live + 255) / 256) * (N / 256);
+    if ((t21 >= 220 && K >= 1024) || (t21 >= 160 && K >= 48 * 64)) return 21;
+  }
+  if (reserved == 0 && M > 1024 && !dgelu_sums) {
+    const bool one_round = rt128 * (N / 64) <= 256;
+    const bool plain_epi = EPI != MMT_EPI_BIAS_GELU && EPI != MMT_EPI_DGELU && !dot_out;
+    if (pol.ppn >= 5 && N < 1024 && N % 64 == 0 && K >= 128 && K % 64 == 0 && packed && plain_epi && (pol.ppn == 5 || K < 1536))
+      return 25;
+    if (pol.ppn && N < 1024 && N % 128 == 0 && K >= 1536 && plain_epi) {
+      const long t128 = rt128 * (N / 128);
+      const int t = pol.ppn == 2 ? 24 : pol.ppn == 3 ? 25 : t128 >= 200 ? 24 : pol.ppn == 4 ? 25 : 0;
+      if (t) return t;
+    }
+    if (pol.narrow && N < 1024 && packed && (pol.narrow != 18 || one_round))
+      return pol.longk && K >= 1536 && one_round ? pol.longk : pol.narrow;
+    if (pol.wide && N >= 1024) return pol.wide;
+    if (pol.pp && N >= 1024 && N % 128 == 0 && K >= 128 && K <= 1024 && rt128 * (N / 128) >= (pol.pp >= 2 ? 512 : 1024)) return 24;
+  }
+  if (reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !dgelu_sums && (pol.t192 || pol.forced3072 || pol.forced1536)) {
+    const int t = wide192_tile(pol, live, N);
+    if (t) return t;
+  }
+  if (reserved == 0 && M <= 1024 && !dgelu_sums) return 13;
+  if (reserved == 0 && M >= 512) {
+    if (N >= 1024 && N % 128 == 0 && !dgelu_sums) return 14;
+    if (packed && N % 64 == 0) return 13;
+  }
+  if (reserved == 0 && M < 512 && N >= 1024 && !dgelu_sums) return 13;  // few rows (the compact last layer): shortest block latency
+  if (EPI == MMT_EPI_BF16 && dot_out) return 13;  // the row-dot sums live in gemm2's LDS-staged epilogue only
+  return (N % 128 == 0 && reserved == 1) ? 1 : 2;
+}
+
+extern "C" int mmt_gemm_select_tile(int epilogue, int M, int N, int K, int packed, int live_rows_hint, int has_colsum,
+                                    int has_dot_out, int reserved) {
+  if (M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > MMT_EPI_BIAS_F32) return MMT_ERR_ARG;
+  return select_tile(epilogue, M, N, K, packed != 0, live_rows_hint, has_colsum != 0, has_dot_out != 0, reserved);
+}
+
 template <int EPI>
 static int dispatch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s) {
-  // Measured on MI355X (tools/gemm_lab.py, tools/gemm_instr.py, profiles/r01_gemm_lab.txt):
-  //   * wide outputs (N >= 1024: QKV, FFN up-projection, dGELU) run best on gemm2's 128x128 tile with 8 waves (wave tile
-  //     64x32) at 2 blocks/CU;
-  //   * when token packing halves the live rows, the N = 512 GEMMs run best on gemm2's 128x64 tile with 8 waves in two
-  //     staggered groups (LDS-DMA issue of one group under the other's MFMAs);
-  //   * the dense N = 512 GEMMs stay on this file's 128x64 4-wave tile (both saturate the ~27 B/clk/CU LDS ingest).
-  // reserved: 1/2 force the gemm.hip tiles, >= 3 a gemm2 tile.
-  //   * short batches (M <= 1024: the text tower's ~560..960 token rows): too few 128x128 tiles for 256 CUs; the
-  //     128x64 8-wave tile wins everywhere (tools/gemm_lab.py --text: 10.3 vs 13.2 us FFN-up at 560 live rows).
-  if ((e.reserved & 0xff) >= 3) return mmt_gemm2_dispatch(e.reserved, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  // r04: the 256x256 eight-phase kernel (gemm3.hip, tile 21) where the problem fills the chip with such tiles for long enough:
-  // at least ~one round of them (220 of 256 CUs) with K >= 1024, or 160 with K >= 3072 (at K = 512 -- 8 K-tiles -- prologue
-  // and epilogue eat the gain: configs[3] 3.00 -> 3.26 ms with it).  Measured (tools/gemm3_lab.py,
-  // tools/gemm_lab.py --tiles 14,21): 1.34 vs 0.94 PFLOP/s at 8192 x 65536 x 7168, 146 vs 206 us at 14464 x 1024 x 6144,
-  // 192 vs 238 us at 14464 x 6144 x 1024; at the headline's 3 639 live rows (180 tiles x 8 K-tiles) it LOSES 30.7 vs 27.7 us.
-  // MMT_TILE_BIG=0 switches it off (same-box A/B).
-  {
-    static int big = -1;
-    static double big_frac = 0.52;
-    if (big < 0) {
-      const char* b = getenv("MMT_TILE_BIG");
-      const char* lf = getenv("MMT_LIVE_FRACTION");
-      if (lf && atof(lf) > 0.0) big_frac = atof(lf);
-      big = b ? atoi(b) : 1;
-    }
-    if (big && e.reserved == 0 && N % 256 == 0 && M > 1024) {
-      const int est = nr ? (int)(M * big_frac) : M;
-      const long t21 = (long)((est + 255) / 256) * (N / 256);
-      if ((t21 >= 220 && K >= 1024) || (t21 >= 160 && K >= 48 * 64)) return mmt_gemm2_dispatch(21, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    }
-  }
-  // lab switches (same-box A/B): MMT_TILE_NARROW = tile for the packed N < 1024 GEMMs, MMT_TILE_WIDE = tile for N >= 1024
-  static int narrow = -1, wide = -1, longk = 0;
-  if (narrow < 0) {
-    const char* a = getenv("MMT_TILE_NARROW");
-    const char* b = getenv("MMT_TILE_WIDE");
-    const char* c = getenv("MMT_TILE_LONGK");  // tile for the packed narrow GEMMs with K >= 1536 (lab: 23 = gemm4.hip)
-    longk = c ? atoi(c) : 0;
-#ifndef MMT_LAB_TILES
-    longk = 0;  // (tile 23 = gemm4.hip exists in the lab library only)
-#endif
-    // r03: the phased 128x64 tile (two 4-wave groups on alternate K-steps, gemm2.hip tile 18) replaces the 8-wave spatial
-    // split for the packed narrow GEMMs: step 1.397 -> 1.385 ms same box; K-loop 61.8k -> 52.0k cycles at two blocks per
-    // CU (dense rows), 49.5k -> 52.0k at one (what bounds both is the ~22-30 B/clk a CU ingests: 24 KiB per K-step of a
-    // 128x64 tile -- tools/gemm_instr.py).  MMT_TILE_NARROW=13 restores the r02 tile.
-    narrow = a ? atoi(a) : 18;
-    wide = b ? atoi(b) : 0;
-  }
-  if (e.reserved == 0 && M > 1024 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
-    // the phased tile keeps a 96 KiB ring = ONE block per CU: it only pays while the live tiles fit one round of 256 CUs
-    // (config B: ~224 of 440); beyond that the 8-wave tile at two blocks per CU wins (tools/splitk_lab.py: 38 vs 49 us at
-    // 440 tiles).  The live row count is on the device; the host estimates it as for the 192-wide tiles.
-    const char* lf = getenv("MMT_LIVE_FRACTION");
-    const double frac = (lf && atof(lf) > 0.0) ? atof(lf) : 0.52;
-    const bool one_round = (double)((M + 127) / 128) * frac * (N / 64) <= 256.0;
-    // r05: the wave-specialised kernel (gemm5.hip) for the long-K GEMMs with narrow outputs (FFN down-projection, FFN-up input
-    // gradient) once its 128 x 128 tiles fill a round of the chip (tile 24; unpacked rows: 220 tiles, one per CU): 30 vs 56 us
-    // per launch in the lab, unpacked step 1.840 -> 1.764 ms same box.  On the packed rows (116 such tiles) neither it nor
-    // the 128 x 64 variant with the five-deep ring (tile 25: 232 tiles, 21.3 vs 31.2 us in the lab) survives the step, where
-    // the operands come from Infinity Cache / HBM and a CU's K-step is bound by how many requests it may keep in flight
-    // (1.32 k cycles per K-step cold against 0.72 k warm: profiles/r05_g5_narrow_budget_*.txt; step 1.290-1.296 vs 1.281 ms).
-    // MMT_TILE_PPN = 0 off, 1 (default) as described, 2 / 3 force tile 24 / 25, 4 tile 24 or else 25.
-    static int ppn = -1;
-    if (ppn < 0) {
-      const char* q = getenv("MMT_TILE_PPN");
-      ppn = q ? atoi(q) : 1;
-    }
-    // (lab: 5 = tile 25 for EVERY packed narrow GEMM, 6 = for the K < 1536 ones only -- the K = hidden GEMMs with N = 512)
-    if (ppn >= 5 && N < 1024 && N % 64 == 0 && K >= 128 && K % 64 == 0 && nr != nullptr && EPI != MMT_EPI_BIAS_GELU &&
-        EPI != MMT_EPI_DGELU && e.dot_out == nullptr && (ppn == 5 || K < 1536))
-      return mmt_gemm2_dispatch(25, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    if (ppn && N < 1024 && N % 128 == 0 && K >= 1536 && EPI != MMT_EPI_BIAS_GELU && EPI != MMT_EPI_DGELU && e.dot_out == nullptr) {
-      const double t128 = (double)((M + 127) / 128) * (nr ? frac : 1.0) * (N / 128);
-      const int t = ppn == 2 ? 24 : ppn == 3 ? 25 : t128 >= 200.0 ? 24 : ppn == 4 ? 25 : 0;
-      if (t) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    }
-    if (narrow && N < 1024 && nr != nullptr && (narrow != 18 || one_round))
-      return mmt_gemm2_dispatch(longk && K >= 1536 && one_round ? longk : narrow, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    if (wide && N >= 1024) return mmt_gemm2_dispatch(wide, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    // r05: the persistent wave-specialised kernel (gemm5.hip, tile 24) for the wide K = hidden GEMMs once a CU gets >= 4 tiles of
-    // 128 x 128 (its first K-loop and last epilogue are not overlapped with anything: two tiles' worth of every block).  Same-box
-    // A/B of the whole step (r05): headline, 696 live tiles = 2.7 per CU: 1.2934 vs 1.2816 ms with it (lab: 24.7 vs 26.5 us
-    // warm, but 31 vs 28 us inside the step for FFN-up); dense rows (1320+ tiles) 1.8355 vs 1.8680 ms.
-    // MMT_TILE_PP = 0 off, 1 (default) >= 1024 estimated live tiles, 2 >= 512.
-    static int pp = -1;
-    if (pp < 0) {
-      const char* q = getenv("MMT_TILE_PP");
-      pp = q ? atoi(q) : 1;
-    }
-    if (pp && N >= 1024 && N % 128 == 0 && K >= 128 && K <= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
-      const double frac2 = nr ? frac : 1.0;
-      if ((double)((M + 127) / 128) * frac2 * (N / 128) >= (pp >= 2 ? 512.0 : 1024.0))
-        return mmt_gemm2_dispatch(24, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    }
-  }
-  if (e.reserved == 0 && M >= 512 && N >= 1024 && N % 192 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum)) {
-    const int t = wide192_tile(M, N, nr != nullptr);
-    if (t) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  }
-  if (e.reserved == 0 && M <= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
-    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  if (e.reserved == 0 && M >= 512) {
-    if (N >= 1024 && N % 128 == 0 && !(EPI == MMT_EPI_DGELU && e.colsum))
-      return mmt_gemm2_dispatch(14, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-    if (nr != nullptr && N % 64 == 0) return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  }
-  // few rows (the compact last layer): the 8-wave staggered tile has the shortest per-block latency
-  if (e.reserved == 0 && M < 512 && N >= 1024 && !(EPI == MMT_EPI_DGELU && e.colsum))
-    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  if (EPI == MMT_EPI_BF16 && e.dot_out)  // the row-dot sums live in gemm2's LDS-staged epilogue only
-    return mmt_gemm2_dispatch(13, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
-  if (N % 128 == 0 && e.reserved == 1) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  const int t = select_tile(EPI, M, N, K, nr != nullptr, e.live_rows_hint, e.colsum != nullptr, e.dot_out != nullptr, e.reserved);
+  if (t >= 3) return mmt_gemm2_dispatch(t, EPI, A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
+  if (t == 1) return launch_nt<128, 128, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
   return launch_nt<128, 64, EPI>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
 }
 

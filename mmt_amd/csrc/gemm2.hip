@@ -116,7 +116,9 @@ __device__ __forceinline__ void gemm2_body(
     // r06: a block without a tile works on the optimizer queue the launch carries (adam_unit.h) until the launch's own
     // blocks are in their last round -- Adam's HBM streaming under the MFMA-bound tiles, on CUs that would sit idle
     if constexpr (NT % 256 == 0) {
-      if (epi.rider) adam_rider_run<NT>(epi.rider, epi.rider_limit, epi.rider_slot, live_tiles * (int)gridDim.y, smem_raw);
+      if (epi.rider)
+        adam_rider_run<NT>(epi.rider, epi.rider_limit, epi.rider_slot, live_tiles * (int)gridDim.y,
+                           (bid - live_tiles) * (int)gridDim.y + (int)blockIdx.y, epi.rider_cap, smem_raw);
     }
     return;
   }
@@ -324,6 +326,9 @@ __device__ __forceinline__ void gemm2_body(
     TICK(t_comp);
   }
   if constexpr (PH) wait_vmcnt<0>();
+  // (riders of this launch -- adam_unit.h -- stop claiming work when the first block of the last round gets here: the
+  // epilogue that follows is the notice they need to finish the pass they are in)
+  if (epi.rider && tid == 0) adam_rider_host_done(epi.rider, epi.rider_slot);
 #ifdef MMT_GEMM2_INSTR
   const long long t_loop_end = clock64();
 #endif
@@ -336,7 +341,6 @@ __device__ __forceinline__ void gemm2_body(
 #else
   gemm_tile_epilogue<BM, BN, WGM, WGN, NT, EPI, PH>(acc, smem_raw, m0, n0, M, N, nrows, Cout, ldc, epi, wm, wn, kg, tid, nullptr);
 #endif
-  if (epi.rider && tid == 0) adam_rider_host_done(epi.rider, epi.rider_slot);  // (riders stop when the last round finishes)
 #ifdef MMT_GEMM2_INSTR
   if (epi.row_index == nullptr && epi.seed_dev != nullptr && tid == 0) {  // lab: seed_dev doubles as the debug buffer
     long long* dbgbuf = (long long*)epi.seed_dev + (int64_t)bid * 16;
@@ -369,12 +373,12 @@ template <int BM, int BN, int WGM, int WGN, int NS, bool BKN = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm2_splitk_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ ws,
     int64_t slab_stride, int64_t ldws, int M, int N, int K, int kchunk, const int32_t* __restrict__ n_rows_dev,
-    const void* rider, int rider_limit, int rider_slot) {
+    const void* rider, int rider_limit, int rider_slot, int rider_cap) {
   const int z = blockIdx.y;
   const int kb = z * kchunk;
   const int kl = min(kchunk, K - kb);
   MmtEpilogue e = {};
-  e.rider = rider; e.rider_limit = rider_limit; e.rider_slot = rider_slot;  // (blocks without a tile: adam_unit.h)
+  e.rider = rider; e.rider_limit = rider_limit; e.rider_slot = rider_slot; e.rider_cap = rider_cap;  // (blocks without a tile: adam_unit.h)
   gemm2_body<BM, BN, WGM, WGN, NS, MMT_EPI_F32, BKN>(A + kb, lda, BKN ? B + (int64_t)kb * ldb : B + kb, ldb,
                                                       ws + (int64_t)z * slab_stride, ldws, M, N, kl, e, n_rows_dev,
                                                       (int)blockIdx.x, (int)gridDim.x);
@@ -468,11 +472,12 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
       const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
       const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
       slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
-      gx += (256 * per_cu + splits - 1) / splits;
+      const int cap = e.rider_cap > 0 ? e.rider_cap : MMT_RIDER_CAP;
+      gx += ((cap < 256 * per_cu ? cap : 256 * per_cu) + splits - 1) / splits;
     }
   }
   hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, NS, BKN>), dim3(gx, splits), dim3(NT),
-                     lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr, rider, e.rider_limit, slot);
+                     lds, s, A, lda, B, ldb, ws, slab, (int64_t)N, M, N, K, per * BK, nr, rider, e.rider_limit, slot, e.rider_cap);
   return 0;
 }
 
@@ -634,7 +639,8 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
       const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
       const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
       e2.rider_slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
-      grid += 256 * per_cu;
+      const int cap = e.rider_cap > 0 ? e.rider_cap : MMT_RIDER_CAP;
+      grid += cap < 256 * per_cu ? cap : 256 * per_cu;
     }
   }
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, NS, EPI, BKN, PH>), dim3(grid), dim3(NT), lds, s, (const bf16_t*)A, lda,

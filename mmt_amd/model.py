@@ -313,6 +313,9 @@ class CENet(nn.Module):
     # the read-out only uses the AGG rows (model.py:583-587): let the last layer compute just those (exact)
     self.tail_rows_only = True
     self._vid_weights = {}
+    # packed token rows of the NEXT minibatch as the loader counted them (None = unknown): lets the GEMM dispatcher price
+    # a packed launch at its live size (include/mmt_hip.h: MmtBertBatch.live_rows_hint); `count_live_rows` computes it
+    self.live_rows_hint = None
     self.overlap_text_heads = False  # measured: no gain on MI355X (1.76 vs 1.74 ms/step), kept as an option
     self._side_streams = {}
     # the reference indexes nn.Embedding tables with these and raises IndexError when they do not fit; the kernels would
@@ -462,6 +465,17 @@ class CENet(nn.Module):
       out.append(('bottom', f.span(self._reduce_params() + emb + per_layer[0])))
     return out
 
+  @staticmethod
+  def count_live_rows(features_ind):
+    """Packed token rows of a minibatch from its HOST-side indicator arrays {expert: (B, T) 0/1} (what the reference's
+    collate hands over, base/base_dataset.py:779-806): one CLS row per sample + per expert one AGG row and its valid
+    feature rows.  The loader calls this before the upload and assigns the result to `live_rows_hint`."""
+    first = next(iter(features_ind.values()))
+    total = int(first.shape[0])
+    for ind in features_ind.values():
+      total += int(ind.shape[0]) + int((torch.as_tensor(ind) != 0).sum())
+    return total
+
   def engine_params(self):
     """Parameters living in the flat buffer (video side), in layout order."""
     return self._flat.params
@@ -576,6 +590,12 @@ class CENet(nn.Module):
                         row_index=plan.row_index if self.pack_tokens else None,  # dense rows ARE the original coordinates
                         n_rows_dev=plan.n_rows if self.pack_tokens else None,
                         out_rows=plan.agg_row if self.tail_rows_only else None, n_out_per_sample=len(mods))
+    # the live token rows as the HOST knows them (tile choice only; the kernels read the device count): set by the loader
+    # (`live_rows_hint`, e.g. RaggedCollator's count), or read off the wire format, which carries them
+    hint = self.live_rows_hint
+    if hint is None and isinstance(features, RaggedFeatures):
+      hint = bsz + sum(int(v) for v in features.live.values())  # CLS + per expert (AGG + valid feature rows)
+    batch.live_rows_hint = int(hint or 0) if self.pack_tokens else 0
     last = self.vid_bert.run_engine(batch, feats)
     # handles for callers that drive the backward of this forward stage by stage (train_step.GraphedTrainStep)
     self._stages = dict(plan=plan, feats=feats, batch=batch, last=last) if last.requires_grad else None

@@ -242,7 +242,7 @@ class FlatAdam:
     backward has run: the unit stays for `step()`).  A unit that overlaps several parameters takes the latest of their
     stages.  chain: another FlatAdam whose queue the rider blocks of THIS queue's launches drain first (all of it must be
     final by then: the native text tower's leftovers under the video side's backward).
-    Returns the number of stages n; `queue_limit(s)` = entries final after stage s.  While a queue is armed, `step()`
+    Returns the number of stages n; `queue_limit(k)` = entries in the first k stages.  While a queue is armed, `step()`
     runs mmt_adam_step_queue (the entries no rider took + the step count) instead of the single fused launch: weights,
     moments and bf16 shadows come out bit-identical (tests/test_optim_gpu.py).  Reference: train.py:100,
     trainer/trainer.py:203-204 (`optimizer.step()` after the whole backward)."""
@@ -250,7 +250,7 @@ class FlatAdam:
 
     import numpy as np
 
-    from ._lib import MmtAdamQueue, RIDER_SLOTS
+    from ._lib import MmtAdamQueue, RIDER_STAGES, RIDER_STATE_WORDS
     f = self.flat
     self._ensure_state()
     if self._frozen_spans():
@@ -291,38 +291,39 @@ class FlatAdam:
     stages = np.maximum(np.array(stages, dtype=np.int64), 0)
     perm = np.argsort(stages, kind='stable')
     stages = stages[perm]
+    n_stages = int(stages[stages < NEVER].max()) + 1 if (stages < NEVER).any() else 0
+    if n_stages > RIDER_STAGES:
+      raise ValueError('optimizer queue: %d stages (at most %d)' % (n_stages, RIDER_STAGES))
     devc = f.master.device
     unit_seg = torch.from_numpy(np.array(seg_ids, dtype=np.int32)[perm].copy()).to(devc)
     unit_blk = torch.from_numpy(np.array(blks, dtype=np.int32)[perm].copy()).to(devc)
-    state = torch.zeros(4 + RIDER_SLOTS, dtype=torch.int32, device=devc)
+    state = torch.zeros(RIDER_STATE_WORDS, dtype=torch.int32, device=devc)
     q = MmtAdamQueue()
     q.p, q.m, q.v, q.g = f.master.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.current_grad().data_ptr()
     q.segs, q.unit_seg, q.unit_blk = dev.data_ptr(), unit_seg.data_ptr(), unit_blk.data_ptr()
     q.state, q.step_dev, q.lr_dev = state.data_ptr(), self._step_store.data_ptr(), self.lr_dev.data_ptr()
     q.lr, q.beta1, q.beta2, q.eps, q.weight_decay = float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay
-    q.n_units = len(seg_ids)
+    q.n_units, q.n_stages = len(seg_ids), n_stages
+    for s_ in range(RIDER_STAGES + 1):  # entries of stage s: [stage_begin[s], stage_begin[s + 1]); beyond n_stages: the rest
+      q.stage_begin[s_] = int(np.searchsorted(stages, s_, side='left')) if s_ <= n_stages else len(seg_ids)
     if chain is not None:
       if chain._queue is None:
         raise ValueError('chain: build the other optimizer\'s queue first')
-      q.chain, q.chain_limit = chain._queue['dev'].data_ptr(), chain._queue['host'].n_units
+      q.chain, q.chain_stages = chain._queue['dev'].data_ptr(), chain._queue['host'].n_stages
     qdev = torch.frombuffer(bytearray(bytes(q)), dtype=torch.uint8).clone().to(devc)
-    n_stages = int(stages[stages < NEVER].max()) + 1 if (stages < NEVER).any() else 0
-    limits = [int(np.searchsorted(stages, s, side='right')) for s in range(n_stages)]
-    self._queue = dict(host=q, dev=qdev, keep=(unit_seg, unit_blk, state, dev), limits=limits, state=state,
+    self._queue = dict(host=q, dev=qdev, keep=(unit_seg, unit_blk, state, dev), state=state,
                        key=(self._seg_key, f.current_grad().data_ptr()), armed=False)
     return n_stages
 
-  def queue_limit(self, stage):
-    """Queue entries whose gradients are final once stage `stage` of the backward has run (-1: before any stage)."""
-    lim = self._queue['limits']
-    if stage < 0 or not lim:
-      return 0
-    return lim[min(stage, len(lim) - 1)]
+  def queue_limit(self, stages):
+    """Queue entries in the first `stages` stages (what riders may run once that many stages of the backward are done)."""
+    q = self._queue['host']
+    return int(q.stage_begin[max(0, min(int(stages), q.n_stages))])
 
   def queue_stats(self):
     """(queue entries, entries taken by riders over all finished steps, finished steps) -- synchronises."""
-    from ._lib import RIDER_SLOTS
-    st = self._queue['state'][2 + RIDER_SLOTS:].tolist()
+    from ._lib import RIDER_STAT0
+    st = self._queue['state'][RIDER_STAT0:RIDER_STAT0 + 2].tolist()
     return self._queue['host'].n_units, st[0], st[1]
 
   def queue_ptr(self):

@@ -171,7 +171,7 @@ class GraphedTrainStep:
   def __init__(self, model, loss_fn, minibatch, lr=5e-5, group=None, use_graphs=True, warmup_steps=3,
                overlap_grad_sync=None, force_collectives=False, grad_dtype=None, capture_collectives=False, fork=None,
                grad_algo='allreduce', split_bottom=True, input_slots=1, bind_inputs=None, shard_optimizer=False,
-               host_feed=None, adam_riders=None):
+               host_feed=None, adam_riders=None, live_rows=None):
     """minibatch: dict of DEVICE tensors as CENet.forward takes them (used as the static input buffers).
     overlap_grad_sync: None = staged backward with per-stage all-reduce when world size > 1; True forces the staged
     backward (also at world size 1, where it only splits graph B); False = one all-reduce after the backward.
@@ -198,6 +198,10 @@ class GraphedTrainStep:
     r03 upload path ran 0.16 ms per step behind the resident one whatever the bytes); `prime()` uploads slot 0 once.
     Contract for the loader: pinned buffer (s + 1) % K holds minibatch i + 1 when step(s) is launched for minibatch i and is
     not rewritten before that step has finished (`step_done(slot)`).
+    live_rows: packed token rows of the minibatches as the loader counts them (`CENet.count_live_rows`; RaggedFeatures
+    carry the count themselves): the GEMM dispatcher picks its tiles for a launch's LIVE size (include/mmt_hip.h:
+    MmtBertBatch.live_rows_hint) at capture time.  `step(slot, live_rows=n)` re-captures (once per distinct tile choice, kept)
+    when a minibatch's count would select other tiles; without any count a packed batch is priced at its allocated rows.
     adam_riders (one rank only; None = on unless MMT_ADAM_RIDERS=0): the optimizer leaves the critical path -- the step's
     Adam update is a queue of 4096-element units ordered by when their gradients are final, the GEMM launches of the
     backward carry it (blocks without a tile of their own -- idle CUs, the last partial round -- stream Adam's bytes under
@@ -219,6 +223,9 @@ class GraphedTrainStep:
     self._keep = []
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if live_rows is not None and hasattr(model, 'live_rows_hint'):
+      model.live_rows_hint = int(live_rows)
+    self._sig, self._by_sig, self._sig_cache = None, {}, {}
     # measurement hook: issue the collectives even at world size 1 (a 1-rank RCCL group) to see what their stream
     # plumbing costs on a single GPU (bench.py --force-collectives)
     self._force_coll = bool(force_collectives) and dist.is_initialized()
@@ -310,29 +317,70 @@ class GraphedTrainStep:
     if use_graphs:
       if int(input_slots) > 1:
         self._statics += [_clone_tree(minibatch) for _ in range(int(input_slots) - 1)]
-        self._caps = []
         if self._host_feed is not None and len(self._host_feed) != len(self._statics):
           raise ValueError('host_feed: one pinned FlatMinibatch per input slot')
-        for si, st in enumerate(self._statics):
-          self.static = st
-          if self._host_feed is not None:
-            nx = (si + 1) % len(self._statics)
-            self._next_upload = (self._statics[nx], self._host_feed[nx])
-          if self._bind:
-            self._bind(st)
-          # the slots never replay concurrently: their captures share ONE graph memory pool (activations / workspaces of a
-          # step exist once, not once per slot); what a capture leaves alive (its loss / embedding outputs) stays allocated
-          self._capture()
-          if self._pool is None:
-            g0 = self._graphs[0]
-            self._pool = g0.pool()
-          self._caps.append((self._graphs, self._e, self.loss, self._one_graph))
-        self.static = self._statics[0]
+      self._capture_slots()
+      self._sig = self._tile_signature(getattr(model, 'live_rows_hint', None))
+
+  def _capture_slots(self):
+    """The captured step for every input slot, under the model's current live-row hint (= tile choice)."""
+    if len(self._statics) > 1:
+      self._caps = []
+      for si, st in enumerate(self._statics):
+        self.static = st
+        if self._host_feed is not None:
+          nx = (si + 1) % len(self._statics)
+          self._next_upload = (self._statics[nx], self._host_feed[nx])
         if self._bind:
-          self._bind(self.static)
-        self._graphs, self._e, self.loss, self._one_graph = self._caps[0]
-      else:
+          self._bind(st)
+        # the slots never replay concurrently: their captures share ONE graph memory pool (activations / workspaces of a
+        # step exist once, not once per slot); what a capture leaves alive (its loss / embedding outputs) stays allocated
         self._capture()
+        if self._pool is None:
+          g0 = self._graphs[0]
+          self._pool = g0.pool()
+        self._caps.append((self._graphs, self._e, self.loss, self._one_graph))
+      self.static = self._statics[0]
+      if self._bind:
+        self._bind(self.static)
+      self._graphs, self._e, self.loss, self._one_graph = self._caps[0]
+    else:
+      self._capture()
+
+  def _tile_signature(self, live_rows):
+    """The tiles the dispatcher picks for the video encoder's GEMMs at `live_rows` packed token rows (None: not applicable).
+    Two minibatches with the same signature replay the same captured step; another signature is another capture."""
+    m = self.model
+    vb = getattr(m, 'vid_bert', None)
+    if live_rows is None or vb is None or not getattr(m, 'pack_tokens', False) or not getattr(m, '_plans', None):
+      return None
+    hit = self._sig_cache.get(int(live_rows))
+    if hit is not None:
+      return hit
+    L, E = _lib.lib(), _lib.EPI
+    rows = next(iter(m._plans.values())).rows
+    d, I = vb.config.hidden_size, vb.config.intermediate_size
+    shapes = [(E['BIAS_BF16'], 3 * d, d, 0), (E['BIAS_DROP_RES'], d, d, 0), (E['BIAS_GELU'], I, d, 0), (E['BIAS_DROP_RES'], d, I, 0),
+              (E['DGELU'], I, d, 0), (E['ADD_F32'], d, I, 0), (E['BF16'], d, d, 1), (E['ADD_F32'], d, 3 * d, 0)]
+    sig = tuple(L.mmt_gemm_select_tile(e, rows, n, k, 1, int(live_rows), 0, dot, 0) for e, n, k, dot in shapes)
+    self._sig_cache[int(live_rows)] = sig
+    return sig
+
+  def _switch_tiles(self, sig, live_rows):
+    """step(live_rows=...) met a minibatch whose live size selects other GEMM tiles than the captures in use: keep those,
+    take (or capture, once) the set for the new choice."""
+    self._by_sig[self._sig] = (self._caps, self._graphs, self._e, self.loss, self._one_graph)
+    self.model.live_rows_hint = int(live_rows)
+    hit = self._by_sig.get(sig)
+    if hit is not None:
+      self._caps, self._graphs, self._e, self.loss, self._one_graph = hit
+    else:
+      cur = torch.cuda.current_stream()
+      self._stream.wait_stream(cur)
+      with torch.cuda.stream(self._stream):
+        self._capture_slots()
+      cur.wait_stream(self._stream)
+    self._sig = sig
 
   # ---- warm-up must not train --------------------------------------------------------------------
   def _snapshot(self):
@@ -853,11 +901,14 @@ class GraphedTrainStep:
       opt_v.build_queue(stage_v, chain=opt_t)
     for o in self.opt_flats:
       o.arm_queue(True)
-    vb.set_rider(opt_v.queue_ptr(), [opt_v.queue_limit(Lv - 1 - l) for l in range(Lv)], 0)
+    # stages of the queue that are final while layer l's backward runs: text heads + the layers above (video side), the
+    # layers above (text tower)
+    cap = max(0, min(0xffff, int(os.environ.get('MMT_RIDER_CAP', '0')))) << 16  # (lab: rider blocks at work per launch)
+    vb.set_rider(opt_v.queue_ptr(), [Lv - l for l in range(Lv)], cap)
     if opt_t is not None:
       tb = m.txt_bert
       Lt = tb.config.num_hidden_layers
-      tb.set_rider(opt_t.queue_ptr(), [opt_t.queue_limit(Lt - 2 - l) for l in range(Lt)], 0)
+      tb.set_rider(opt_t.queue_ptr(), [Lt - 1 - l for l in range(Lt)], cap)
 
   def _disarm_riders(self):
     self.model.vid_bert.set_rider(None)
@@ -1110,10 +1161,17 @@ class GraphedTrainStep:
     cur.wait_stream(self._stream)
     return self.loss
 
-  def step(self, slot=0):
-    """Runs one optimisation step on the static inputs (of `slot`); returns the (device) loss tensor."""
+  def step(self, slot=0, live_rows=None):
+    """Runs one optimisation step on the static inputs (of `slot`); returns the (device) loss tensor.  live_rows: the
+    minibatch's packed token rows as the loader counted them (see the constructor)."""
     if not self.use_graphs:
+      if live_rows is not None and hasattr(self.model, 'live_rows_hint'):
+        self.model.live_rows_hint = int(live_rows)
       return self.eager_step()
+    if live_rows is not None:
+      sig = self._tile_signature(live_rows)
+      if sig is not None and sig != self._sig:
+        self._switch_tiles(sig, live_rows)
     for o in self.opt_flats:
       o.sync_lr()  # learning-rate schedule: the captured optimizer graph reads the rate from the device
     if self._caps is not None:

@@ -26,8 +26,11 @@ def _to_dev(mb):
   return out
 
 
-def _run(model, mb, text, out='conf'):
+def _run(model, mb, text, out='conf', hint=True):
   model.txt_bert.text = text.view(-1, text.shape[-1])
+  # what a loader does before the upload: count the minibatch's packed token rows, so that the GEMM dispatcher picks its
+  # tiles for the launch's LIVE size (MmtBertBatch.live_rows_hint); hint=False: a packed batch priced at its allocated rows
+  model.live_rows_hint = type(model).count_live_rows(mb['features_ind']) if (hint and model.pack_tokens) else None
   return model(mb['token_ids'], mb['features'], mb['features_t'], mb['features_ind'], mb['features_avgpool'],
                mb['features_maxpool'], mb['query_masks'], out=out, device=DEV)
 
@@ -35,6 +38,25 @@ def _run(model, mb, text, out='conf'):
 def _cos(a, b):
   a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
   return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def test_live_row_hint_changes_tiles_not_results():
+  """The host's live-row count only selects GEMM tiles (gemm.hip: select_tile): configB packed, with the loader's count (the
+  phased one-round tile 18 for the N = 512 GEMMs) and without it (priced at all 6976 rows: tiles 13 / 24), gives the same
+  similarities up to the summation order of the tiles, and the count itself equals what the plan kernel counts on the device."""
+  fx = load_cenet_fixture('configB')
+  model = build_native_cenet(fx.meta, pack_tokens=True)
+  model.load_state_dict(fx.state_dict)
+  model.to(DEV).eval()
+  mb, text = _to_dev(fx.batch), fx.text.to(DEV)
+  with torch.no_grad():
+    a = _run(model, mb, text, hint=True)['cross_view_conf_matrix'].clone()
+    hinted = model.live_rows_hint
+    plan = model._plans[next(iter(model._plans))]
+    assert hinted == int(plan.n_rows.item()) < plan.rows
+    b = _run(model, mb, text, hint=False)['cross_view_conf_matrix']
+  assert model.live_rows_hint is None
+  assert (a - b).abs().max().item() < 5e-4 and np.abs(a.cpu().numpy() - fx.gold['eval_sims']).max() < 2e-3
 
 
 @pytest.mark.parametrize('name', ['tiny', 'configA', 'configB', 'config4', 'config4b32', 'config5', 'config5b16'])

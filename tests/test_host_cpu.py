@@ -39,14 +39,49 @@ def test_library_exports_every_declared_symbol_and_bindings_match():
   assert set(_lib.SIGNATURES) == set(decl)
   assert _lib.lib().mmt_abi_version() == 3
   # struct layouts agree with the C side (sizes are what the kernels are compiled against)
-  assert ctypes.sizeof(_lib.MmtEpilogue) == 136  # + dot_src / lddot / dot_out (r04), rider / rider_limit / rider_slot (r06)
+  assert ctypes.sizeof(_lib.MmtEpilogue) == 144  # + dot_src / lddot / dot_out (r04), rider / rider_limit / rider_slot / live_rows_hint (r06)
   assert ctypes.sizeof(_lib.MmtPackItem) == 48
   assert ctypes.sizeof(_lib.MmtExpertIO) == 96
   assert ctypes.sizeof(_lib.MmtBertLayer) == 28 * 8
   assert ctypes.sizeof(_lib.MmtBertBatch) == 128  # + side_stream (r03), rider / rider_limits / rider_slot0 / live_rows_hint (r06)
-  assert ctypes.sizeof(_lib.MmtAdamQueue) == 120 and _header_define('MMT_RIDER_SLOTS') == _lib.RIDER_SLOTS
+  assert ctypes.sizeof(_lib.MmtAdamQueue) == 416 and _header_define('MMT_RIDER_SLOTS') == _lib.RIDER_SLOTS
+  assert _header_define('MMT_RIDER_STAGES') == _lib.RIDER_STAGES and _lib.RIDER_STATE_WORDS == 72 + 1 + 1024 + 64 + 4096
   assert ctypes.sizeof(_lib.MmtVideoFront) == 8 + 6 * 4 + 11 * 8  # experts | M B T pack max_pos do_cast | 11 pointers
   assert ctypes.sizeof(_lib.MmtTextHeadsOpts) == 16 + 4 * 8          # + video_front (r03)
+
+
+def test_gemm_tile_policy_is_a_function_of_shape_and_live_rows():
+  """mmt_gemm_select_tile (gemm.hip: select_tile) for the five shipped policies -- 14: 128x128 two blocks per CU, 18: phased
+  128x64 while ONE round covers the live tiles, 13: 8-wave 128x64 at two blocks per CU, 24: persistent wave-specialised kernel
+  from >= 4 tiles per CU (wide) / >= 200 tiles of 128x128 (long K, narrow), 21: 256x256 from a chip's worth of such tiles, 2:
+  the 4-wave dense N = 512 kernel -- as a function of (epilogue, M, N, K, packed, live rows): the live count the HOST passes
+  (MmtBertBatch.live_rows_hint) decides, no constant tied to the benchmark generator's fill (VERDICT r05 item 4 / weak 8, 11);
+  without a hint a packed batch is priced at its allocated rows."""
+  from mmt_amd import _lib
+  if any(k.startswith('MMT_TILE_') or k == 'MMT_LIVE_FRACTION' for k in os.environ):
+    pytest.skip('tile policy switches set in the environment')
+  f = ctypes.CDLL(_lib.LIB_PATH).mmt_gemm_select_tile
+  E = _lib.EPI
+  shapes = [('BIAS_BF16', 1536, 512, 0), ('BIAS_DROP_RES', 512, 512, 0), ('BIAS_GELU', 3072, 512, 0), ('BIAS_DROP_RES', 512, 3072, 0),
+            ('DGELU', 3072, 512, 0), ('ADD_F32', 512, 3072, 0), ('BF16', 512, 512, 1), ('ADD_F32', 512, 1536, 0)]
+  #            QKV  attn-out FFN-up FFN-down dGELU dFFN-up dO  dQKV     (config B: 32 x 218 = 6976 token rows, d 512, I 3072)
+  want = {(6976, 1, 3639): [14, 18, 14, 18, 14, 18, 18, 18],   # the benchmark's fill: 29 live row tiles, 232 narrow tiles = one round
+          (6976, 1, 1900): [14, 18, 14, 18, 14, 18, 18, 18],   # fill 0.25
+          (6976, 1, 5300): [14, 13, 14, 13, 14, 13, 13, 13],   # fill 0.75: 336 narrow tiles > one round -> two blocks per CU
+          (6976, 1, 6976): [14, 13, 24, 24, 24, 24, 13, 24],   # fill 1.0 = what a packed batch without a hint is priced at
+          (6976, 1, 0):    [14, 13, 24, 24, 24, 24, 13, 24],
+          (6976, 0, 0):    [14, 2, 24, 24, 24, 24, 13, 24],    # dense rows
+          (22656, 1, 11600): [24, 13, 24, 24, 24, 24, 13, 24]}  # configs[3], S = 708
+  for (M, packed, live), tiles in want.items():
+    got = [f(E[e], M, n, k, packed, live, 0, dot, 0) for e, n, k, dot in shapes]
+    assert got == tiles, ((M, packed, live), got)
+  # configs[4] (d 1024, I 6144, 14.5 k live of 27.9 k rows): the 256x256 kernel; short batches and the compact last layer: tile 13
+  assert [f(E['BIAS_GELU'], 27904, 6144, 1024, 1, 14464, 0, 0, 0), f(E['BIAS_DROP_RES'], 27904, 1024, 6144, 1, 14464, 0, 0, 0)] == [21, 21]
+  assert [f(E['BIAS_GELU'], 960, 3072, 768, 1, 560, 0, 0, 0), f(E['BIAS_GELU'], 224, 3072, 512, 0, 0, 0, 0, 0)] == [13, 13]
+  # a hint larger than the allocation or <= 0 is "unknown"; forced tiles (MmtEpilogue.reserved) win
+  assert f(E['BIAS_DROP_RES'], 6976, 512, 3072, 1, 10 ** 6, 0, 0, 0) == f(E['BIAS_DROP_RES'], 6976, 512, 3072, 1, -5, 0, 0, 0) == 24
+  assert f(E['BIAS_GELU'], 6976, 3072, 512, 1, 3639, 0, 0, 13) == 13 and f(E['BIAS_GELU'], 6976, 3072, 512, 0, 0, 0, 0, 1) == 1
+  assert f(99, 1, 1, 1, 0, 0, 0, 0, 0) < 0
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -292,14 +292,16 @@ def test_adam_queue_with_riders_is_bit_identical_to_the_fused_step(ridden):
     if step == 0:
       ob._ensure_state()
       n_stages = ob.build_queue(lambda p: stage[id(p)])
-      assert n_stages == 2 and 0 < ob.queue_limit(0) < ob.queue_limit(1) < ob._queue['host'].n_units
+      assert n_stages == 2 and 0 < ob.queue_limit(1) < ob.queue_limit(2) < ob._queue['host'].n_units
       ob.arm_queue(True)
-    lim = dict(none=0, some=ob.queue_limit(0), all=ob.queue_limit(1))[ridden]
-    if lim:  # rider blocks with no host launch: 3 blocks of 2 x 256 threads take entries [0, lim) two at a time
-      _lib.check(_lib.lib().mmt_adam_rider_probe(ob.queue_ptr(), lim, 3, ops._stream()), 'mmt_adam_rider_probe')
-      assert int(ob._queue['state'][0]) == lim
+    stages = dict(none=0, some=1, all=2)[ridden]
+    if stages:  # rider blocks with no host launch: 3 blocks of 2 x 256 threads claim chunks of the first `stages` stages
+      _lib.check(_lib.lib().mmt_adam_rider_probe(ob.queue_ptr(), stages, 3, ops._stream()), 'mmt_adam_rider_probe')
+      claimed = ob._queue['state'][:2].tolist()  # (a claim counter may overshoot its stage: fetch-add, never retried)
+      assert claimed[0] >= ob.queue_limit(1) and (stages < 2 or claimed[1] >= ob.queue_limit(2) - ob.queue_limit(1))
     ob.step()  # the rest of the queue + the step count
-    assert int(ob._queue['state'][:2 + _lib.RIDER_SLOTS].abs().sum()) == 0
+    st = ob._queue['state']
+    assert int(st[:_lib.RIDER_STAT0].abs().sum()) == 0 and int(st[_lib.RIDER_STAT0 + 64:].abs().sum()) == 0
     assert torch.equal(fa.master, fb.master)
     assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
     assert int(oa.step_dev) == int(ob.step_dev) == step + 1
@@ -307,7 +309,7 @@ def test_adam_queue_with_riders_is_bit_identical_to_the_fused_step(ridden):
       for x, y in zip(fa.shadow(k), fb.shadow(k)):
         assert (x is None and y is None) or torch.equal(x, y), k
   n, taken, steps = ob.queue_stats()
-  assert steps == 3 and taken == 3 * dict(none=0, some=ob.queue_limit(0), all=ob.queue_limit(1))[ridden]
+  assert steps == 3 and taken == 3 * ob.queue_limit(dict(none=0, some=1, all=2)[ridden])
 
 
 def test_graphed_step_with_adam_riders_trains_bit_identically():
