@@ -172,6 +172,10 @@ __device__ __forceinline__ void adam_rider_run(const void* rider, int stages, in
   if (resident <= 0) resident = 256;
   const int last_round = live_total > 0 ? ((live_total - 1) % resident) + 1 : 0;
   const int free_slots = resident - last_round;
+  // cap: bits 0..11 = rider blocks at work (0: MMT_RIDER_CAP), bits 12..15 = passes a block makes (0: until the host's tail
+  // begins; n: exactly n claims, no polling of the host -- a launch of known length cannot then be outlasted by a rider)
+  const int max_pass = (cap >> 12) & 15;
+  cap &= 0xfff;
   if (cap <= 0) cap = MMT_RIDER_CAP;
   if (rank >= (free_slots < cap ? free_slots : cap)) return;  // (no memory access: most tile-less blocks leave here)
   const MmtAdamQueue* __restrict__ qd = (const MmtAdamQueue*)rider;
@@ -184,10 +188,10 @@ __device__ __forceinline__ void adam_rider_run(const void* rider, int stages, in
   const int chain_stages = chain ? qd->chain_stages : 0;
   if (stages > qd->n_stages) stages = qd->n_stages;
   int s_own = 0, s_chain = 0;  // (thread 0's) first stages not known to be exhausted
-  for (;;) {
+  for (int pass = 0; max_pass == 0 || pass < max_pass; ++pass) {
     if (tid == 0) {
       int first = -1, n = 0, which = 0;
-      const int done = live_total > 0
+      const int done = live_total > 0 && max_pass == 0
           ? __hip_atomic_load(qd->state + MMT_RIDER_SLOT0 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       if (live_total <= 0 || done < thresh) {
         if (chain && adam_rider_claim(chain, chain_stages, s_chain, first, n)) which = 1;

@@ -472,7 +472,7 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
       const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
       const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
       slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
-      const int cap = e.rider_cap > 0 ? e.rider_cap : MMT_RIDER_CAP;
+      const int cap = (e.rider_cap & 0xfff) > 0 ? (e.rider_cap & 0xfff) : MMT_RIDER_CAP;
       gx += ((cap < 256 * per_cu ? cap : 256 * per_cu) + splits - 1) / splits;
     }
   }
@@ -639,7 +639,7 @@ static int launch2(const void* A, int64_t lda, const void* B, int64_t ldb, void*
       const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / NT;
       const int per_cu = by_lds < by_threads ? (by_lds < 1 ? 1 : by_lds) : by_threads;
       e2.rider_slot = (e.rider_slot & 0xffff) | ((256 * per_cu) << 16);
-      const int cap = e.rider_cap > 0 ? e.rider_cap : MMT_RIDER_CAP;
+      const int cap = (e.rider_cap & 0xfff) > 0 ? (e.rider_cap & 0xfff) : MMT_RIDER_CAP;
       grid += cap < 256 * per_cu ? cap : 256 * per_cu;
     }
   }

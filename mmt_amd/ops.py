@@ -41,8 +41,9 @@ def dropout_params(p):
 
 
 def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, aux=None, colsum=None,
-            row_index=None, drop_key=0, drop_p=0.0, n_rows_dev=None, tile=0, seed_dev=None):
-  """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue.  a/b bf16 row-major, rows padded to 128."""
+            row_index=None, drop_key=0, drop_p=0.0, n_rows_dev=None, tile=0, seed_dev=None, live_rows=0):
+  """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue.  a/b bf16 row-major, rows padded to 128.  live_rows: the host's
+  count of the rows n_rows_dev will report (tile choice only, MmtEpilogue.live_rows_hint; 0 = unknown)."""
   _need_cuda(a, b, out)
   M = a.shape[0] if m is None else m
   N, K = b.shape
@@ -56,6 +57,7 @@ def gemm_nt(a, b, out, epilogue='BF16', m=None, bias=None, res=None, out2=None, 
   thr, scale = dropout_params(drop_p)
   e.drop_key, e.drop_thr16, e.drop_scale = drop_key, thr, scale
   e.reserved = tile
+  e.live_rows_hint = int(live_rows or 0)
   e.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None
   rc = _lib.lib().mmt_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
                                    EPI[epilogue], ctypes.byref(e), _p(n_rows_dev), _stream())

@@ -605,8 +605,10 @@ class GraphedTrainStep:
       return False
     return all(p.requires_grad for p in m._flat.params)
 
-  def _stage_list(self, e, g):
-    """[(callable, [names of the flat-gradient regions that are final once it has run])], in execution order."""
+  def _stage_list(self, e, g, single_range=False):
+    """[(callable, [names of the flat-gradient regions that are final once it has run])], in execution order.
+    single_range: ONE stage -- loss, text heads, read-out, then the whole encoder as one engine call (one batched
+    LayerNorm / table reduction at its end instead of one per stage) and the video tokens."""
     model, vb = self.model, self.model.vid_bert
     st = {}
 
@@ -646,6 +648,12 @@ class GraphedTrainStep:
         st['run'](n_layers - 1, n_layers - 1)
 
     names = dict(self._grad_regions())
+    if single_range:
+      def whole():
+        head()
+        st['run'](n_layers - 1, 0)
+        model._video_tokens_backward(model._stages['plan'], st['run'].dfeat)
+      return [(whole, list(names) + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
     stages = [(top, (['top'] if 'top' in names else []) + ['flat%d' % (i + 1) for i in range(len(self._extra_flats))])]
     for l in range(n_layers - 2, 0, -1):
       stages.append((lambda l=l: st['run'](l, l), ['layer%d' % l]))
@@ -903,7 +911,10 @@ class GraphedTrainStep:
       o.arm_queue(True)
     # stages of the queue that are final while layer l's backward runs: text heads + the layers above (video side), the
     # layers above (text tower)
-    cap = max(0, min(0xffff, int(os.environ.get('MMT_RIDER_CAP', '0')))) << 16  # (lab: rider blocks at work per launch)
+    # (lab: MMT_RIDER_CAP = rider blocks at work per launch, MMT_RIDER_PASSES = passes a rider block makes, 0 = until the
+    # host launch is in its tail; both travel in the upper half of rider_slot0 -> MmtEpilogue.rider_cap)
+    cap = max(0, min(0xfff, int(os.environ.get('MMT_RIDER_CAP', '0'))))
+    cap = (cap | (max(0, min(15, int(os.environ.get('MMT_RIDER_PASSES', '0')))) << 12)) << 16
     vb.set_rider(opt_v.queue_ptr(), [Lv - l for l in range(Lv)], cap)
     if opt_t is not None:
       tb = m.txt_bert
@@ -925,7 +936,7 @@ class GraphedTrainStep:
     self._regions = self._region_table()
     self._arm_riders()
     try:
-      for fn, _ in self._stage_list(e, g):
+      for fn, _ in self._stage_list(e, g, single_range=True):
         fn()
     finally:
       self._disarm_riders()

@@ -24,9 +24,24 @@ res, z = rnd(R, d, dtype=torch.float32), torch.zeros(R, d, device=dev, dtype=tor
 nrd = torch.tensor([rows], device=dev, dtype=torch.int32)
 big = torch.zeros(768 << 20, device=dev, dtype=torch.uint8)
 
-up = lambda: ops.gemm_nt(x, w1, g, 'BIAS_GELU', m=DENSE, bias=b1, out2=hpre, n_rows_dev=nrd)
-down = lambda tile=0: ops.gemm_nt(g, w2, z, 'BIAS_DROP_RES', m=DENSE, bias=b2, res=res, drop_key=1, drop_p=0.1, n_rows_dev=nrd, tile=tile)
+up = lambda: ops.gemm_nt(x, w1, g, 'BIAS_GELU', m=DENSE, bias=b1, out2=hpre, n_rows_dev=nrd, live_rows=rows)
+down = lambda tile=0: ops.gemm_nt(g, w2, z, 'BIAS_DROP_RES', m=DENSE, bias=b2, res=res, drop_key=1, drop_p=0.1, n_rows_dev=nrd, tile=tile,
+                                  live_rows=rows)
 thrash = lambda: big.fill_(1)
+
+# r06: `--pmc warm|cold|producer`: ONLY that variant of the FFN-down GEMM (the tile the step runs), 30 plain launches, for a
+# rocprofv3 --pmc pass per variant (the L2 hit rate / fabric requests / request latency of the lab next to the step's:
+# profiles/r06_pmc_cache_cold_lab.txt) -- one process per variant, because a profile groups launches by kernel name and grid.
+if '--pmc' in sys.argv:
+  mode = sys.argv[sys.argv.index('--pmc') + 1]
+  for _ in range(30):
+    if mode in ('cold', 'producer'):
+      thrash()
+    if mode == 'producer':
+      up()
+    down()
+  torch.cuda.synchronize()
+  sys.exit(0)
 
 
 def graph_time(fn, iters=10):
