@@ -399,9 +399,10 @@ def main():
                   help='bit mask of the work that leaves the main stream for a parallel branch of the step graph '
                        '(mmt_amd.train_step.FORK_*: 1 weight gradients, 2 ... in two early launches, 4 LN/table reductions, '
                        '16 per-region Adam, 32 text heads, 64 ReduceDim weight gradients); default 0 = one serial chain (forked graphs measured slower, DESIGN section 7)')
-  ap.add_argument('--no-adam-riders', action='store_true',
-                  help='one rank: the optimizer as ONE launch after the backward (r01-r05) instead of riding in the '
-                       'backward\'s GEMM launches (GraphedTrainStep(adam_riders=))')
+  ap.add_argument('--adam-riders', action='store_true',
+                  help='one rank: the optimizer\'s units ride in the backward\'s GEMM launches (GraphedTrainStep(adam_riders=True); '
+                       'measured slower than the one optimizer launch after the backward, DESIGN section 7)')
+  ap.add_argument('--no-adam-riders', action='store_true', help='(the default; kept for the r06 A/B scripts)')
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
@@ -510,7 +511,7 @@ def main():
                               capture_collectives=args.capture_collectives, fork=args.fork, grad_algo=args.grad_algo,
                               input_slots=slots, bind_inputs=bind, shard_optimizer=args.shard_optimizer,
                               host_feed=batches if in_graph_feed else None,
-                              adam_riders=False if args.no_adam_riders else None,
+                              adam_riders=True if args.adam_riders else (False if args.no_adam_riders else None),
                               live_rows=live_hints[0] if pack else None)
     runner.measure_exposed = world > 1 or args.force_collectives
     runner.host_sync_uploads = not args.stream_wait_uploads

@@ -221,6 +221,21 @@ static bool splitk_ffn(const Ws&, int rows, int d, int K) {
   return splitk_ffn_mode() > 0 && rows >= 2048 && K >= 2048 && d <= 512;
 }
 
+// r06: the short-batch case of gemm_hidden (the text tower: a few hundred live rows, K = intermediate) already runs split-K;
+// its slab-summing epilogue launch and the LayerNorm launch behind it are ONE launch when the LayerNorm reads the slabs
+// itself (mmt_splitk_ln_fwd_ex / mmt_ln_bwd_slabs_ex: + bias, dropout, residual resp. + residual gradient) -- two graph
+// nodes less per layer, forward and backward.  -> splits (0: not this case).  MMT_SPLITK_LN=0 restores the r05 launches.
+static int small_splitk_ln(const Ws& w, int rows, int d, int K) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MMT_SPLITK_LN");
+    on = e ? atoi(e) : 1;
+  }
+  const int tiles = ((rows + 127) / 128) * (d / 64), ksteps = K / 64;
+  if (!on || !(tiles < 160 && ksteps >= 32 && rows <= 4 * w.t.cap)) return 0;
+  return ksteps >= 48 ? 4 : 2;
+}
+
 // r05: BertSelfOutput's projection + LayerNorm as one launch where the hidden size is the 512 of the video BERT (a block of
 // gemm_ln.hip owns 32 whole rows of 512 columns).  OPT-IN (MMT_FUSE_OUT_LN=1): it removes three graph nodes and three reads
 // of z per step, but every block streams the whole 512 KiB weight through its CU's ~21 B/clk ingest -- same-box A/B of the
@@ -327,17 +342,19 @@ extern "C" int mmt_bert_forward(const MmtBertModel* m, const MmtBertBatch* b, vo
     e.bias = P.b2; e.res = L.a32; e.ldres = d; e.row_index = b->row_index; e.seed_dev = b->seed_dev;
     e.drop_key = site_key(l, SITE_FFN_OUT); e.drop_thr16 = th; e.drop_scale = sh;
     float* hout32 = (l == m->layers - 1) ? out_last : L.h32;
-    if (splitk_ffn(w, rows, d, I)) {
-      const int mode = splitk_ffn_mode();
+    const int small_sp = small_splitk_ln(w, rows, d, I);
+    if (splitk_ffn(w, rows, d, I) || small_sp) {
+      const int mode = small_sp ? 10 * small_sp : splitk_ffn_mode();
+      float* slabs = small_sp ? w.t.slabs : w.kslab;
       int sp = 0;
       int64_t sstride = 0;
       TRY(mmt_gemm_splitk_geometry(rows, d, I, mode / 10, &sp, &sstride));
       {
         ProbeScope probe(1, l == 0, stream);
-        TRY(mmt_gemm_nt_splitk_ex(L.g, I, P.w2, I, nullptr, d, rows, d, I, MMT_EPI_F32, nullptr, w.kslab, mode / 10, mode % 10,
+        TRY(mmt_gemm_nt_splitk_ex(L.g, I, P.w2, I, nullptr, d, rows, d, I, MMT_EPI_F32, nullptr, slabs, mode / 10, mode % 10,
                                   b->n_rows_dev, 1, stream));
       }
-      TRY(mmt_splitk_ln_fwd_ex(w.kslab, sp, sstride, P.b2, L.a32, nullptr, nullptr, b->row_index, nullptr,
+      TRY(mmt_splitk_ln_fwd_ex(slabs, sp, sstride, P.b2, L.a32, nullptr, nullptr, b->row_index, nullptr,
                                site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, L.z2, P.ln2_g, P.ln2_b, m->ln_eps, hout32, L.h16,
                                L.mean2, L.rstd2, rows, d, b->n_rows_dev, stream));
       hin32 = hout32;
@@ -421,6 +438,9 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
   // gradient wrt the current layer's output: ping-pongs between the caller's buffer and dA, starting at the top layer
   // (the buffer that holds the gradient wrt layer l's OUTPUT depends on l alone; "layer -1" = the embedding stage)
   float* dcur = ((m->layers - 1 - l_hi) & 1) ? w.dA : dlast;
+  const float* dc_slabs = nullptr;  // != null: the gradient wrt the current layer's output is sum(slabs) + w.dz, not *dcur
+  int dc_sp = 0;
+  int64_t dc_stride = 0;
   for (int l = l_hi; l >= l_lo && !embed_only; --l) {
     const MmtBertLayer& P = m->layer[l];
     LayerWs& L = w.layer[l];
@@ -511,8 +531,14 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     gatt.item[1].A = dy;    gatt.item[1].lda = d;     gatt.item[1].B = L.ctx; gatt.item[1].ldb = d; gatt.item[1].N = d;     gatt.item[1].K2 = d;
     gatt.item[1].out = P.g_wo;   gatt.item[1].bias_out = P.g_bo;
     // --- BertOutput: LN2 <- dropout <- dense(I->d) ---
+    if (dc_slabs) {  // the layer above left its input gradient as split-K slabs + the residual gradient in w.dz (see below)
+      TRY(mmt_ln_bwd_slabs_ex(dc_slabs, dc_sp, dc_stride, w.dz, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, dy2, w.ln_partials[2 * l + 2],
+                              rows, d, 1, nr, b->row_index, site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
+      dc_slabs = nullptr;
+    } else {
     TRY(mmt_ln_bwd(dcur, L.z2, L.mean2, L.rstd2, P.ln2_g, w.dz, dy2, w.ln_partials[2 * l + 2], rows, d, 1, nr, b->row_index,
                    site_key(l, SITE_FFN_OUT), th, sh, b->seed_dev, stream));
+    }
     add_job(w.ln_partials[2 * l + 2], ln_blocks, 3, 2, d, P.g_ln2_g, P.g_ln2_b);
     MmtEpilogue e = {}; e.live_rows_hint = lh;
     e.aux = L.hpre; e.ldaux = I;
@@ -523,15 +549,19 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
       TRY(mmt_wgrad_grouped(&gffn, side));
     }
     // --- BertIntermediate: dense(d->I) ---
-    if (splitk_ffn(w, rows, d, I)) {
-      const int mode = splitk_ffn_mode();
+    const int small_sp = small_splitk_ln(w, rows, d, I);
+    if (splitk_ffn(w, rows, d, I) || small_sp) {
+      const int mode = small_sp ? 10 * small_sp : splitk_ffn_mode();
+      float* slabs = small_sp ? w.t.slabs : w.kslab;
       int sp = 0;
       int64_t sstride = 0;
       TRY(mmt_gemm_splitk_geometry(rows, d, I, mode / 10, &sp, &sstride));
-      TRY(mmt_gemm_nt_splitk_ex(dhpre, I, P.w1_t, I, nullptr, d, rows, d, I, MMT_EPI_F32, nullptr, w.kslab, mode / 10, mode % 10,
+      MmtEpilogue er = {}; er.live_rows_hint = lh;
+      ride(er, l);
+      TRY(mmt_gemm_nt_splitk_ex(dhpre, I, P.w1_t, I, nullptr, d, rows, d, I, MMT_EPI_F32, &er, slabs, mode / 10, mode % 10,
                                 nr, 1, stream));
       // w.dz is read (residual gradient) and rewritten (LN1 input gradient) by the same lanes at the same elements
-      TRY(mmt_ln_bwd_slabs_ex(w.kslab, sp, sstride, w.dz, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1],
+      TRY(mmt_ln_bwd_slabs_ex(slabs, sp, sstride, w.dz, L.z1, L.mean1, L.rstd1, P.ln1_g, w.dz, dy, w.ln_partials[2 * l + 1],
                               rows, d, 1, nr, b->row_index, site_key(l, SITE_ATTN_OUT), th, sh, b->seed_dev, stream));
     } else {
     e = {}; e.live_rows_hint = lh;
@@ -573,6 +603,16 @@ extern "C" int mmt_bert_backward_range(const MmtBertModel* m, const MmtBertBatch
     float* dnext = (dcur == dlast) ? w.dA : dlast;  // ping-pong between the caller's buffer and dA
     // dA was consumed by the LN1 backward above, so it is free again here.
     ride(e, l);
+    // r06, short batches: the split-K slabs of dX = dQKV . Wqkv are summed (+ the residual gradient w.dz) by the LayerNorm
+    // backward of the layer below instead of by a slab-reducing epilogue launch -- when that layer runs in this call and
+    // nothing is forked (the weight gradients below read dqkv, not the slabs; w.dz is not written in between)
+    const int qkv_sp = (l > l_lo && !fork_w) ? small_splitk_ln(w, rows, d, 3 * d) : 0;
+    if (qkv_sp) {
+      TRY(mmt_gemm_splitk_geometry(rows, d, 3 * d, qkv_sp, &dc_sp, &dc_stride));
+      TRY(mmt_gemm_nt_splitk_ex(dqkv, 3 * d, P.wqkv_t, 3 * d, nullptr, d, rows, d, 3 * d, MMT_EPI_F32, &e, w.t.slabs, qkv_sp, 0, nr, 1,
+                                stream));
+      dc_slabs = w.t.slabs;
+    } else
     TRY(gemm_hidden(w, rows, d, dqkv, 3 * d, P.wqkv_t, 3 * d, dnext, d, 3 * d, MMT_EPI_ADD_F32, &e, nr, stream));
     // --- all four weight gradients + bias gradients of the layer: ONE grouped launch (256 tiles at d=512, I=3072) ---
     if (!fork_w) {

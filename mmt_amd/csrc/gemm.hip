@@ -822,13 +822,17 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
   // rows, and the launch has at least 3/4 of a tile per CU over thousands of rows (configs[4]: d = 1024, 256 tiles).
   // MMT_WGRAD3=0 switches it off (same-box A/B).
   {
-    static int w3 = -1;
+    static int w3 = -1, w3_rows = 2048, w3_tiles = 192;
     if (w3 < 0) {
       const char* e = getenv("MMT_WGRAD3");
       w3 = e ? atoi(e) : 1;
+      const char* r = getenv("MMT_WGRAD3_ROWS");   // (lab: the thresholds of this choice)
+      const char* t = getenv("MMT_WGRAD3_TILES");
+      if (r) w3_rows = atoi(r);
+      if (t) w3_tiles = atoi(t);
     }
     int t3 = 0;
-    bool ok = w3 != 0 && h.rows >= 2048;
+    bool ok = w3 != 0 && h.rows >= w3_rows;
     for (int q = 0; q < h.count && ok; ++q) {
       const MmtWgradItem& it = h.item[q];
       ok = it.A && it.B && it.out && it.N > 0 && it.K2 > 0 && it.N % 256 == 0 && it.K2 % 256 == 0 && it.splits <= 1 &&
@@ -836,7 +840,7 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
            it.lda >= 256 && it.ldb >= 256;
       t3 += (it.N / 256) * (it.K2 / 256);
     }
-    if (ok && t3 >= 192) {
+    if (ok && t3 >= w3_tiles) {
       int tb = 0;
       for (int q = 0; q < h.count; ++q) {
         MmtWgradItem& it = h.item[q];

@@ -202,11 +202,13 @@ class GraphedTrainStep:
     carry the count themselves): the GEMM dispatcher picks its tiles for a launch's LIVE size (include/mmt_hip.h:
     MmtBertBatch.live_rows_hint) at capture time.  `step(slot, live_rows=n)` re-captures (once per distinct tile choice, kept)
     when a minibatch's count would select other tiles; without any count a packed batch is priced at its allocated rows.
-    adam_riders (one rank only; None = on unless MMT_ADAM_RIDERS=0): the optimizer leaves the critical path -- the step's
-    Adam update is a queue of 4096-element units ordered by when their gradients are final, the GEMM launches of the
-    backward carry it (blocks without a tile of their own -- idle CUs, the last partial round -- stream Adam's bytes under
-    the MFMA-bound tiles) and the optimizer launch at the end only runs what is left.  Bit-identical to the serial
-    fused step (tests/test_optim_gpu.py); needs the stage-by-stage backward (native text heads and losses).
+    adam_riders (one rank only; None = OFF unless MMT_ADAM_RIDERS=1): the optimizer inside the backward -- the step's Adam
+    update is a queue of 4096-element units ordered by when their gradients are final, the GEMM launches of the
+    backward carry it (blocks without a tile of their own -- idle CUs, the last partial round -- stream Adam's bytes beside
+    the tiles) and the optimizer launch at the end only runs what is left.  Bit-identical to the serial fused step
+    (tests/test_optim_gpu.py); needs the stage-by-stage backward (native text heads and losses).  MEASURED SLOWER on
+    MI355X in every configuration (r06, DESIGN section 7: the hosting GEMMs are bound by memory latency, every unit a rider
+    streams costs 2-3x what it costs in the optimizer's own launch -- headline 1.31-1.58 ms against 1.28 ms), hence opt-in.
     Reference: train.py:100, trainer/trainer.py:203-204.
     The warm-up steps only allocate buffers and optimizer state: weights, Adam moments and step count, BatchNorm
     statistics and the dropout seed are restored afterwards, so the first `step()` IS the first optimisation step."""
@@ -217,7 +219,7 @@ class GraphedTrainStep:
     self._side = None
     self._fork_on = False  # decided after the first warm-up step (needs the model's stage handles)
     if adam_riders is None:
-      adam_riders = os.environ.get('MMT_ADAM_RIDERS', '1') != '0'
+      adam_riders = os.environ.get('MMT_ADAM_RIDERS', '0') == '1'
     self._want_riders = bool(adam_riders)
     self._rider_on = False  # decided after the first warm-up step as well
     self._keep = []
