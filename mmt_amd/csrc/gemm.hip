@@ -926,6 +926,7 @@ int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const
 // to tests (tests/test_host_cpu.py asserts the tile of every shipped (shape, live rows) class).
 struct TilePolicy {
   int big = 1;      // MMT_TILE_BIG   : 256x256 eight-phase kernel (gemm3.hip, tile 21) where it fills the chip
+  int big_kmin = 1024;  // MMT_TILE_BIG_KMIN: ... from this K on (with >= 220 such tiles; K >= 3072: >= 160)
   int narrow = 18;  // MMT_TILE_NARROW: tile of the packed N < 1024 GEMMs (18 = phased 128x64 while one round covers them; 13)
   int wide = 0;     // MMT_TILE_WIDE  : lab, tile for N >= 1024
   int longk = 0;    // MMT_TILE_LONGK : lab (23 = gemm4.hip), packed narrow GEMMs with K >= 1536
@@ -941,6 +942,7 @@ static const TilePolicy& tile_policy() {
     TilePolicy p;
     auto geti = [](const char* name, int def) { const char* v = getenv(name); return v ? atoi(v) : def; };
     p.big = geti("MMT_TILE_BIG", p.big);
+    p.big_kmin = geti("MMT_TILE_BIG_KMIN", p.big_kmin);
     p.narrow = geti("MMT_TILE_NARROW", p.narrow);
     p.wide = geti("MMT_TILE_WIDE", p.wide);
     p.ppn = geti("MMT_TILE_PPN", p.ppn);
@@ -1007,7 +1009,7 @@ static int select_tile(int EPI, int M, int N, int K, bool packed, int live_hint,
   const long rt128 = (live + 127) / 128;  // live row tiles of 128
   if (pol.big && reserved == 0 && N % 256 == 0 && M > 1024) {
     const long t21 = (long)((live + 255) / 256) * (N / 256);
-    if ((t21 >= 220 && K >= 1024) || (t21 >= 160 && K >= 48 * 64)) return 21;
+    if ((t21 >= 220 && K >= pol.big_kmin) || (t21 >= 160 && K >= 48 * 64 && K >= pol.big_kmin)) return 21;
   }
   if (reserved == 0 && M > 1024 && !dgelu_sums) {
     const bool one_round = rt128 * (N / 64) <= 256;
