@@ -403,6 +403,8 @@ def main():
                   help='one rank: the optimizer\'s units ride in the backward\'s GEMM launches (GraphedTrainStep(adam_riders=True); '
                        'measured slower than the one optimizer launch after the backward, DESIGN section 7)')
   ap.add_argument('--no-adam-riders', action='store_true', help='(the default; kept for the r06 A/B scripts)')
+  ap.add_argument('--tower-base-ms', type=float, default=0.0,
+                  help='with --text-tower native: ms/step of the SAME box\'s step with the synthetic tower, for the tower-only roofline')
   ap.add_argument('--comm-log', action='store_true',
                   help='N > 1: NCCL_DEBUG=INFO (RCCL prints the rings/trees and the algorithm + protocol of every collective)')
   args = ap.parse_args()
@@ -519,8 +521,10 @@ def main():
     slots_used = slots
     in_graph_feed_used = in_graph_feed
     it, first = 0, None
+    slot_batch = {}  # input slot -> index of the minibatch it holds
     if in_graph_feed:
       runner.prime(0)
+      slot_batch.update({i: i % NBATCH for i in range(slots)})  # (slots == NBATCH: slot s always receives batches[s])
 
       def feed():  # nothing to do per step: step(slot) uploads slot + 1 from its pinned buffer inside its own graph
         nonlocal it
@@ -534,11 +538,14 @@ def main():
         cur = it % slots
         it += 1
         runner.upload(batches[it % NBATCH], it % slots)
+        slot_batch[it % slots] = it % NBATCH
         return cur
       runner.upload(batches[0], 0)
+      slot_batch[0] = 0
     elif slots > 1:
       for i in range(slots):  # the resident minibatches ARE the slots' inputs
         runner.load(batches[i % NBATCH], i)
+        slot_batch[i] = i % NBATCH
 
       def feed():
         nonlocal it
@@ -550,6 +557,7 @@ def main():
       def feed():
         nonlocal it
         runner.load_prefetched()
+        slot_batch[0] = it % NBATCH
         it += 1
         runner.prefetch(batches[it % NBATCH])
         return 0
@@ -557,15 +565,14 @@ def main():
     else:
       def feed():
         nonlocal it
-        runner.load(batches[it % NBATCH]); it += 1
+        runner.load(batches[it % NBATCH])
+        slot_batch[0] = it % NBATCH
+        it += 1
         return 0
-    # the minibatch in slot s is batches[s % NBATCH] in the resident arrangement; the other arrangements rotate through all
-    # of them, whose counts select the same tiles (checked here: a loader would pass each minibatch's own count)
-    sigs = {runner._tile_signature(h) for h in live_hints} if pack else {None}
-    assert len(sigs) == 1, 'the synthetic minibatches fall into different tile-policy buckets: %r' % (sigs,)
-
+    # every step passes the count of the minibatch it consumes, as a loader would: minibatches whose counts select other GEMM
+    # tiles replay another capture of the step (GraphedTrainStep keeps one set of captures per tile choice)
     def hint(slot):
-      return live_hints[slot % NBATCH] if (pack and slots > 1 and not args.host_inputs) else (live_hints[0] if pack else None)
+      return live_hints[slot_batch.get(slot, 0)] if pack else None
     for _ in range(warmup):
       s_ = feed()
       l = runner.step(s_, live_rows=hint(s_))
@@ -613,6 +620,8 @@ def main():
   torch.cuda.synchronize()
   site_times = {st: pr.finish(stride=towers, offset=towers - 1) for st, pr in probes.items()}
   staged = runner.staged
+  # (parameters, parameters with bf16 shadows) of every flat buffer: the HBM accounting of --text-tower native
+  tower_flat_sizes = [(int(o.flat.count), int(sum(sh['rows'] * sh['cols'] for sh in o.flat.shadows))) for o in runner.opt_flats]
   # share of the optimizer's units of work that rode in the backward's GEMM launches (the rest ran in the optimizer launch)
   riders = None
   if runner._rider_on:
@@ -698,6 +707,30 @@ def main():
       att = [r for r in tops if 'self-attention' in r['kernel']]
       if att:  # both attention launches of the full layers together, as a share of the step
         out['attention_share_of_step'] = sum(r['share_of_step'] for r in att)
+    if args.text_tower == 'native':
+      # The text tower at ~560 live caption tokens is a WEIGHT-STREAMING problem (its FLOPs, ~0.4 TF per step, are noise): the
+      # step is priced against the HBM roof.  Algorithmic bytes per step = what must cross HBM once: every bf16 GEMM weight read by
+      # the forward and its transposed copy by the input-gradient GEMMs, the fp32 gradient of every parameter written once, and
+      # the Adam pass (g, w, m, v read; w, m, v + both bf16 shadows written) -- for BOTH flat buffers (video side + tower);
+      # activations are negligible beside them.  `tower_only`: the same for the tower's buffer alone against the time the
+      # tower adds to the step (this invocation's step minus the synthetic-tower step of the same box, when --tower-base-ms
+      # gives it).
+      def flat_bytes(n_params, n_shadowed):
+        return dict(weights_bf16_fwd=2 * n_shadowed, weights_bf16_dgrad=2 * n_shadowed, grad_write_f32=4 * n_params,
+                    adam_read=16 * n_params, adam_write=12 * n_params + 4 * n_shadowed)
+      parts = []
+      for nf in tower_flat_sizes:
+        parts.append(flat_bytes(*nf))
+      total = sum(sum(p.values()) for p in parts)
+      sec = elapsed / args.steps
+      out['roofline_hbm_step'] = dict(bound='hbm', unit='GB/s', peak=8000.0, achieved=total / sec / 1e9, frac=total / sec / 8e12,
+                                      algorithmic_bytes_per_step=total, per_flat_buffer=parts,
+                                      note='whole step (video side + native text tower); the tower alone: see tower_only')
+      if args.tower_base_ms:
+        tsec = sec - args.tower_base_ms * 1e-3
+        tb = sum(parts[-1].values())
+        out['roofline_hbm_step']['tower_only'] = dict(added_ms=tsec * 1e3, algorithmic_bytes=tb, achieved=tb / tsec / 1e9,
+                                                      frac=tb / tsec / 8e12, hbm_floor_ms=tb / 6.3e12 * 1e3)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
     if args.config == 4:

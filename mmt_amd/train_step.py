@@ -326,6 +326,7 @@ class GraphedTrainStep:
 
   def _capture_slots(self):
     """The captured step for every input slot, under the model's current live-row hint (= tile choice)."""
+    self._n_capture_sets = getattr(self, '_n_capture_sets', 0) + 1
     if len(self._statics) > 1:
       self._caps = []
       for si, st in enumerate(self._statics):

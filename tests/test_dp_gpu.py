@@ -539,3 +539,47 @@ def test_sharded_sim_loss_over_rccl_matches_gloo_run(tmp_path):
     assert abs(x['loss'] - y['loss']) < 1e-6
     for k in ('dvid', 'dtxt', 'dtw'):
       assert (x[k] - y[k]).abs().max() <= 1e-6 * max(1.0, x[k].abs().max().item()), k
+
+
+def test_step_recaptures_when_the_live_row_count_selects_other_tiles():
+  """GraphedTrainStep.step(slot, live_rows=n): the loader's count of packed token rows picks the GEMM tiles at capture time
+  (MmtBertBatch.live_rows_hint).  A minibatch whose count selects OTHER tiles (config B: 0.5 -> 0.9 of the token grid filled
+  moves the N = 512 GEMMs off the one-round phased tile and the wide ones onto the persistent kernel) replays its own
+  capture, made once and kept; going back costs nothing; and the training trajectory is the one of a runner that never
+  hears a count (every batch priced at its allocated rows) up to the summation order of the tiles."""
+  import bench
+  from mmt_amd import synthetic
+  from mmt_amd.loss import MaxMarginRankingLoss
+  from mmt_amd.model import CENet
+  from mmt_amd.train_step import FlatMinibatch, GraphedTrainStep
+  dev = torch.device('cuda', 0)
+  bench.select_config(1)
+  mbs, hints = [], []
+  for i, fill in enumerate((0.5, 0.92)):
+    mb, text = synthetic.make_batch(500 + i, bench.BATCH, synthetic.MSRVTT_MODALITIES, bench.TOKENS, max_pos=bench.MAX_POS, fill=fill)
+    mb['text'] = text.view(-1, 768)
+    hints.append(CENet.count_live_rows(mb['features_ind']))
+    mbs.append(FlatMinibatch(mb, dev))
+
+  def make(live):
+    torch.manual_seed(0)
+    model = bench.build_model(pack=True).to(dev).train()
+    static = FlatMinibatch(mbs[0], dev)
+    model.txt_bert.text = static['text']
+    return model, GraphedTrainStep(model, MaxMarginRankingLoss(0.05, True), static, lr=5e-5, warmup_steps=1, live_rows=live)
+
+  ma, ra = make(hints[0])
+  mb_, rb = make(None)
+  sig0 = ra._sig
+  assert sig0 is not None and rb._sig is None and ra._tile_signature(hints[1]) != sig0
+  losses = []
+  for step, which in enumerate((0, 1, 1, 0, 1)):
+    ra.load(mbs[which]); rb.load(mbs[which])
+    la, lb = ra.step(0, live_rows=hints[which]), rb.step(0)
+    assert (ra._sig == sig0) == (which == 0)
+    losses.append((float(la), float(lb)))
+  assert len(ra._by_sig) == 2 and ra._n_capture_sets == 2  # two tile choices met: two sets of captures, none made twice
+  for la, lb in losses:
+    assert la == la and abs(la - lb) <= 2e-3 * abs(lb), losses
+  rel = (ma._flat.master - mb_._flat.master).norm() / mb_._flat.master.norm()
+  assert rel < 1e-5, rel.item()
