@@ -116,9 +116,9 @@ class KernelProbe:
 
 # rocprofv3 evidence the JSON line quotes (tools/final_profiles.sh writes them): one set of PMC passes per shape -- the
 # unpacked ('dense') timing of configs[1] has its own --, and the by-grid kernel-trace summary of the replayed graph
-PMC_CSVS = {1: 'r05_pmc_kernels.csv', 3: 'r05_pmc_config3.csv', 4: 'r05_pmc_config4.csv', 'dense': 'r05_pmc_dense.csv'}
-STATS_CSVS = {1: 'r05_kernel_stats_packed_by_grid.csv', 3: 'r05_kernel_stats_config3_by_grid.csv',
-              4: 'r05_kernel_stats_config4_by_grid.csv', 'dense': 'r05_kernel_stats_dense_by_grid.csv'}
+PMC_CSVS = {1: 'r06_pmc_kernels.csv', 3: 'r06_pmc_config3.csv', 4: 'r06_pmc_config4.csv', 'dense': 'r06_pmc_dense.csv'}
+STATS_CSVS = {1: 'r06_kernel_stats_packed_by_grid.csv', 3: 'r06_kernel_stats_config3_by_grid.csv',
+              4: 'r06_kernel_stats_config4_by_grid.csv', 'dense': 'r06_kernel_stats_dense_by_grid.csv'}
 PMC_CSV = os.path.join('profiles', PMC_CSVS[1])
 STATS_CSV = os.path.join('profiles', STATS_CSVS[1])
 
@@ -484,6 +484,7 @@ def main():
   live_hints = [None] * NBATCH
   if not args.ragged_inputs:
     live_hints = [CENet.count_live_rows(b['features_ind']) for b in batches]
+  text_hint = CENet.count_live_tokens(batches[0]['token_ids']) if args.text_tower == 'native' else None
   slots_used = 1
   in_graph_feed_used = False
 
@@ -492,6 +493,7 @@ def main():
     (barrier + synchronize on both sides, MAX over ranks).  -> dict(model, runner, elapsed, first_loss, final_loss)"""
     torch.manual_seed(0)
     model = build_model(pack=pack, text_tower=args.text_tower).to(dev).train()
+    model.text_live_rows_hint = text_hint  # (caption tokens of a minibatch, as a loader counts them: tile choice of the tower's GEMMs)
     mdist.broadcast_parameters(model)
     static = FlatMinibatch(batches[0], dev)
 

@@ -316,6 +316,7 @@ class CENet(nn.Module):
     # packed token rows of the NEXT minibatch as the loader counted them (None = unknown): lets the GEMM dispatcher price
     # a packed launch at its live size (include/mmt_hip.h: MmtBertBatch.live_rows_hint); `count_live_rows` computes it
     self.live_rows_hint = None
+    self.text_live_rows_hint = None  # the same for the native text tower: real caption tokens (`count_live_tokens`)
     self.overlap_text_heads = False  # measured: no gain on MI355X (1.76 vs 1.74 ms/step), kept as an option
     self._side_streams = {}
     # the reference indexes nn.Embedding tables with these and raises IndexError when they do not fit; the kernels would
@@ -475,6 +476,12 @@ class CENet(nn.Module):
     for ind in features_ind.values():
       total += int(ind.shape[0]) + int((torch.as_tensor(ind) != 0).sum())
     return total
+
+  @staticmethod
+  def count_live_tokens(token_ids):
+    """Real caption tokens of a minibatch from its HOST-side `token_ids` (B, C, W, 2) = [id, valid] (model/model.py:353-357
+    reads the same two planes): what the loader assigns to `text_live_rows_hint`."""
+    return int((torch.as_tensor(token_ids)[..., 1] != 0).sum())
 
   def engine_params(self):
     """Parameters living in the flat buffer (video side), in layout order."""
@@ -801,6 +808,11 @@ class CENet(nn.Module):
       out = self.txt_bert(None)
       return out[0][:, 0] if self.post_agg == 'cls' else (torch.max(out[0][:, 1:], 1)[0] if self.post_agg == 'mxp'
                                                           else torch.mean(out[0][:, 1:], 1))
+    if self._native_text_tower:  # (the loader's token count, or -- token_ids still on the host -- counted here)
+      hint = self.text_live_rows_hint
+      if hint is None and not token_ids.is_cuda:
+        hint = self.count_live_tokens(token_ids)
+      self.txt_bert.live_rows_hint = hint
     tok = token_ids.view(b * c, w, f).to(device)
     input_ids = tok[:, :, 0].long()
     attention_mask = tok[:, :, 1].long()

@@ -86,6 +86,9 @@ class TextBertModel(BertModel):
       emb.weight.data[cfg.pad_token_id].zero_()
     self.embeddings.word_embeddings = emb
     self.cls_only = False
+    # real (un-padded) caption tokens of the NEXT minibatch as the loader counted them (None = unknown): the GEMM dispatcher
+    # prices the packed launches at their live size (MmtBertBatch.live_rows_hint; CENet.text_live_rows_hint forwards it)
+    self.live_rows_hint = None
     self.pack_tokens = True      # with cls_only: drop the padded tokens (exact, see mmt_text_plan)
     self.compute_pooler = False  # model/model.py:376 reads output[0] only
     self._plans = {}
@@ -167,6 +170,7 @@ class TextBertModel(BertModel):
       feats = _WordEmbeddingFn.apply(self, p.packed[0], rows, table, p.n_rows)
       batch = EngineBatch(None, p.packed[1], p.packed[2], p.zero_bias, rows, bsz, seq, cu_seqlens=p.cu,
                           row_index=p.packed[3], n_rows_dev=p.n_rows, out_rows=p.packed_cls, n_out_per_sample=1)
+      batch.live_rows_hint = int(self.live_rows_hint or 0)
     else:
       p.ids[:rows].copy_(input_ids.reshape(-1))
       if token_type_ids is None:
