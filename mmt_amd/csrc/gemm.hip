@@ -914,7 +914,6 @@ static int launch_nt(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 
 int mmt_gemm2_dispatch(int tile, int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        int64_t ldc, int M, int N, int K, const MmtEpilogue& e, const int32_t* nr, hipStream_t s);
-bool mmt_deep_ring_enabled();  // gemm2.hip (MMT_DEEP_RING)
 
 // ---- tile policy ---------------------------------------------------------------------------------------------------
 // Which kernel runs a GEMM is a pure function of its shape, its epilogue and the number of LIVE rows (token packing: the
@@ -1031,15 +1030,12 @@ static int select_tile(int EPI, int M, int N, int K, bool packed, int live_hint,
     const int t = wide192_tile(pol, live, N);
     if (t) return t;
   }
-  // short batches and few-row problems: the 8-wave 128x64 tile -- with the six-deep ring (tile 26, one block per CU) while the
-  // live tiles fit one round of the chip (r06: these launches are latency-bound), else three-deep at two blocks per CU (13)
-  const int small = (mmt_deep_ring_enabled() && rt128 * (N / 64) <= 256) ? 26 : 13;
-  if (reserved == 0 && M <= 1024 && !dgelu_sums) return small;
+  if (reserved == 0 && M <= 1024 && !dgelu_sums) return 13;
   if (reserved == 0 && M >= 512) {
     if (N >= 1024 && N % 128 == 0 && !dgelu_sums) return 14;
     if (packed && N % 64 == 0) return 13;
   }
-  if (reserved == 0 && M < 512 && N >= 1024 && !dgelu_sums) return small;  // few rows (the compact last layer): shortest block latency
+  if (reserved == 0 && M < 512 && N >= 1024 && !dgelu_sums) return 13;  // few rows (the compact last layer): shortest block latency
   if (EPI == MMT_EPI_BF16 && dot_out) return 13;  // the row-dot sums live in gemm2's LDS-staged epilogue only
   return (N % 128 == 0 && reserved == 1) ? 1 : 2;
 }

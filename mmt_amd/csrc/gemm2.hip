@@ -223,9 +223,10 @@ __device__ __forceinline__ void gemm2_body(
       }
     } else {
     const int ahead = min(KT - kt - 1, NS - 2);  // stages issued after kt that may stay in flight
-    if (NS >= 6 && ahead >= 4) wait_vmcnt<4 * L>();
-    else if (NS >= 5 && ahead >= 3) wait_vmcnt<3 * L>();
-    else if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    // (r06: a six-deep ring -- five stages in flight, 144 KiB -- for the launches that do not fill the chip, the text tower's
+    // and the compact last layer's, measured neutral: tower step 4.098 / 4.105 vs 4.109 / 4.104 ms, headline + 2 us; their
+    // K-step is the issue cost of the LDS-DMA instructions + the barrier, not a prefetch distance.  Removed again.)
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     TICK(t_wait);
@@ -483,22 +484,6 @@ static int launch_splitk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t 
   return 0;
 }
 
-// r06: the six-deep ring (144 KiB: one block per CU) for split-K launches whose LIVE blocks fit one round of the chip -- these
-// launches are latency-bound (see tile 26).  MMT_DEEP_RING=0 switches it (and tile 26) off.
-bool mmt_deep_ring_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("MMT_DEEP_RING");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
-}
-static bool splitk_deep_ring(int M, int N, int splits, bool packed, int live_hint) {
-  if (!mmt_deep_ring_enabled()) return false;
-  const int live = packed && live_hint > 0 && live_hint < M ? live_hint : M;
-  return (long)((live + 127) / 128) * (N / 64) * splits <= 256;
-}
-
 // epilogue: MMT_EPI_BF16 / F32 / BIAS_F32 / ADD_F32 / BIAS_DROP_RES.  ws: mmt_gemm_nt_splitk_workspace_floats() floats
 // (slab s = ws + s * round_up(M,128) * N, leading dimension N).
 // splits <= 0: as many as there are K-steps, at most 16 (skinny problems).  wide: 128x128 tiles (N % 128 == 0) instead of
@@ -532,8 +517,6 @@ static int splitk_impl(const void* A, int64_t lda, const void* B, int64_t ldb, v
   else if (wide == 2)  // 256x128 tiles: half the L2 -> LDS bytes per MAC of the 128x128 tile (the N = 512 GEMMs re-read
                        // their operands from L2 ~10x; at ~15 TB/s aggregate that traffic is what bounds them)
     rc = launch_splitk<256, 128, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
-  else if (!wide && splitk_deep_ring(M, N, splits, n_rows_dev != nullptr, e.live_rows_hint))
-    rc = launch_splitk<128, 64, 4, 2, 6>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
   else
     rc = wide ? launch_splitk<128, 128, 2, 4, 2>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s)
               : launch_splitk<128, 64, 4, 2, 3>(a, lda, b, ldb, ws, slab, M, Mpad, N, K, splits, per, n_rows_dev, e, s);
@@ -680,10 +663,6 @@ static int pick2(int tile, const void* A, int64_t lda, const void* B, int64_t ld
   switch (tile & 0xff) {
     case 13: if (N % 64 == 0) G2(128, 64, 4, 2, 3); break;    // 8 waves on 128x64 (wave 32x32), staggered, 2 blocks/CU
     case 14: if (N % 128 == 0) G2(128, 128, 2, 4, 2); break;  // 8 waves on 128x128, in phase, 2 blocks/CU
-    // r06: tile 13 with a SIX-deep ring (144 KiB, one block per CU) for launches that do not fill the chip (short batches: the
-    // text tower, the compact last layer): their K-step is not bandwidth- but LATENCY-bound (~0.5 us = the fabric round trip
-    // divided by the two stages a three-deep ring keeps in flight), so five stages in flight shorten the K-loop
-    case 26: if (N % 64 == 0) G2(128, 64, 4, 2, 6); break;
     case 18:  // 2 x 4 waves on 128x64, PHASED: the groups take alternate K-steps (wave tile 64x32), 1-2 blocks/CU
       if (N % 64 == 0) return launch2<128, 64, 2, 2, 4, EPI, false, true>(A, lda, B, ldb, C, ldc, M, N, K, e, nr, s);
       break;

