@@ -201,7 +201,9 @@ class GraphedTrainStep:
     live_rows: packed token rows of the minibatches as the loader counts them (`CENet.count_live_rows`; RaggedFeatures
     carry the count themselves): the GEMM dispatcher picks its tiles for a launch's LIVE size (include/mmt_hip.h:
     MmtBertBatch.live_rows_hint) at capture time.  `step(slot, live_rows=n)` re-captures (once per distinct tile choice, kept)
-    when a minibatch's count would select other tiles; without any count a packed batch is priced at its allocated rows.
+    when a minibatch's count would select other tiles -- on ONE rank; with several ranks the constructor's count stands (a
+    re-capture contains collectives that all ranks would have to enter); without any count a packed batch is priced at its
+    allocated rows.
     adam_riders (one rank only; None = OFF unless MMT_ADAM_RIDERS=1): the optimizer inside the backward -- the step's Adam
     update is a queue of 4096-element units ordered by when their gradients are final, the GEMM launches of the
     backward carry it (blocks without a tile of their own -- idle CUs, the last partial round -- stream Adam's bytes beside
@@ -1182,7 +1184,10 @@ class GraphedTrainStep:
       if live_rows is not None and hasattr(self.model, 'live_rows_hint'):
         self.model.live_rows_hint = int(live_rows)
       return self.eager_step()
-    if live_rows is not None:
+    if live_rows is not None and not self._multi:
+      # (one rank only: a re-capture of the multi-rank step issues collectives -- the eager all-gather between its graphs --
+      # and only the ranks whose minibatch changed bucket would enter them; under data parallelism the tiles stay the ones of
+      # the constructor's count)
       sig = self._tile_signature(live_rows)
       if sig is not None and sig != self._sig:
         self._switch_tiles(sig, live_rows)
