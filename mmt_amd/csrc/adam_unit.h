@@ -127,7 +127,19 @@ constexpr int adam_rider_lds_bytes() { return 64 + (NT / 256) * MMT_RIDER_TILE_B
 #define MMT_RIDER_SUBTICKET0 (MMT_RIDER_STAT0 + 64)  // 64 first-level ticket words of mmt_adam_step_queue, one 256-byte line each
 static_assert(MMT_RIDER_STATE_WORDS == MMT_RIDER_SUBTICKET0 + 64 * 64, "queue state layout (include/mmt_hip.h)");
 
-// the hosting launch's own blocks report here when they are done (thread 0 of a finished block)
+// The hosting launch reports "my last round of tiles is ending" here: ONE block per launch does -- the first block of the last
+// round, thread 0, at the end of its K-loop (blocks of a round run in lock-step: one representative is enough).  r06's first
+// versions let EVERY block with a tile report: 232-696 agent-scope atomics on one word, all within a microsecond, are
+// serialised at ~30 ns each and the launch cannot end before its last one has -- +3...5 us on every hosting launch whatever
+// the riders did.  x index of the reporting block (its y index is 0):
+__device__ __forceinline__ int adam_rider_signal_x(int live_tiles, int gy, int slot_word) {
+  int resident = (slot_word >> 16) & 0xffff;
+  if (resident <= 0) resident = 256;
+  const int live_total = live_tiles * gy;
+  const int last_round = live_total > 0 ? ((live_total - 1) % resident) + 1 : 0;
+  const int first = live_tiles - (last_round + gy - 1) / gy;  // (blocks are numbered x-major within a y row: approximate for gy > 1)
+  return first > 0 ? first : 0;
+}
 __device__ __forceinline__ void adam_rider_host_done(const void* rider, int slot_word) {
   const MmtAdamQueue* q = (const MmtAdamQueue*)rider;
   __hip_atomic_fetch_add(q->state + MMT_RIDER_SLOT0 + (slot_word & 0xffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -183,7 +195,7 @@ __device__ __forceinline__ void adam_rider_run(const void* rider, int stages, in
   volatile int* ctl = (volatile int*)smem;
   float (*tile)[65] = (float (*)[65])(smem + 64 + grp * MMT_RIDER_TILE_BYTES);
   const int slot = slot_word & 0xffff;
-  const int thresh = live_total - last_round + 1;  // reports at which the last round is ending (>= 1 with live blocks)
+  const int thresh = 1;  // the launch's reporting block (adam_rider_signal_x) has reached the end of its K-loop
   const MmtAdamQueue* __restrict__ chain = qd->chain;
   const int chain_stages = chain ? qd->chain_stages : 0;
   if (stages > qd->n_stages) stages = qd->n_stages;

@@ -331,7 +331,9 @@ __device__ __forceinline__ void gemm2_body(
   if constexpr (PH) wait_vmcnt<0>();
   // (riders of this launch -- adam_unit.h -- stop claiming work when the first block of the last round gets here: the
   // epilogue that follows is the notice they need to finish the pass they are in)
-  if (epi.rider && tid == 0) adam_rider_host_done(epi.rider, epi.rider_slot);
+  if (epi.rider && tid == 0 && blockIdx.y == 0 && ((epi.rider_cap >> 12) & 15) == 0 &&
+      bid == adam_rider_signal_x(live_tiles, (int)gridDim.y, epi.rider_slot))
+    adam_rider_host_done(epi.rider, epi.rider_slot);
 #ifdef MMT_GEMM2_INSTR
   const long long t_loop_end = clock64();
 #endif
