@@ -312,6 +312,30 @@ def test_wgrad_grouped(live):
       _close('bias grad', bias, rb, 1e-3, 1e-5)
 
 
+@pytest.mark.parametrize('live', [None, 561, 64])
+def test_wgrad_grouped_short_contraction(live):
+  """A text-tower layer's weight gradients (432 tiles of 128x128, <= 1024 rows): the one-group kernel at two blocks per CU
+  (gemm.hip: wgrad_grouped_kernel<1>) against torch -- full and ragged live rows, bias gradients, garbage beyond the live rows."""
+  from mmt_amd import ops
+  rows, d, inter = 960, 768, 3072
+  shapes = [(3 * d, d), (d, d), (inter, d), (d, inter)]  # (N, K2): dWqkv, dWo, dW1, dW2
+  items, refs = [], []
+  n = rows if live is None else live
+  for i, (N, K2) in enumerate(shapes):
+    a = _rand((1024, N), seed=170 + i, dtype=torch.bfloat16)
+    b = _rand((1024, K2), 0.1, seed=180 + i, dtype=torch.bfloat16)
+    a[n:] = float('nan')
+    b[n:] = float('nan')
+    out, bias = torch.full((N, K2), 5.0, device=_dev()), torch.full((N,), 5.0, device=_dev())
+    items.append((a, b, out, bias))
+    refs.append((a[:n].float().t() @ b[:n].float(), a[:n].float().sum(0)))
+  nr = torch.tensor([n], device=_dev(), dtype=torch.int32)
+  ops.wgrad_grouped(items, rows, n_rows_dev=nr)
+  for (a, b, out, bias), (rw, rb) in zip(items, refs):
+    _close('wgrad short', out, rw, 6e-3, 3e-4)
+    _close('bias grad short', bias, rb, 2e-3, 1e-5)
+
+
 @pytest.mark.parametrize('d', [256, 512, 1024])
 def test_layernorm_fwd_bwd(d):
   from mmt_amd import ops
