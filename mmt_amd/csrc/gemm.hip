@@ -307,14 +307,9 @@ extern "C" int mmt_debug_set_wgrad_buffer(void* p) {
 #else
 #define WTICK(acc) do {} while (0)
 #endif
-// NG = 2: the kernel described above (512 threads, 128 KiB of LDS: one block per CU).  NG = 1 (r06): ONE group of four waves walks
-// every unit -- 256 threads, 64 KiB: two blocks per CU and no exchange at the end -- for SHORT contractions (the text tower: ~560
-// live rows = 9 units): there a launch's 432 tiles are all resident at once instead of taking two rounds of a kernel whose
-// prologue + exchange epilogue (15 k cycles) outweigh nine units of work.
-template <int NG>
-__global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g) {
+__global__ __launch_bounds__(512) void wgrad_grouped_kernel(MmtWgradGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-  bf16_t* smem = (bf16_t*)wg_smem;  // [2 stages][NG groups][A 64x128 | B 64x128]
+  bf16_t* smem = (bf16_t*)wg_smem;  // [2 stages][2 groups][A 64x128 | B 64x128]
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
 #pragma unroll 1
@@ -353,10 +348,10 @@ __global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g
   const int per_split = (units_all + nsplit - 1) / nsplit;
   const int u0 = split * per_split;
   const int units = max(0, min(units_all, u0 + per_split) - u0);
-  const int steps = (units + NG - 1) / NG;  // each step: group kg takes unit NG s + kg
+  const int steps = (units + 1) / 2;       // each step: group 0 takes unit 2s, group 1 unit 2s+1
 
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
-  const int kg = NG == 2 ? wave8 >> 2 : 0, wave = wave8 & 3;
+  const int kg = wave8 >> 2, wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   // bias gradient (column sums of the A operand) in the first tile column: the two waves that hold the same A fragments
@@ -373,10 +368,10 @@ __global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   constexpr int GSTAGE = 2 * 64 * 128;      // one group's [A | B] tiles
-  constexpr int TSTAGE = NG * GSTAGE;       // all groups
+  constexpr int TSTAGE = 2 * GSTAGE;        // both groups
 
   auto stage = [&](int step, int st) {
-    const int unit = NG * step + kg;
+    const int unit = 2 * step + kg;
     if (unit < units) {
       bf16_t* base = smem + st * TSTAGE + kg * GSTAGE;
       stage_tn(A, lda, (u0 + unit) * 64, n0, base, wave, lane);
@@ -395,11 +390,11 @@ __global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g
     WTICK(t_bar);
     if (s + 1 < steps) stage(s + 1, cur ^ 1);
     WTICK(t_issue);
-    const int unit = NG * s + kg;
+    const int unit = 2 * s + kg;
     bf16_t* at = smem + cur * TSTAGE + kg * GSTAGE;
     bf16_t* bt = at + 64 * 128;
     const int live = unit < units ? nrows - (u0 + unit) * 64 : 0;  // rows of this unit that exist (<= 0: nothing to do)
-    if (NG * s + NG - 1 >= units || nrows - (u0 + NG * s + NG - 1) * 64 < 64) {  // last step: ragged tails (block-uniform condition)
+    if (2 * s + 1 >= units || nrows - (u0 + 2 * s + 1) * 64 < 64) {  // last step: ragged tails (block-uniform condition)
       if (live > 0 && live < 64) {
         for (int e = wave * 64 + lane; e < (64 - live) * 32; e += 256) {
           const int r = live + e / 32, q = e % 32;
@@ -444,7 +439,6 @@ __global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g
   }
 #endif
   // ---- sum the two wave groups through LDS (group 1 -> group 0), then store ----
-  if constexpr (NG == 2) {
   __syncthreads();
   f32x4* xch = (f32x4*)wg_smem;  // [20][256] f32x4 = 80 KiB
   const int t4 = wave * 64 + lane;
@@ -463,7 +457,6 @@ __global__ __launch_bounds__(256 * NG) void wgrad_grouped_kernel(MmtWgradGroup g
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] += xch[(i * 4 + j) * 256 + t4];
     accb[i] += xch[(16 + i) * 256 + t4];
-  }
   }
   float* __restrict__ out = nsplit > 1 ? it.slab + (int64_t)split * it.N_out * it.ldo : it.out;
   float* __restrict__ bias_out = nsplit > 1 ? (it.bias_slab ? it.bias_slab + (int64_t)split * it.N_out : nullptr) : it.bias_out;
@@ -884,25 +877,16 @@ extern "C" int mmt_wgrad_grouped(const MmtWgradGroup* g, void* stream) {
   }
   constexpr int lds = 2 * 2 * 2 * 64 * 128 * 2;   // lock-step: 2 stages x 2 wave groups x (A + B) 64x128 bf16 = 128 KiB
   constexpr int lds_phased = 36 * 256 * 16;       // phased: the same 128 KiB ring; 144 KiB for the final exchange
-  static int lockstep = -1, short_rows = 1024;
+  static int lockstep = -1;
   if (lockstep < 0) {
-    hipError_t rc = hipFuncSetAttribute((const void*)wgrad_grouped_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (rc == hipSuccess)
-      rc = hipFuncSetAttribute((const void*)wgrad_grouped_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds / 2);
+    hipError_t rc = hipFuncSetAttribute((const void*)wgrad_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (rc == hipSuccess)
       rc = hipFuncSetAttribute((const void*)wgrad_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_phased);
     if (rc != hipSuccess) return (int)rc;
     const char* e = getenv("MMT_WGRAD_LOCKSTEP");
     lockstep = e ? atoi(e) : 0;
-    const char* r = getenv("MMT_WGRAD_SHORT_ROWS");  // (0 = never the short-contraction kernel)
-    if (r) short_rows = atoi(r);
   }
-  // r06: short contractions (every item over <= short_rows rows, nothing split: the text tower's layers) on the one-group
-  // kernel at two blocks per CU -- the launch is one round of resident tiles
-  bool is_short = h.rows <= short_rows && tiles > 256;
-  for (int q = 0; q < h.count && is_short; ++q) is_short = h.item[q].splits <= 1;
-  if (is_short) hipLaunchKernelGGL(wgrad_grouped_kernel<1>, dim3(tiles), dim3(256), lds / 2, (hipStream_t)stream, h);
-  else if (lockstep) hipLaunchKernelGGL(wgrad_grouped_kernel<2>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, h);
+  if (lockstep) hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, h);
   else hipLaunchKernelGGL(wgrad_phased_kernel, dim3(tiles), dim3(512), lds_phased, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }

@@ -314,8 +314,10 @@ def test_wgrad_grouped(live):
 
 @pytest.mark.parametrize('live', [None, 561, 64])
 def test_wgrad_grouped_short_contraction(live):
-  """A text-tower layer's weight gradients (432 tiles of 128x128, <= 1024 rows): the one-group kernel at two blocks per CU
-  (gemm.hip: wgrad_grouped_kernel<1>) against torch -- full and ragged live rows, bias gradients, garbage beyond the live rows."""
+  """A text-tower layer's weight gradients (432 tiles of 128x128 over <= 1024 rows: nine 64-row units, 1.7 tiles per CU)
+  against torch -- full and ragged live rows, bias gradients, garbage beyond the live rows.  (r06 tried a one-group lock-step
+  kernel at two blocks per CU for this shape: 39.4 us per launch against the phased kernel's 28.3, tower step 4.28 vs 4.16 ms;
+  reverted, profiles/r06_experiments.txt.)"""
   from mmt_amd import ops
   rows, d, inter = 960, 768, 3072
   shapes = [(3 * d, d), (d, d), (inter, d), (d, inter)]  # (N, K2): dWqkv, dWo, dW1, dW2
